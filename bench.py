@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""bench.py -- Gbases/s of `smooth W=101` over a 24-chromosome, 3.1 Gbp synthetic f64 signal
+(BASELINE.json metric, configs[1]) on N MI355X GPUs of one node, chromosomes sharded
+across ranks (LPT, no data-path collective).
+
+    python bench.py                                  # 1 GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A step is one pass of the hot path over the whole genome: one FIR launch per chromosome
+(libgenodsp_hip.so through its C ABI), inputs resident in HBM before the clock starts.
+Rank 0 prints ONE JSON line.  `value` = bases of all ranks / max-over-ranks step time.
+`roofline` is measured live with HIP events on the launch stream; `cpu_baseline` times the
+unmodified reference (oracle/_ref, kind "reference") or, when that build is absent, the
+CPU restatement (kind "port") on this host, rank 0 at N=1 only, on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# hg38-like chromosome lengths fixed by SURVEY.md Appendix D (sum 3 088 269 832)
+GENOME = [("chr1", 248956422), ("chr2", 242193529), ("chr3", 198295559), ("chr4", 190214555),
+          ("chr5", 181538259), ("chr6", 170805979), ("chr7", 159345973), ("chr8", 145138636),
+          ("chr9", 138394717), ("chr10", 133797422), ("chr11", 135086622), ("chr12", 133275309),
+          ("chr13", 114364328), ("chr14", 107043718), ("chr15", 101991189), ("chr16", 90338345),
+          ("chr17", 83257441), ("chr18", 80373285), ("chr19", 58617616), ("chr20", 64444167),
+          ("chr21", 46709983), ("chr22", 50818468), ("chrX", 156040895), ("chrY", 57227415)]
+SEED = 20240611
+WINDOW = 101
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+FP64_VALU_PEAK_TFLOPS = 78.6     # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+BYTES_PER_BASE = 16              # 8 B read + 8 B write per base for smooth
+
+
+def lpt_shards(lengths, nranks):
+    """Longest-processing-time greedy: chromosome index lists per rank."""
+    order = sorted(range(len(lengths)), key=lambda i: -lengths[i])
+    load = [0] * nranks
+    shards = [[] for _ in range(nranks)]
+    for i in order:
+        r = min(range(nranks), key=lambda k: load[k])
+        shards[r].append(i)
+        load[r] += lengths[i]
+    return shards
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--mode", choices=["fma", "exact"], default="fma",
+                    help="FIR arithmetic of the headline number (the other one is reported too)")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink every chromosome (debugging only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch one rank per GPU" % (args.gpus, world))
+
+    import torch
+    import genodsp_amd as gd
+
+    torch.cuda.set_device(local_rank)
+    gd.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    names = [c for c, _ in GENOME]
+    lengths = [max(1, int(n * args.scale)) for _, n in GENOME]
+    total_bases = sum(lengths)
+    mine = lpt_shards(lengths, world)[rank]
+
+    # ---- resident signal: in/out vector per chromosome of this rank, generated in HBM
+    stream = gd.Stream()
+    vin = {i: gd.DeviceVector(lengths[i]) for i in mine}
+    vout = {i: gd.DeviceVector(lengths[i]) for i in mine}
+    for i in mine:
+        gd.synth_coverage(SEED, i, 0, lengths[i], mode=1, out=vin[i], stream=stream.handle)
+    stream.sync()
+
+    def step(mode):
+        for i in mine:
+            gd.smooth(vin[i], WINDOW, out=vout[i], mode=mode, stream=stream.handle)
+
+    def timed(mode, steps, warmup):
+        for _ in range(warmup):
+            step(mode)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        e0, e1 = gd.Event(), gd.Event()
+        t0 = time.perf_counter()
+        e0.record(stream.handle)
+        for _ in range(steps):
+            step(mode)
+        e1.record(stream.handle)
+        torch.cuda.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+        wall_ms = (t1 - t0) * 1e3 / steps
+        dev_ms = e0.elapsed_ms(e1) / steps          # HIP events on the launch stream
+        if dist is not None:
+            t = torch.tensor([wall_ms, dev_ms], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall_ms, dev_ms = float(t[0]), float(t[1])
+        return wall_ms, dev_ms
+
+    head_mode = gd.FIR_FMA if args.mode == "fma" else gd.FIR_EXACT
+    other_mode = gd.FIR_EXACT if args.mode == "fma" else gd.FIR_FMA
+    wall_ms, dev_ms = timed(head_mode, args.steps, args.warmup)
+    o_wall_ms, o_dev_ms = timed(other_mode, max(1, args.steps // 2), 1)
+
+    # ---- parity spot check against the CPU oracle (checker only): sampled windows of the
+    #      longest local chromosome, exact mode must be bit-identical, fma within tolerance
+    parity = spot_check(gd, vin, vout, mine, lengths, stream)
+
+    def roofline(dev_ms_per_step):
+        # per launch: algorithmic bytes = 16 B/base x bases of that launch; averaged over the
+        # rank with the most bases (the one that sets the step time)
+        bases_rank = max(sum(lengths[i] for i in sh) for sh in lpt_shards(lengths, world))
+        launches = max(1, len(lpt_shards(lengths, world)[0]))
+        avg_launch_ms = dev_ms_per_step / launches
+        achieved = BYTES_PER_BASE * bases_rank / (dev_ms_per_step * 1e-3) / 1e9
+        flops = 2.0 * WINDOW * bases_rank / (dev_ms_per_step * 1e-3) / 1e12
+        return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(),
+                "kernel": "fir_fixed_kernel<101,9>", "avg_launch_ms": round(avg_launch_ms, 4),
+                "launches_per_step": launches,
+                "algorithmic_bytes_per_launch": int(BYTES_PER_BASE * bases_rank / launches),
+                "fp64_valu_tflops": round(flops, 2),
+                "fp64_valu_frac": round(flops / FP64_VALU_PEAK_TFLOPS, 4)}
+
+    result = {
+        "metric": "Gbases/sec on smooth W=101 over 3.1 Gbp",
+        "value": round(total_bases / (wall_ms * 1e-3) / 1e9, 2),
+        "unit": "Gbases/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(wall_ms, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "smooth W=101 on 24-chrom 3.1 Gbp synthetic signal (BASELINE configs[1])",
+                   "window": WINDOW, "chromosomes": len(GENOME), "bases": total_bases,
+                   "fir_mode": args.mode, "sharding": "whole chromosomes, LPT over ranks",
+                   "signal": "read-depth-like x U(0.5,1.5), seed %d" % SEED},
+        "roofline": roofline(dev_ms),
+        "other_mode": {"fir_mode": "exact" if args.mode == "fma" else "fma",
+                       "value": round(total_bases / (o_wall_ms * 1e-3) / 1e9, 2),
+                       "ms_per_step": round(o_wall_ms, 4), "roofline": roofline(o_dev_ms)},
+        "parity": parity,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(gd, lengths, names, stream)
+    barrier()
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def measured_traffic():
+    """HBM bytes per launch from the PMC passes committed under profiles/ (null until measured)."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            return json.load(f).get("fir_fixed_kernel_bytes_per_launch")
+    return None
+
+
+def spot_check(gd, vin, vout, mine, lengths, stream):
+    from oracle import cpu                           # the checker; never on the measured path
+    i = max(mine, key=lambda k: lengths[k])
+    n = lengths[i]
+    rng = np.random.default_rng(1)
+    half = (WINDOW - 1) // 2
+    starts = [0, max(0, n - 4096)] + [int(s) for s in rng.integers(0, max(1, n - 4096), 6)]
+    taps = cpu.hann_window(WINDOW)
+    out = {"chromosome": GENOME[i][0], "windows": len(starts), "window_len": min(4096, n)}
+    worst = 0.0
+    exact_ok = True
+    for mode, key in ((gd.FIR_EXACT, "exact"), (gd.FIR_FMA, "fma")):
+        gd.smooth(vin[i], WINDOW, out=vout[i], mode=mode, stream=stream.handle)
+        stream.sync()
+        for s in starts:
+            m = min(4096, n - s)
+            lo, hi = max(0, s - half), min(n, s + m + half)
+            x = cpu.synth_coverage(SEED, i, lo, hi - lo, 1)
+            xp = np.concatenate([np.zeros(half - (s - lo)), x, np.zeros(half - (hi - (s + m)))])
+            # zero-padded FIR of the padded stretch, then cut the m outputs that belong to [s, s+m)
+            want = cpu.fir(xp, taps)[half:half + m] if xp.size > 2 * half else cpu.fir(xp, taps)
+            got = vout[i].buf.download(np.float64, m, vout[i].offset + 8 * s)
+            if key == "exact":
+                exact_ok = exact_ok and (got.tobytes() == want.tobytes())
+            else:
+                scale = cpu.fir(np.abs(xp), taps)[half:half + m]
+                bound = WINDOW * 2.0 ** -52 * scale
+                worst = max(worst, float(np.max(np.abs(got - want) / np.maximum(bound, 1e-300))))
+    out["exact_bit_identical"] = bool(exact_ok)
+    out["fma_worst_err_over_bound"] = round(worst, 4)
+    out["ok"] = bool(exact_ok and worst <= 1.0)
+    return out
+
+
+def cpu_baseline(gd, lengths, names, stream):
+    """Time the CPU path on a bounded sample: smooth W=101 over chr21 + chr22 (97.5 Mbp at
+    full scale), one thread, the same synthetic signal copied back from HBM."""
+    from oracle import cpu, ref
+    sample = [names.index("chr21"), names.index("chr22")]
+    vecs = {}
+    for i in sample:
+        d = gd.synth_coverage(SEED, i, 0, lengths[i], mode=1, stream=stream.handle)
+        stream.sync()
+        vecs[i] = d.numpy()
+    bases = sum(lengths[i] for i in sample)
+    if ref.available():
+        g = ref.Genome([(names[i], lengths[i]) for i in sample])
+        for i in sample:
+            g.set(names[i], vecs[i])
+        t0 = time.perf_counter()
+        g.run("= smooth W=%d" % WINDOW)
+        dt = time.perf_counter() - t0
+        outs = {i: g.get(names[i]) for i in sample}
+        g.close()
+        kind = "reference"
+    else:
+        t0 = time.perf_counter()
+        outs = {i: cpu.smooth(vecs[i], WINDOW) for i in sample}
+        dt = time.perf_counter() - t0
+        kind = "port"
+    # the same chromosomes through the HIP path in exact mode must match every bit
+    same = True
+    for i in sample:
+        d = gd.DeviceVector.from_numpy(vecs[i])
+        got = gd.smooth(d, WINDOW, mode=gd.FIR_EXACT, stream=stream.handle).numpy()
+        same = same and (got.tobytes() == outs[i].tobytes())
+    return {"value": round(bases / dt / 1e9, 5), "unit": "Gbases/s", "cores": 1, "kind": kind,
+            "sample": "smooth W=101 on chr21+chr22 (%d bases) of the same synthetic signal, %.1f s"
+                      % (bases, dt),
+            "hip_exact_bit_identical_on_sample": bool(same)}
+
+
+if __name__ == "__main__":
+    main()

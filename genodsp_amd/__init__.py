@@ -1,0 +1,419 @@
+"""genodsp_amd -- MI355X-native genomic-signal DSP (genodsp-compatible hot path).
+
+This package is the thin Python face of the C ABI in include/genodsp_hip.h
+(genodsp_amd/libgenodsp_hip.so: hand-written HIP kernels for gfx950).  It exists
+for tests and bench.py; the drop-in product is the C library plus the C host
+driver under genodsp_amd/host/.  There is no CPU fallback anywhere in here.
+
+    import genodsp_amd as gd
+    v = gd.DeviceVector.from_numpy(x)        # f64 chromosome vector in HBM
+    out = gd.smooth(v, 101)                  # op_smooth_apply, sum.c:616-676
+    out.numpy()
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import GdspError, SIGNATURES, SO_PATH, build, call, lib
+
+FIR_EXACT, FIR_FMA = 0, 1
+OVERLAP_SUM, OVERLAP_MIN, OVERLAP_MAX = 0, 1, 2
+DBL_MAX = float(np.finfo(np.float64).max)
+DBL_MIN = float(np.finfo(np.float64).tiny)
+
+
+def device_count():
+    n = C.c_int(0)
+    call("gdsp_device_count", C.byref(n))
+    return n.value
+
+
+def set_device(i):
+    call("gdsp_set_device", int(i))
+
+
+def _sp(stream):
+    return C.c_void_p(stream) if stream else None
+
+
+class Stream:
+    def __init__(self):
+        h = C.c_void_p()
+        call("gdsp_stream_create", C.byref(h))
+        self.handle = h.value
+
+    def sync(self):
+        call("gdsp_stream_sync", C.c_void_p(self.handle))
+
+    def close(self):
+        if self.handle:
+            call("gdsp_stream_destroy", C.c_void_p(self.handle))
+            self.handle = None
+
+
+def sync(stream=None):
+    call("gdsp_stream_sync", _sp(stream))
+
+
+class Event:
+    def __init__(self):
+        h = C.c_void_p()
+        call("gdsp_event_create", C.byref(h))
+        self.handle = h.value
+
+    def record(self, stream=None):
+        call("gdsp_event_record", C.c_void_p(self.handle), _sp(stream))
+
+    def elapsed_ms(self, later):
+        ms = C.c_float()
+        call("gdsp_event_elapsed_ms", C.c_void_p(self.handle), C.c_void_p(later.handle), C.byref(ms))
+        return ms.value
+
+
+class DeviceBuffer:
+    """Raw HBM allocation (hipMalloc), 256-byte aligned."""
+
+    def __init__(self, nbytes):
+        p = C.c_void_p()
+        call("gdsp_malloc", C.byref(p), int(nbytes))
+        self.ptr = p.value
+        self.nbytes = int(nbytes)
+
+    def free(self):
+        if self.ptr:
+            call("gdsp_free", C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def upload(self, arr, offset=0, stream=None):
+        arr = np.ascontiguousarray(arr)
+        assert offset + arr.nbytes <= self.nbytes
+        call("gdsp_memcpy_h2d", C.c_void_p(self.ptr + offset), arr.ctypes.data_as(C.c_void_p), arr.nbytes, _sp(stream))
+        sync(stream)
+
+    def download(self, dtype, count, offset=0, stream=None):
+        out = np.empty(count, dtype)
+        assert offset + out.nbytes <= self.nbytes
+        call("gdsp_memcpy_d2h", out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr + offset), out.nbytes, _sp(stream))
+        sync(stream)
+        return out
+
+
+class DeviceVector:
+    """A chromosome's worth of f64 values in HBM (the reference's spec.valVector)."""
+
+    def __init__(self, n, buf=None, offset=0):
+        self.n = int(n)
+        self.buf = buf if buf is not None else DeviceBuffer(max(self.n, 2) * 8)
+        self.offset = offset
+        assert offset % 16 == 0
+
+    @property
+    def ptr(self):
+        return C.c_void_p(self.buf.ptr + self.offset)
+
+    @classmethod
+    def from_numpy(cls, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        v = cls(arr.size)
+        if arr.size:
+            v.buf.upload(arr, v.offset)
+        return v
+
+    def numpy(self):
+        return self.buf.download(np.float64, self.n, self.offset)
+
+    def like(self):
+        return DeviceVector(self.n)
+
+    def copy(self, stream=None):
+        out = self.like()
+        if self.n:
+            call("gdsp_memcpy_d2d", out.ptr, self.ptr, self.n * 8, _sp(stream))
+        return out
+
+
+def _dev_array(arr, dtype):
+    arr = np.ascontiguousarray(arr, dtype=dtype)
+    buf = DeviceBuffer(max(arr.nbytes, 16))
+    if arr.nbytes:
+        buf.upload(arr)
+    return buf
+
+
+# ----------------------------------------------------------------- sum.c ----
+
+def hann_taps(W):
+    w = np.empty(W, np.float64)
+    call("gdsp_hann_taps", W, w.ctypes.data_as(C.c_void_p))
+    return w
+
+
+class FirPlan:
+    def __init__(self, taps):
+        taps = np.ascontiguousarray(taps, dtype=np.float64)
+        h = C.c_void_p()
+        call("gdsp_fir_plan_create", C.byref(h), taps.ctypes.data_as(C.c_void_p), taps.size)
+        self.handle = h.value
+        self.W = taps.size
+
+    def apply(self, v, out=None, mode=FIR_EXACT, stream=None):
+        out = out if out is not None else v.like()
+        call("gdsp_fir_apply", C.c_void_p(self.handle), v.ptr, out.ptr, v.n, mode, _sp(stream))
+        return out
+
+    def close(self):
+        if self.handle:
+            call("gdsp_fir_plan_destroy", C.c_void_p(self.handle))
+            self.handle = None
+
+
+def smooth(v, W=101, out=None, mode=FIR_EXACT, stream=None):
+    out = out if out is not None else v.like()
+    call("gdsp_smooth", v.ptr, out.ptr, v.n, W, mode, _sp(stream))
+    return out
+
+
+def sliding_sum(v, W, denom=1.0, out=None, stream=None):
+    out = out if out is not None else v.like()
+    call("gdsp_sliding_sum", v.ptr, out.ptr, v.n, W, float(denom), _sp(stream))
+    return out
+
+
+def window_sum(v, W, denom=1.0, use_actual=False, zero=0.0, stream=None):
+    call("gdsp_window_sum", v.ptr, v.n, W, float(denom), int(use_actual), float(zero), _sp(stream))
+    return v
+
+
+def cumulative_sum(v, stream=None):
+    work = DeviceBuffer(lib().gdsp_cumulative_sum_work(v.n))
+    call("gdsp_cumulative_sum", v.ptr, v.n, C.c_void_p(work.ptr), _sp(stream))
+    sync(stream)
+    return v
+
+
+# -------------------------------------------------------------- minmax.c ----
+
+def local_extrema(v, N, want_max, fill, out=None, stream=None):
+    out = out if out is not None else v.like()
+    call("gdsp_local_extrema", v.ptr, out.ptr, v.n, N, int(want_max), float(fill), _sp(stream))
+    return out
+
+
+def localmax(v, N=3, zero=0.0, **kw):
+    return local_extrema(v, N, True, zero, **kw)
+
+
+def localmin(v, N=3, infinity=DBL_MAX, **kw):
+    return local_extrema(v, N, False, infinity, **kw)
+
+
+def best_extrema(v, W, want_max, out=None, stream=None):
+    out = out if out is not None else v.like()
+    call("gdsp_best_extrema", v.ptr, out.ptr, v.n, W, int(want_max), _sp(stream))
+    return out
+
+
+# ---------------------------------------------------------- morphology.c ----
+
+def split_length(length):
+    """dilate/erode <length> -> (left, right), morphology.c:917-920 / :1369-1372."""
+    left = int(float(length) / 2)
+    return left, int(length) - left
+
+
+def dilate(v, left, right, T=0.0, one=1.0, zero=0.0, out=None, stream=None):
+    out = out if out is not None else v.like()
+    call("gdsp_dilate", v.ptr, out.ptr, v.n, left, right, float(T), float(one), float(zero), _sp(stream))
+    return out
+
+
+def erode(v, left, right, T=0.0, one=1.0, zero=0.0, out=None, stream=None):
+    out = out if out is not None else v.like()
+    call("gdsp_erode", v.ptr, out.ptr, v.n, left, right, float(T), float(one), float(zero), _sp(stream))
+    return out
+
+
+def close(v, length, T=0.0, one=1.0, zero=0.0, out=None, stream=None):
+    out = out if out is not None else v.like()
+    call("gdsp_close", v.ptr, out.ptr, v.n, float(length), float(T), float(one), float(zero), _sp(stream))
+    return out
+
+
+def open_(v, length, T=0.0, one=1.0, zero=0.0, out=None, stream=None):
+    out = out if out is not None else v.like()
+    call("gdsp_open", v.ptr, out.ptr, v.n, float(length), float(T), float(one), float(zero), _sp(stream))
+    return out
+
+
+# --------------------------------------------- logical.c, mask.c, add.c ----
+
+def binarize(v, T=0.0, ties_above=False, one=1.0, zero=0.0, stream=None):
+    call("gdsp_binarize", v.ptr, v.n, float(T), int(ties_above), float(one), float(zero), _sp(stream))
+    return v
+
+
+def clip(v, lo=None, hi=None, stream=None):
+    call("gdsp_clip", v.ptr, v.n, lo is not None, 0.0 if lo is None else float(lo),
+         hi is not None, 0.0 if hi is None else float(hi), _sp(stream))
+    return v
+
+
+def erase(v, lo=None, hi=None, keep_inside=False, zero=0.0, stream=None):
+    call("gdsp_erase", v.ptr, v.n, lo is not None, 0.0 if lo is None else float(lo),
+         hi is not None, 0.0 if hi is None else float(hi), int(keep_inside), float(zero), _sp(stream))
+    return v
+
+
+def add_constant(v, c, stream=None):
+    call("gdsp_add_constant", v.ptr, v.n, float(c), _sp(stream))
+    return v
+
+
+def abs_(v, stream=None):
+    call("gdsp_abs", v.ptr, v.n, _sp(stream))
+    return v
+
+
+def invert(v, mid, stream=None):
+    call("gdsp_invert", v.ptr, v.n, float(mid), _sp(stream))
+    return v
+
+
+def fill(v, val, stream=None):
+    call("gdsp_fill", v.ptr, v.n, float(val), _sp(stream))
+    return v
+
+
+def genome_minmax(vecs, window=1, lo=-DBL_MAX, hi=DBL_MAX, stream=None):
+    """(min, max, count) over the sampled values of all vectors."""
+    acc = DeviceBuffer(32)
+    call("gdsp_minmax_init", C.c_void_p(acc.ptr), _sp(stream))
+    for v in vecs:
+        call("gdsp_minmax_update", v.ptr, v.n, window, float(lo), float(hi), C.c_void_p(acc.ptr), _sp(stream))
+    r = acc.download(np.float64, 3, stream=stream)
+    return float(r[0]), float(r[1]), int(r[2])
+
+
+# ---------------------------------------------------------- percentile.c ----
+
+# digit schedule over the 64-bit key: sign+exponent first, then the mantissa
+SELECT_DIGITS = [(52, 12), (39, 13), (26, 13), (13, 13), (0, 13)]
+
+
+def percentile(vecs, p_thousandths, window=1, lo=-DBL_MAX, hi=DBL_MAX, allreduce=None, stream=None):
+    """Exact percentiles of the sampled genome (percentile.c:392-751), non-destructive.
+
+    vecs: this rank's chromosome vectors.  allreduce(np_u64_array, op) -> array sums
+    ("sum") or min/maxes ("min"/"max") over ranks; None on a single GPU.
+    Returns (count, [values])."""
+    L = lib()
+    results = []
+    count = None
+    first = None           # the prefix-free first pass is shared by every requested percentile
+    for pt in p_thousandths:
+        prefix = 0
+        value = None
+        k = None
+        for di, (shift, bits) in enumerate(SELECT_DIGITS):
+            nb = 1 << bits
+            if di == 0 and first is not None:
+                hist = first
+            else:
+                dh = DeviceBuffer((nb + 2) * 8)
+                call("gdsp_select_hist_init", C.c_void_p(dh.ptr), bits, _sp(stream))
+                for v in vecs:
+                    call("gdsp_select_histogram", v.ptr, v.n, window, float(lo), float(hi), shift, bits,
+                         C.c_uint64(prefix), C.c_void_p(dh.ptr), _sp(stream))
+                hist = dh.download(np.uint64, nb + 2, stream=stream)
+                if allreduce is not None:
+                    hist[:nb] = allreduce(hist[:nb].copy(), "sum")
+                    hist[nb:nb + 1] = allreduce(hist[nb:nb + 1].copy(), "min")
+                    hist[nb + 1:] = allreduce(hist[nb + 1:].copy(), "max")
+                if di == 0:
+                    first = hist
+            if di == 0:
+                count = int(hist[:nb].sum())
+                if count == 0:
+                    return 0, []
+                k = L.gdsp_percentile_rank(count, int(pt))
+            if hist[nb] == hist[nb + 1]:           # one distinct candidate left
+                value = L.gdsp_key_to_double(int(hist[nb]))
+                break
+            b, kw = C.c_uint32(), C.c_uint64()
+            call("gdsp_select_pick", hist.ctypes.data_as(C.c_void_p), bits, C.c_uint64(k), C.byref(b), C.byref(kw))
+            prefix |= b.value << shift
+            k = kw.value
+        if value is None:
+            value = L.gdsp_key_to_double(prefix)
+        results.append(value)
+    return count, results
+
+
+# ------------------------------------- genodsp.c / add.c / multiply.c ------
+
+class BinnedIntervals:
+    """Intervals of one chromosome, staged on the device with their tile CSR."""
+
+    def __init__(self, n, start, end, val):
+        start = np.ascontiguousarray(start, np.uint32)
+        end = np.ascontiguousarray(end, np.uint32)
+        val = np.ascontiguousarray(val, np.float64)
+        tile = lib().gdsp_interval_tile()
+        ntiles = (n + tile - 1) // tile
+        offsets = np.zeros(ntiles + 1, np.uint32)
+        length = C.c_uint64()
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        call("gdsp_bin_intervals", n, vp(start), vp(end), start.size, vp(offsets), None, C.byref(length))
+        tlist = np.zeros(max(length.value, 1), np.uint32)
+        call("gdsp_bin_intervals", n, vp(start), vp(end), start.size, vp(offsets), vp(tlist), C.byref(length))
+        self.n = n
+        self.d_start = _dev_array(start, np.uint32)
+        self.d_end = _dev_array(end, np.uint32)
+        self.d_val = _dev_array(val, np.float64)
+        self.d_offsets = _dev_array(offsets, np.uint32)
+        self.d_list = _dev_array(tlist, np.uint32)
+
+    def _args(self):
+        return [C.c_void_p(b.ptr) for b in (self.d_start, self.d_end, self.d_val, self.d_offsets, self.d_list)]
+
+
+def apply_intervals(v, start, end, val, overlap=OVERLAP_SUM, clear=False, missing=0.0, stream=None):
+    b = BinnedIntervals(v.n, start, end, val)
+    call("gdsp_apply_intervals", v.ptr, v.n, *b._args(), overlap, int(clear), float(missing), _sp(stream))
+    sync(stream)
+    return v
+
+
+def scale_intervals(v, start, end, val, divide=False, infinity=DBL_MAX, stream=None):
+    b = BinnedIntervals(v.n, start, end, val)
+    call("gdsp_scale_intervals", v.ptr, v.n, *b._args(), int(divide), float(infinity), _sp(stream))
+    sync(stream)
+    return v
+
+
+def report_runs(v, collapse=True, uncovered=0, stream=None):
+    """(start, end, value) arrays of the runs report_intervals would print."""
+    work = DeviceBuffer(lib().gdsp_report_runs_work(v.n))
+    cnt = DeviceBuffer(16)
+    call("gdsp_report_runs", v.ptr, v.n, int(collapse), uncovered, None, None, None, 0,
+         C.c_void_p(cnt.ptr), C.c_void_p(work.ptr), _sp(stream))
+    n = int(cnt.download(np.uint32, 1, stream=stream)[0])
+    if n == 0:
+        return np.empty(0, np.uint32), np.empty(0, np.uint32), np.empty(0, np.float64)
+    s, e, x = DeviceBuffer(n * 4), DeviceBuffer(n * 4), DeviceBuffer(n * 8)
+    call("gdsp_report_runs", v.ptr, v.n, int(collapse), uncovered, C.c_void_p(s.ptr), C.c_void_p(e.ptr),
+         C.c_void_p(x.ptr), n, C.c_void_p(cnt.ptr), C.c_void_p(work.ptr), _sp(stream))
+    return (s.download(np.uint32, n, stream=stream), e.download(np.uint32, n, stream=stream),
+            x.download(np.float64, n, stream=stream))
+
+
+def synth_coverage(seed, chrom_index, start, count, mode=0, out=None, stream=None):
+    out = out if out is not None else DeviceVector(count)
+    call("gdsp_synth_coverage", out.ptr, C.c_uint64(seed), chrom_index, start, count, mode, _sp(stream))
+    return out

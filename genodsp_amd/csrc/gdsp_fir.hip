@@ -1,0 +1,356 @@
+// gdsp_fir.hip -- zero-padded direct FIR over one chromosome (the `smooth` operator).
+//
+// Replaces the hot loop of op_smooth_apply, sum.c:651-663 in the reference:
+//     out[ix] = sum over taps k (ascending) of taps[k] * v[ix - hOff + k]
+// with taps outside [0,n) skipped.  Skipping a tap and adding taps[k]*(+0.0) give
+// the same bits (the running sum starts at +0.0 and can never become -0.0), so
+// the kernels stage a zero-padded tile and run the full tap range everywhere.
+//
+// Shape of the work on MI355X.  W=101 taps on f64 is 101 multiply-adds against
+// 16 bytes per base: the FP64 vector pipe (16 lanes/clk/SIMD), not HBM, is the
+// first limit, so the kernel is organised around keeping that pipe issuing:
+//   * one workgroup = 256 threads = one tile of 256*R consecutive outputs,
+//     staged once into LDS with its (W-1) halo by 16-byte coalesced loads;
+//   * each thread owns R *consecutive* outputs and walks its R+W-1 inputs once:
+//     one ds_read_b64 feeds up to R multiply-adds, so LDS traffic is ~1/R of the
+//     arithmetic.  R is odd: lane stride = R doubles = 2R dwords, and 2R*t mod 64
+//     is distinct for the 32 lanes of a ds_read_b64 group only when R is odd --
+//     no padding, no swizzle, the LDS image stays linear;
+//   * taps are wave-uniform: they sit in the kernarg segment and reach the VALU
+//     as SGPR operands, costing no vector registers and no LDS reads;
+//   * results go back through LDS so that the global store is 16 bytes per lane,
+//     fully coalesced, instead of R strided 8-byte stores per lane.
+// EXACT mode issues v_mul_f64 + v_add_f64 per tap (bit-identical to the
+// reference's unfused x86 loop); FMA mode issues one v_fma_f64 per tap.
+// This translation unit is compiled with -ffp-contract=off so that only the
+// explicit __builtin_fma is ever fused.
+
+#include <math.h>
+#include <string.h>
+#include <stdlib.h>
+#include <mutex>
+#include "gdsp_common.h"
+
+#define FIR_THREADS 256
+#define FIR_R       9            // outputs per thread (odd, see above)
+#define FIR_KC_MAX  1026         // taps per LDS stage in the generic kernel (multiple of FIR_R)
+
+template <int W> struct FirTaps { double w[W]; };
+
+// ------------------------------------------------------------------ store ----
+// Tile results: registers -> LDS (lane-strided, conflict-free for odd R) ->
+// coalesced 16-byte global stores.  Caller has already synchronised after the
+// last read of the staged inputs.
+template <int R>
+__device__ __forceinline__ void fir_store_tile (double* lds, const double (&acc)[R],
+                                                double* __restrict__ out, int64_t tileStart, uint32_t n)
+	{
+	constexpr int T = FIR_THREADS * R;
+	double* mine = lds + threadIdx.x * R;
+#pragma unroll
+	for (int r=0 ; r<R ; r++) mine[r] = acc[r];
+	__syncthreads ();
+
+	if (tileStart + T <= (int64_t) n)
+		{
+		double2*       dst = reinterpret_cast<double2*> (out + tileStart);
+		const double2* src = reinterpret_cast<const double2*> (lds);
+#pragma unroll
+		for (int i=0 ; i<(T/2 + FIR_THREADS - 1)/FIR_THREADS ; i++)
+			{
+			int p = threadIdx.x + i*FIR_THREADS;
+			if (p < T/2) dst[p] = src[p];
+			}
+		}
+	else
+		{
+		for (int p=threadIdx.x ; p<T ; p+=FIR_THREADS)
+			{ if (tileStart + p < (int64_t) n) out[tileStart+p] = lds[p]; }
+		}
+	}
+
+// ---------------------------------------------------- compile-time W kernel ----
+template <int W, int R, bool FMA>
+__global__ __launch_bounds__(FIR_THREADS)
+void fir_fixed_kernel (const double* __restrict__ in, double* __restrict__ out,
+                       uint32_t n, uint32_t ntiles, FirTaps<W> taps)
+	{
+	constexpr int H  = (W - 1) / 2;
+	constexpr int T  = FIR_THREADS * R;
+	constexpr int SH = H & 1;                 // keeps the first staged index even
+	constexpr int L  = T + W - 1 + SH;
+	constexpr int LP = (L + 1) & ~1;
+	__shared__ __attribute__((aligned(16))) double lds[LP];
+
+	const uint32_t tile      = gdsp_xcd_tile (blockIdx.x, ntiles);
+	const int64_t  tileStart = (int64_t) tile * T;
+	const int64_t  g0        = tileStart - H - SH;
+
+	// stage tile + halo
+	if ((g0 >= 0) && (g0 + LP <= (int64_t) n))
+		{
+		const double2* src = reinterpret_cast<const double2*> (in + g0);
+		double2*       dst = reinterpret_cast<double2*> (lds);
+#pragma unroll
+		for (int i=0 ; i<(LP/2 + FIR_THREADS - 1)/FIR_THREADS ; i++)
+			{
+			int p = threadIdx.x + i*FIR_THREADS;
+			if (p < LP/2) dst[p] = src[p];
+			}
+		}
+	else
+		{
+		for (int p=threadIdx.x ; p<LP ; p+=FIR_THREADS)
+			{
+			int64_t g = g0 + p;
+			lds[p] = ((g >= 0) && (g < (int64_t) n))? in[g] : 0.0;
+			}
+		}
+	__syncthreads ();
+
+	// R outputs per thread; input j of this thread meets tap k=j-r of output r
+	const double* x = lds + SH + threadIdx.x * R;
+	double acc[R];
+#pragma unroll
+	for (int r=0 ; r<R ; r++) acc[r] = 0.0;
+
+#pragma unroll
+	for (int j=0 ; j<R+W-1 ; j++)
+		{
+		const double xv = x[j];
+#pragma unroll
+		for (int r=0 ; r<R ; r++)
+			{
+			const int k = j - r;
+			if ((k >= 0) && (k < W))
+				{
+				if (FMA) acc[r] = __builtin_fma (taps.w[k], xv, acc[r]);
+				else     acc[r] = acc[r] + taps.w[k] * xv;
+				}
+			}
+		}
+
+	__syncthreads ();
+	fir_store_tile<R> (lds, acc, out, tileStart, n);
+	}
+
+// --------------------------------------------------------- run-time W kernel ----
+// Any odd W (up to the reference's 50001, sum.c:478).  Taps are walked in stages
+// of at most KC so the LDS image stays small; the accumulators live in registers
+// across stages, so every output still sums its taps in ascending order.
+template <int R, bool FMA>
+__global__ __launch_bounds__(FIR_THREADS)
+void fir_generic_kernel (const double* __restrict__ in, double* __restrict__ out,
+                         uint32_t n, uint32_t ntiles,
+                         const double* __restrict__ taps, uint32_t W, uint32_t KC)
+	{
+	extern __shared__ __attribute__((aligned(16))) double ldsDyn[];
+	constexpr int T = FIR_THREADS * R;
+
+	const uint32_t tile      = gdsp_xcd_tile (blockIdx.x, ntiles);
+	const int64_t  tileStart = (int64_t) tile * T;
+	const int64_t  H         = (W - 1) / 2;
+
+	double acc[R];
+#pragma unroll
+	for (int r=0 ; r<R ; r++) acc[r] = 0.0;
+
+	for (uint32_t k0=0 ; k0<W ; k0+=KC)
+		{
+		const uint32_t kc  = (W - k0 < KC)? (W - k0) : KC;
+		const uint32_t kcR = ((kc + R - 1) / R) * R;
+		const int64_t  gA  = tileStart - H + k0;          // global index of this stage's first input
+		const int      sh  = (int) (gA & 1);               // (gA may be negative: & 1 is still its parity)
+		const int64_t  g0  = gA - sh;
+		const int      L   = (T + (int) kcR + R + sh + 1) & ~1;
+
+		if (k0 != 0) __syncthreads ();
+		if ((g0 >= 0) && (g0 + L <= (int64_t) n))
+			{
+			const double2* src = reinterpret_cast<const double2*> (in + g0);
+			double2*       dst = reinterpret_cast<double2*> (ldsDyn);
+			for (int p=threadIdx.x ; p<L/2 ; p+=FIR_THREADS) dst[p] = src[p];
+			}
+		else
+			{
+			for (int p=threadIdx.x ; p<L ; p+=FIR_THREADS)
+				{
+				int64_t g = g0 + p;
+				ldsDyn[p] = ((g >= 0) && (g < (int64_t) n))? in[g] : 0.0;
+				}
+			}
+		__syncthreads ();
+
+		const double* x = ldsDyn + sh + threadIdx.x * R;
+		double xw[2*R];
+#pragma unroll
+		for (int r=0 ; r<R ; r++) xw[r] = x[r];
+
+		for (uint32_t kb=0 ; kb<kc ; kb+=R)
+			{
+#pragma unroll
+			for (int r=0 ; r<R ; r++) xw[R+r] = x[kb+R+r];
+#pragma unroll
+			for (int kk=0 ; kk<R ; kk++)
+				{
+				if (kb + kk < kc)                          // wave-uniform
+					{
+					const double w = taps[k0+kb+kk];
+#pragma unroll
+					for (int r=0 ; r<R ; r++)
+						{
+						if (FMA) acc[r] = __builtin_fma (w, xw[r+kk], acc[r]);
+						else     acc[r] = acc[r] + w * xw[r+kk];
+						}
+					}
+				}
+#pragma unroll
+			for (int r=0 ; r<R ; r++) xw[r] = xw[R+r];
+			}
+		}
+
+	__syncthreads ();
+	fir_store_tile<R> (ldsDyn, acc, out, tileStart, n);
+	}
+
+// ------------------------------------------------------------------- host ----
+
+struct gdsp_fir_plan
+	{
+	uint32_t W;
+	double*  h_taps;     // W values
+	double*  d_taps;     // W values + padding, device
+	};
+
+extern "C" {
+
+// Hann taps exactly as the reference builds them (sum.c:632-645): mirrored
+// store of (1-cos(2*pi*x))/2 for x=(k+1)/(W+1), ascending sum, divide.
+int gdsp_hann_taps (uint32_t W, double* h_taps)
+	{
+	GDSP_REQUIRE (h_taps != NULL, "h_taps is NULL");
+	GDSP_REQUIRE ((W >= 3) && (W & 1), "W must be odd and >= 3");
+	const uint32_t hOff = (W - 1) / 2;
+	const double   pi   = 3.14159265358979323846264;
+	for (uint32_t k=0 ; k<=hOff ; k++)
+		{
+		double x = (k+1) / (double) (W+1);
+		h_taps[k] = h_taps[W-1-k] = (1 - cos (2*pi*x)) / 2;
+		}
+	double total = 0.0;
+	for (uint32_t k=0 ; k<W ; k++) total += h_taps[k];
+	for (uint32_t k=0 ; k<W ; k++) h_taps[k] /= total;
+	return GDSP_OK;
+	}
+
+int gdsp_fir_plan_create (gdsp_fir_plan** plan, const double* h_taps, uint32_t W)
+	{
+	GDSP_REQUIRE (plan != NULL, "plan is NULL");
+	GDSP_REQUIRE (h_taps != NULL, "h_taps is NULL");
+	GDSP_REQUIRE ((W >= 1) && (W & 1), "W must be odd");
+	gdsp_fir_plan* p = (gdsp_fir_plan*) calloc (1, sizeof(gdsp_fir_plan));
+	if (p == NULL) { gdsp_set_error ("out of host memory");  return GDSP_ENOMEM; }
+	p->W = W;
+	p->h_taps = (double*) malloc ((size_t) W * sizeof(double));
+	if (p->h_taps == NULL) { free (p);  gdsp_set_error ("out of host memory");  return GDSP_ENOMEM; }
+	memcpy (p->h_taps, h_taps, (size_t) W * sizeof(double));
+	size_t padded = (size_t) W + 2*FIR_R;
+	hipError_t e = hipMalloc ((void**) &p->d_taps, padded * sizeof(double));
+	if (e != hipSuccess) { free (p->h_taps);  free (p);  GDSP_HIP_TRY (e); }
+	e = hipMemset (p->d_taps, 0, padded * sizeof(double));
+	if (e == hipSuccess) e = hipMemcpy (p->d_taps, h_taps, (size_t) W * sizeof(double), hipMemcpyHostToDevice);
+	if (e != hipSuccess) { (void) hipFree (p->d_taps);  free (p->h_taps);  free (p);  GDSP_HIP_TRY (e); }
+	*plan = p;
+	return GDSP_OK;
+	}
+
+int gdsp_fir_plan_destroy (gdsp_fir_plan* plan)
+	{
+	if (plan == NULL) return GDSP_OK;
+	hipError_t e = hipFree (plan->d_taps);
+	free (plan->h_taps);
+	free (plan);
+	GDSP_HIP_TRY (e);
+	return GDSP_OK;
+	}
+
+int gdsp_fir_apply (const gdsp_fir_plan* plan, const double* d_in, double* d_out,
+                    uint32_t n, int mode, void* stream)
+	{
+	GDSP_REQUIRE (plan != NULL, "plan is NULL");
+	GDSP_REQUIRE ((mode == GDSP_FIR_EXACT) || (mode == GDSP_FIR_FMA), "unknown mode");
+	if (n == 0) return GDSP_OK;
+	GDSP_REQUIRE ((d_in != NULL) && (d_out != NULL), "NULL vector");
+	GDSP_REQUIRE (d_in != d_out, "FIR is out-of-place: d_out must not alias d_in");
+	GDSP_REQUIRE (gdsp_aligned16 (d_in) && gdsp_aligned16 (d_out), "vectors must be 16-byte aligned");
+
+	constexpr int  T = FIR_THREADS * FIR_R;
+	const uint32_t ntiles = (uint32_t) (((uint64_t) n + T - 1) / T);
+	hipStream_t    s = gdsp_stream (stream);
+
+	if (plan->W == 101)
+		{
+		FirTaps<101> taps;
+		memcpy (taps.w, plan->h_taps, sizeof(taps.w));
+		if (mode == GDSP_FIR_FMA)
+			hipLaunchKernelGGL ((fir_fixed_kernel<101, FIR_R, true>),  dim3(ntiles), dim3(FIR_THREADS), 0, s,
+			                    d_in, d_out, n, ntiles, taps);
+		else
+			hipLaunchKernelGGL ((fir_fixed_kernel<101, FIR_R, false>), dim3(ntiles), dim3(FIR_THREADS), 0, s,
+			                    d_in, d_out, n, ntiles, taps);
+		}
+	else
+		{
+		uint32_t KC = ((plan->W + FIR_R - 1) / FIR_R) * FIR_R;
+		if (KC > FIR_KC_MAX) KC = FIR_KC_MAX;
+		size_t ldsBytes = ((size_t) T + KC + 2*FIR_R + 4) * sizeof(double);
+		if (mode == GDSP_FIR_FMA)
+			hipLaunchKernelGGL ((fir_generic_kernel<FIR_R, true>),  dim3(ntiles), dim3(FIR_THREADS), ldsBytes, s,
+			                    d_in, d_out, n, ntiles, plan->d_taps, plan->W, KC);
+		else
+			hipLaunchKernelGGL ((fir_generic_kernel<FIR_R, false>), dim3(ntiles), dim3(FIR_THREADS), ldsBytes, s,
+			                    d_in, d_out, n, ntiles, plan->d_taps, plan->W, KC);
+		}
+	GDSP_LAUNCH_CHECK ();
+	return GDSP_OK;
+	}
+
+// Hann plans cached per (device, W): `smooth` rebuilds its window for every
+// chromosome in the reference (sum.c:632-645); here it is built once.
+#define SMOOTH_CACHE 32
+static struct { int device; uint32_t W; gdsp_fir_plan* plan; } smoothCache[SMOOTH_CACHE];
+static int        smoothCacheLen = 0;
+static std::mutex smoothCacheLock;
+
+int gdsp_smooth (const double* d_in, double* d_out, uint32_t n, uint32_t W, int mode, void* stream)
+	{
+	GDSP_REQUIRE ((W >= 3) && (W & 1), "W must be odd and >= 3");
+	GDSP_REQUIRE (W <= 50001, "W exceeds 50001");          // sum.c:478, :557-558
+	int device = 0;
+	GDSP_HIP_TRY (hipGetDevice (&device));
+
+	gdsp_fir_plan* plan = NULL;
+		{
+		std::lock_guard<std::mutex> hold (smoothCacheLock);
+		for (int i=0 ; i<smoothCacheLen ; i++)
+			{ if ((smoothCache[i].device == device) && (smoothCache[i].W == W)) { plan = smoothCache[i].plan;  break; } }
+		if (plan == NULL)
+			{
+			double* taps = (double*) malloc ((size_t) W * sizeof(double));
+			if (taps == NULL) { gdsp_set_error ("out of host memory");  return GDSP_ENOMEM; }
+			gdsp_hann_taps (W, taps);
+			int rc = gdsp_fir_plan_create (&plan, taps, W);
+			free (taps);
+			if (rc != GDSP_OK) return rc;
+			if (smoothCacheLen == SMOOTH_CACHE)
+				{ gdsp_fir_plan_destroy (smoothCache[0].plan);  smoothCache[0] = smoothCache[--smoothCacheLen]; }
+			smoothCache[smoothCacheLen].device = device;
+			smoothCache[smoothCacheLen].W      = W;
+			smoothCache[smoothCacheLen].plan   = plan;
+			smoothCacheLen++;
+			}
+		}
+	return gdsp_fir_apply (plan, d_in, d_out, n, mode, stream);
+	}
+
+} // extern "C"

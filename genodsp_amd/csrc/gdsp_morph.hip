@@ -1,0 +1,281 @@
+// gdsp_morph.hip -- dilate / erode / close / open on the binarised signal.
+//
+// Reference: op_dilate_apply morphology.c:882-1072, op_erode_apply :1331-1454,
+// op_close_apply :231-319, op_open_apply :529-605.  The reference walks each
+// chromosome once with a run-length state machine; the same results follow
+// from per-position questions about the set S = {i : v[i] > T}:
+//   dilate: one  iff  S meets [i-right, i+left]
+//   erode:  one  iff  [i-right, i+left] lies inside S    (outside the vector = not in S)
+//   close:  one  iff  i in S, or i sits in a gap of S that touches neither end of
+//                     the vector and is no longer than closingLength
+//   open:   one  iff  i sits in a run of S longer than openingLength
+// Only predicates and integer distances are involved, so the output is
+// bit-identical to the reference.
+//
+// HBM-bound (8 B read + 8 B write per base) on MI355X.  A workgroup turns a tile
+// of the signal plus its halo into a *bit* mask in LDS: lanes load 16 bytes each,
+// wave ballots gather the predicate bits, and 128 bases become two 64-bit words
+// -- a 1001-base halo costs 126 bytes of LDS, so tiles are large (16 K bases)
+// and the halo re-read stays ~6 %.  Per-word "next set bit at or after" /
+// "previous set bit at or before" tables (one block-wide scan) then answer
+// every query above with one or two LDS reads, whatever the window length.
+
+#include <math.h>
+#include "gdsp_common.h"
+
+#define MO_THREADS   256
+#define MO_MIN_TILE  16384
+#define MO_MAX_STAGE 262144          // staged bases per workgroup (mask 32 KiB + tables 32 KiB)
+#define MO_STAGE_UNROLL 4
+#define MO_NONE_HI   0x3fffffff      // "no set bit to the right"
+#define MO_NONE_LO   (-0x3fffffff)   // "no set bit to the left"
+
+enum { MO_DILATE = 0, MO_ERODE = 1, MO_CLOSE = 2, MO_OPEN = 3 };
+
+__device__ __forceinline__ uint64_t mo_spread32 (uint64_t x)
+	{
+	x &= 0xFFFFFFFFULL;
+	x = (x | (x << 16)) & 0x0000FFFF0000FFFFULL;
+	x = (x | (x <<  8)) & 0x00FF00FF00FF00FFULL;
+	x = (x | (x <<  4)) & 0x0F0F0F0F0F0F0F0FULL;
+	x = (x | (x <<  2)) & 0x3333333333333333ULL;
+	x = (x | (x <<  1)) & 0x5555555555555555ULL;
+	return x;
+	}
+
+// membership tests, written as the reference writes them (they differ for NaN only)
+template <int OP>
+__device__ __forceinline__ bool mo_member (double x, double T, int64_t g)
+	{
+	if (OP == MO_DILATE) return (g == 0)? (x > T) : !(x <= T);   // morphology.c:930 vs :935
+	if (OP == MO_CLOSE)  return !(x <= T);                        // morphology.c:265, :270
+	return (x > T);                                               // :1384/:1391, :563/:568
+	}
+
+struct MoTables { const uint64_t* mask;  const int* nextFrom;  const int* prevTo; };
+
+// smallest set position >= p (p inside the staged range), or MO_NONE_HI
+__device__ __forceinline__ int mo_next (const MoTables& t, int p)
+	{
+	int      w    = p >> 6;
+	uint64_t bits = t.mask[w] >> (p & 63);
+	if (bits) return p + __builtin_ctzll (bits);
+	return t.nextFrom[w+1];
+	}
+// largest set position <= p, or MO_NONE_LO
+__device__ __forceinline__ int mo_prev (const MoTables& t, int p)
+	{
+	int      w    = p >> 6;
+	uint64_t bits = t.mask[w] << (63 - (p & 63));
+	if (bits) return p - __builtin_clzll (bits);
+	return (w > 0)? t.prevTo[w-1] : MO_NONE_LO;
+	}
+
+template <int OP>
+__global__ __launch_bounds__(MO_THREADS)
+void morph_kernel (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t ntiles,
+                   int tile, int haloL, int nwords,
+                   int left, int right, double length, double T, double one, double zero)
+	{
+	extern __shared__ __attribute__((aligned(16))) uint64_t moLds[];
+	uint64_t* mask     = moLds;                                    // nwords
+	int*      nextFrom = reinterpret_cast<int*> (mask + nwords);   // nwords+1
+	int*      prevTo   = nextFrom + nwords + 1;                    // nwords
+	__shared__ int scanA[MO_THREADS], scanB[MO_THREADS];
+
+	const uint32_t t         = gdsp_xcd_tile (blockIdx.x, ntiles);
+	const int64_t  tileStart = (int64_t) t * tile;
+	const int64_t  g0        = tileStart - haloL;                  // multiple of 128
+	const int      lane      = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+	// erode and open ask about the complement (positions NOT in S; outside the vector counts)
+	const bool complement = (OP == MO_ERODE) || (OP == MO_OPEN);
+
+	// ---- stage: 128 bases per wave-step -> two mask words; MO_STAGE_UNROLL steps' loads in flight
+	for (int c0 = wave*MO_STAGE_UNROLL ; 2*c0 < nwords ; c0 += (MO_THREADS/64)*MO_STAGE_UNROLL)
+		{
+		double x[MO_STAGE_UNROLL], y[MO_STAGE_UNROLL];
+		bool   hx[MO_STAGE_UNROLL], hy[MO_STAGE_UNROLL];
+#pragma unroll
+		for (int u=0 ; u<MO_STAGE_UNROLL ; u++)
+			{
+			const int64_t g = g0 + 128*(int64_t) (c0+u) + 2*lane;
+			const bool live = (2*(c0+u) < nwords);
+			hx[u] = live && (g >= 0) && (g < (int64_t) n);
+			hy[u] = live && (g + 1 >= 0) && (g + 1 < (int64_t) n);
+			x[u] = 0.0;  y[u] = 0.0;
+			if (hx[u] && hy[u]) { double2 d = *reinterpret_cast<const double2*> (in + g);  x[u] = d.x;  y[u] = d.y; }
+			else                { if (hx[u]) x[u] = in[g];  if (hy[u]) y[u] = in[g+1]; }
+			}
+#pragma unroll
+		for (int u=0 ; u<MO_STAGE_UNROLL ; u++)
+			{
+			const int     c = c0 + u;
+			const int64_t g = g0 + 128*(int64_t) c + 2*lane;
+			const uint64_t E = __ballot (hx[u] && mo_member<OP> (x[u], T, g));
+			const uint64_t O = __ballot (hy[u] && mo_member<OP> (y[u], T, g+1));
+			if ((lane == 0) && (2*c < nwords))
+				{
+				uint64_t wA = mo_spread32 (E)       | (mo_spread32 (O)       << 1);
+				uint64_t wB = mo_spread32 (E >> 32) | (mo_spread32 (O >> 32) << 1);
+				if (complement) { wA = ~wA;  wB = ~wB; }
+				mask[2*c]   = wA;
+				mask[2*c+1] = wB;
+				}
+			}
+		}
+	__syncthreads ();
+
+	// ---- per-word tables by one block-wide scan: each thread owns K consecutive words
+	const int K  = (nwords + MO_THREADS - 1) / MO_THREADS;
+	const int w0 = threadIdx.x * K, w1 = (w0 + K < nwords)? w0 + K : nwords;
+		{
+		int firstSet = MO_NONE_HI, lastSet = MO_NONE_LO;
+		for (int w=w0 ; w<w1 ; w++)
+			{
+			uint64_t m = mask[w];
+			if (m)
+				{
+				if (firstSet == MO_NONE_HI) firstSet = 64*w + __builtin_ctzll (m);
+				lastSet = 64*w + 63 - __builtin_clzll (m);
+				}
+			}
+		scanA[threadIdx.x] = firstSet;       // suffix-min over threads
+		scanB[threadIdx.x] = lastSet;        // prefix-max over threads
+		__syncthreads ();
+		for (int d=1 ; d<MO_THREADS ; d*=2)
+			{
+			int a = ((int) threadIdx.x + d < MO_THREADS)? scanA[threadIdx.x + d] : MO_NONE_HI;
+			int b = ((int) threadIdx.x - d >= 0)?         scanB[threadIdx.x - d] : MO_NONE_LO;
+			__syncthreads ();
+			if (a < scanA[threadIdx.x]) scanA[threadIdx.x] = a;
+			if (b > scanB[threadIdx.x]) scanB[threadIdx.x] = b;
+			__syncthreads ();
+			}
+		int carryHi = ((int) threadIdx.x + 1 < MO_THREADS)? scanA[threadIdx.x + 1] : MO_NONE_HI;
+		int carryLo = ((int) threadIdx.x - 1 >= 0)?         scanB[threadIdx.x - 1] : MO_NONE_LO;
+		for (int w=w1-1 ; w>=w0 ; w--)
+			{
+			uint64_t m = mask[w];
+			if (m) carryHi = 64*w + __builtin_ctzll (m);
+			nextFrom[w] = carryHi;
+			}
+		for (int w=w0 ; w<w1 ; w++)
+			{
+			uint64_t m = mask[w];
+			if (m) carryLo = 64*w + 63 - __builtin_clzll (m);
+			prevTo[w] = carryLo;
+			}
+		if (threadIdx.x == 0) nextFrom[nwords] = MO_NONE_HI;
+		}
+	__syncthreads ();
+
+	// ---- answer: two adjacent bases per lane, one 16-byte store
+	const MoTables tb = { mask, nextFrom, prevTo };
+	for (int o = 2*threadIdx.x ; o < tile ; o += 2*MO_THREADS)
+		{
+		const int64_t g = tileStart + o;
+		if (g >= (int64_t) n) break;
+		double r[2];
+#pragma unroll
+		for (int u=0 ; u<2 ; u++)
+			{
+			const int p = haloL + o + u;           // staged position of this base
+			bool isOne;
+			if (OP == MO_DILATE)
+				isOne = (mo_next (tb, p - right) <= p + left);
+			else if (OP == MO_ERODE)               // first position outside S at or after p-right
+				isOne = (mo_next (tb, p - right) > p + left);
+			else if (OP == MO_CLOSE)
+				{
+				int e = mo_next (tb, p);
+				if (e == p) isOne = true;          // in S
+				else
+					{
+					int s = mo_prev (tb, p);
+					isOne = (e != MO_NONE_HI) && (s != MO_NONE_LO) && !((double) (e - (s+1)) > length);
+					}
+				}
+			else // MO_OPEN: the tables describe the complement
+				{
+				int e = mo_next (tb, p);
+				if (e == p) isOne = false;         // not in S
+				else
+					{
+					int s = mo_prev (tb, p);
+					isOne = (e == MO_NONE_HI) || (s == MO_NONE_LO) || ((double) (e - (s+1)) > length);
+					}
+				}
+			r[u] = isOne? one : zero;
+			}
+		if (g + 1 < (int64_t) n) *reinterpret_cast<double2*> (out + g) = make_double2 (r[0], r[1]);
+		else                     out[g] = r[0];
+		}
+	}
+
+template <int OP>
+static int morph_launch (const double* d_in, double* d_out, uint32_t n, uint64_t left, uint64_t right,
+                         double length, double T, double one, double zero, void* stream)
+	{
+	if (n == 0) return GDSP_OK;
+	GDSP_REQUIRE ((d_in != NULL) && (d_out != NULL), "NULL vector");
+	GDSP_REQUIRE (d_in != d_out, "out-of-place operator: d_out must not alias d_in");
+	GDSP_REQUIRE (gdsp_aligned16 (d_in) && gdsp_aligned16 (d_out), "vectors must be 16-byte aligned");
+
+	// how far a query can look to either side of its base
+	uint64_t reachL, reachR;
+	if ((OP == MO_DILATE) || (OP == MO_ERODE))
+		{
+		// nothing beyond the vector matters: clamp so the arithmetic stays in int
+		if (left  > n) left  = n;
+		if (right > n) right = n;
+		reachL = right;  reachR = left + 1;
+		}
+	else
+		{
+		double l = (length < 0)? 0 : length;
+		uint64_t h = (l >= (double) n)? (uint64_t) n + 1 : (uint64_t) floor (l) + 1;
+		reachL = reachR = h + 1;
+		}
+	const uint64_t haloL = ((reachL + 127) / 128) * 128;
+	const uint64_t haloR = ((reachR + 127) / 128) * 128;
+	if (haloL + haloR + 512 > MO_MAX_STAGE)
+		{
+		gdsp_set_error ("%s: window reaching %llu+%llu bases exceeds what one LDS tile holds (max %d)",
+		                __func__, (unsigned long long) reachL, (unsigned long long) reachR, MO_MAX_STAGE - 512);
+		return GDSP_EINVAL;
+		}
+	uint64_t tile = 4 * (haloL + haloR);
+	if (tile < MO_MIN_TILE) tile = MO_MIN_TILE;
+	if (tile + haloL + haloR > MO_MAX_STAGE) tile = MO_MAX_STAGE - haloL - haloR;
+	tile = (tile / 512) * 512;
+	const int      nwords = (int) ((haloL + tile + haloR) / 64);
+	const uint32_t ntiles = (uint32_t) (((uint64_t) n + tile - 1) / tile);
+	const size_t   bytes  = (size_t) nwords * 8 + ((size_t) 2*nwords + 2) * 4;
+
+	hipLaunchKernelGGL ((morph_kernel<OP>), dim3(ntiles), dim3(MO_THREADS), bytes, gdsp_stream (stream),
+	                    d_in, d_out, n, ntiles, (int) tile, (int) haloL, nwords,
+	                    (int) left, (int) right, length, T, one, zero);
+	GDSP_LAUNCH_CHECK ();
+	return GDSP_OK;
+	}
+
+extern "C" {
+
+int gdsp_dilate (const double* d_in, double* d_out, uint32_t n, uint32_t left, uint32_t right,
+                 double T, double one, double zero, void* stream)
+	{ return morph_launch<MO_DILATE> (d_in, d_out, n, left, right, 0.0, T, one, zero, stream); }
+
+int gdsp_erode (const double* d_in, double* d_out, uint32_t n, uint32_t left, uint32_t right,
+                double T, double one, double zero, void* stream)
+	{ return morph_launch<MO_ERODE> (d_in, d_out, n, left, right, 0.0, T, one, zero, stream); }
+
+int gdsp_close (const double* d_in, double* d_out, uint32_t n, double closingLength,
+                double T, double one, double zero, void* stream)
+	{ return morph_launch<MO_CLOSE> (d_in, d_out, n, 0, 0, closingLength, T, one, zero, stream); }
+
+int gdsp_open (const double* d_in, double* d_out, uint32_t n, double openingLength,
+               double T, double one, double zero, void* stream)
+	{ return morph_launch<MO_OPEN> (d_in, d_out, n, 0, 0, openingLength, T, one, zero, stream); }
+
+} // extern "C"

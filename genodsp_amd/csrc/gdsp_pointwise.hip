@@ -1,0 +1,222 @@
+// gdsp_pointwise.hip -- per-base operators: binarize, clip, erase, addconst, abs,
+// invert, fill, and the min/max/count reduction behind invert and percentile 0/100.
+//
+// All of these are one load and one store per base (16 B/base) and therefore HBM
+// bound on MI355X: each lane moves 16 bytes per access, four accesses in flight,
+// and the grid is capped so every workgroup streams a long contiguous run.
+// Comparisons are written in the same form as the reference's so that NaN and
+// signed-zero inputs take the same branch.
+
+#include <float.h>
+#include "gdsp_common.h"
+
+#define PW_THREADS 256
+#define PW_UNROLL  4
+#define PW_MAX_BLOCKS (256 * 8)
+
+template <class F>
+__global__ __launch_bounds__(PW_THREADS)
+void pointwise_kernel (double* __restrict__ v, uint32_t n, F f)
+	{
+	double2*     p      = reinterpret_cast<double2*> (v);
+	const size_t npairs = (size_t) n / 2;
+	const size_t stride = (size_t) gridDim.x * PW_THREADS;
+	size_t       i      = (size_t) blockIdx.x * PW_THREADS + threadIdx.x;
+
+	for ( ; i + (PW_UNROLL-1)*stride < npairs ; i += PW_UNROLL*stride)
+		{
+		double2 d[PW_UNROLL];
+#pragma unroll
+		for (int u=0 ; u<PW_UNROLL ; u++) d[u] = p[i + u*stride];
+#pragma unroll
+		for (int u=0 ; u<PW_UNROLL ; u++) { d[u].x = f (d[u].x);  d[u].y = f (d[u].y); }
+#pragma unroll
+		for (int u=0 ; u<PW_UNROLL ; u++) p[i + u*stride] = d[u];
+		}
+	for ( ; i < npairs ; i += stride)
+		{
+		double2 d = p[i];
+		d.x = f (d.x);  d.y = f (d.y);
+		p[i] = d;
+		}
+	if ((n & 1) && (blockIdx.x == 0) && (threadIdx.x == 0)) v[n-1] = f (v[n-1]);
+	}
+
+template <class F>
+static int pointwise_launch (double* d_v, uint32_t n, F f, void* stream)
+	{
+	if (n == 0) return GDSP_OK;
+	GDSP_REQUIRE (d_v != NULL, "NULL vector");
+	GDSP_REQUIRE (gdsp_aligned16 (d_v), "vector must be 16-byte aligned");
+	size_t   npairs = (size_t) n / 2;
+	size_t   want   = (npairs + (size_t) PW_THREADS*PW_UNROLL - 1) / ((size_t) PW_THREADS*PW_UNROLL);
+	uint32_t blocks = (uint32_t) (want < 1? 1 : (want > PW_MAX_BLOCKS? PW_MAX_BLOCKS : want));
+	hipLaunchKernelGGL ((pointwise_kernel<F>), dim3(blocks), dim3(PW_THREADS), 0, gdsp_stream (stream), d_v, n, f);
+	GDSP_LAUNCH_CHECK ();
+	return GDSP_OK;
+	}
+
+// logical.c:247-257
+struct BinarizeAbove { double T, one, zero;  __device__ double operator() (double x) const { return (x >= T)? one : zero; } };
+struct BinarizeBelow { double T, one, zero;  __device__ double operator() (double x) const { return (x >  T)? one : zero; } };
+// mask.c:893-911
+struct ClipMin  { double lo;      __device__ double operator() (double x) const { return (x < lo)? lo : x; } };
+struct ClipMax  { double hi;      __device__ double operator() (double x) const { return (x > hi)? hi : x; } };
+struct ClipBoth { double lo, hi;  __device__ double operator() (double x) const { return (x < lo)? lo : ((x > hi)? hi : x); } };
+// mask.c:1187-1227 (kind: 0 below-min, 1 above-max, 2 outside, 3 >=min, 4 <=max, 5 inside)
+template <int KIND>
+struct Erase
+	{
+	double lo, hi, zero;
+	__device__ double operator() (double x) const
+		{
+		bool hit;
+		if      (KIND == 0) hit = (x < lo);
+		else if (KIND == 1) hit = (x > hi);
+		else if (KIND == 2) hit = (x < lo) || (x > hi);
+		else if (KIND == 3) hit = (x >= lo);
+		else if (KIND == 4) hit = (x <= hi);
+		else                hit = (x >= lo) && (x <= hi);
+		return hit? zero : x;
+		}
+	};
+struct AddConst { double c;       __device__ double operator() (double x) const { return x + c; } };          // add.c:738-739
+struct AbsVal   {                 __device__ double operator() (double x) const { return (x < 0)? -x : x; } }; // add.c:1046-1047
+struct Invert   { double twoMid;  __device__ double operator() (double x) const { return twoMid - x; } };      // add.c:935-936
+struct FillVal  { double c;       __device__ double operator() (double)   const { return c; } };
+
+// ---------------------------------------------------------------- reduction ----
+// d_minmax[0] = min, [1] = max, [2] = count of the sampled values (every window-th
+// element with lo <= v <= hi; the two rejection tests are the reference's
+// `v < min -> skip`, `v > max -> skip`, percentile.c:447-448).
+__device__ __forceinline__ void atomic_min_f64 (double* addr, double val)
+	{
+	unsigned long long* a = reinterpret_cast<unsigned long long*> (addr);
+	unsigned long long  old = *a, assumed;
+	do  {
+		assumed = old;
+		if (!(val < __longlong_as_double ((long long) assumed))) break;
+		old = atomicCAS (a, assumed, (unsigned long long) __double_as_longlong (val));
+		} while (assumed != old);
+	}
+__device__ __forceinline__ void atomic_max_f64 (double* addr, double val)
+	{
+	unsigned long long* a = reinterpret_cast<unsigned long long*> (addr);
+	unsigned long long  old = *a, assumed;
+	do  {
+		assumed = old;
+		if (!(val > __longlong_as_double ((long long) assumed))) break;
+		old = atomicCAS (a, assumed, (unsigned long long) __double_as_longlong (val));
+		} while (assumed != old);
+	}
+
+__global__ __launch_bounds__(PW_THREADS)
+void minmax_kernel (const double* __restrict__ v, uint32_t n, uint32_t window, double lo, double hi,
+                    double* __restrict__ result)
+	{
+	const size_t nsamp  = ((size_t) n + window - 1) / window;
+	const size_t stride = (size_t) gridDim.x * PW_THREADS;
+	double   mn = DBL_MAX, mx = -DBL_MAX;
+	uint32_t cnt = 0;
+
+	for (size_t s = (size_t) blockIdx.x * PW_THREADS + threadIdx.x ; s < nsamp ; s += stride)
+		{
+		double x = v[s * window];
+		if (x < lo) continue;
+		if (x > hi) continue;
+		if (x < mn) mn = x;
+		if (x > mx) mx = x;
+		cnt++;
+		}
+
+	// wave reduce (64 lanes), then one set of atomics per wave
+	for (int off=32 ; off>0 ; off>>=1)
+		{
+		double   omn = __shfl_down (mn, off, 64);
+		double   omx = __shfl_down (mx, off, 64);
+		uint32_t oc  = __shfl_down (cnt, off, 64);
+		if (omn < mn) mn = omn;
+		if (omx > mx) mx = omx;
+		cnt += oc;
+		}
+	if ((threadIdx.x & 63) == 0)
+		{
+		if (cnt != 0)
+			{
+			atomic_min_f64 (&result[0], mn);
+			atomic_max_f64 (&result[1], mx);
+			atomicAdd (&result[2], (double) cnt);
+			}
+		}
+	}
+
+extern "C" {
+
+int gdsp_binarize (double* d_v, uint32_t n, double T, int tiesAbove, double one, double zero, void* stream)
+	{
+	if (tiesAbove) return pointwise_launch (d_v, n, BinarizeAbove {T, one, zero}, stream);
+	return pointwise_launch (d_v, n, BinarizeBelow {T, one, zero}, stream);
+	}
+
+int gdsp_clip (double* d_v, uint32_t n, int haveMin, double minVal, int haveMax, double maxVal, void* stream)
+	{
+	GDSP_REQUIRE (haveMin || haveMax, "clip needs a minimum or a maximum");
+	if (!haveMax) return pointwise_launch (d_v, n, ClipMin {minVal}, stream);
+	if (!haveMin) return pointwise_launch (d_v, n, ClipMax {maxVal}, stream);
+	return pointwise_launch (d_v, n, ClipBoth {minVal, maxVal}, stream);
+	}
+
+int gdsp_erase (double* d_v, uint32_t n, int haveMin, double minVal, int haveMax, double maxVal,
+                int keepInside, double zero, void* stream)
+	{
+	GDSP_REQUIRE (haveMin || haveMax, "erase needs a minimum or a maximum");
+	if (keepInside)
+		{
+		if (!haveMax) return pointwise_launch (d_v, n, Erase<0> {minVal, maxVal, zero}, stream);
+		if (!haveMin) return pointwise_launch (d_v, n, Erase<1> {minVal, maxVal, zero}, stream);
+		return pointwise_launch (d_v, n, Erase<2> {minVal, maxVal, zero}, stream);
+		}
+	if (!haveMax) return pointwise_launch (d_v, n, Erase<3> {minVal, maxVal, zero}, stream);
+	if (!haveMin) return pointwise_launch (d_v, n, Erase<4> {minVal, maxVal, zero}, stream);
+	return pointwise_launch (d_v, n, Erase<5> {minVal, maxVal, zero}, stream);
+	}
+
+int gdsp_add_constant (double* d_v, uint32_t n, double c, void* stream)
+	{
+	if (c == 0.0) return GDSP_OK;                       // add.c:736
+	return pointwise_launch (d_v, n, AddConst {c}, stream);
+	}
+
+int gdsp_abs (double* d_v, uint32_t n, void* stream)
+	{ return pointwise_launch (d_v, n, AbsVal {}, stream); }
+
+int gdsp_invert (double* d_v, uint32_t n, double mid, void* stream)
+	{ return pointwise_launch (d_v, n, Invert {2*mid}, stream); }
+
+int gdsp_fill (double* d_v, uint32_t n, double val, void* stream)
+	{ return pointwise_launch (d_v, n, FillVal {val}, stream); }
+
+int gdsp_minmax_init (double* d_minmax, void* stream)
+	{
+	GDSP_REQUIRE (d_minmax != NULL, "NULL result");
+	static const double init[3] = { DBL_MAX, -DBL_MAX, 0.0 };
+	GDSP_HIP_TRY (hipMemcpyAsync (d_minmax, init, sizeof(init), hipMemcpyHostToDevice, gdsp_stream (stream)));
+	return GDSP_OK;
+	}
+
+int gdsp_minmax_update (const double* d_v, uint32_t n, uint32_t window, double lo, double hi,
+                        double* d_minmax, void* stream)
+	{
+	if (n == 0) return GDSP_OK;
+	GDSP_REQUIRE ((d_v != NULL) && (d_minmax != NULL), "NULL pointer");
+	if (window == 0) window = 1;
+	size_t   nsamp  = ((size_t) n + window - 1) / window;
+	size_t   want   = (nsamp + (size_t) PW_THREADS*4 - 1) / ((size_t) PW_THREADS*4);
+	uint32_t blocks = (uint32_t) (want < 1? 1 : (want > PW_MAX_BLOCKS? PW_MAX_BLOCKS : want));
+	hipLaunchKernelGGL (minmax_kernel, dim3(blocks), dim3(PW_THREADS), 0, gdsp_stream (stream),
+	                    d_v, n, window, lo, hi, d_minmax);
+	GDSP_LAUNCH_CHECK ();
+	return GDSP_OK;
+	}
+
+} // extern "C"

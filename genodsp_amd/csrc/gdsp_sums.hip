@@ -1,0 +1,275 @@
+// gdsp_sums.hip -- slidingsum, sum (non-overlapping windows), cumulativesum.
+//
+// Reference: op_sliding_sum_apply sum.c:420-463, op_window_sum_apply :211-252,
+// op_cumulative_sum_apply :776-792.
+//
+// Parity policy.  The reference forms these
+// with ONE accumulator walking the whole chromosome, so its rounding error is a
+// function of everything to the left of a position; no parallel evaluation can
+// reproduce those bits for arbitrary reals.  What is reproduced exactly:
+//   * `sum`: each window is summed by one thread in ascending order, exactly the
+//     reference's order, for windows up to WS_SEQ_MAX bases -> bit-identical;
+//   * `slidingsum`, `cumulativesum`, and `sum` over longer windows: bit-identical
+//     whenever every partial sum is exactly representable (integer or dyadic
+//     signals such as read depth, the operator's normal input); otherwise within
+//     the reference's own accumulated rounding error (tests state the bound).
+// All three are HBM-bound (16 B/base).
+
+#include "gdsp_common.h"
+
+#define SU_THREADS 256
+
+// ------------------------------------------------- block-wide inclusive scan ----
+// Inclusive prefix sum of lds[0..L) in place.  Each thread owns C consecutive
+// values, C odd so the lane stride is conflict-free for ds_read_b64.
+__device__ __forceinline__ void block_prefix_sum (double* lds, int L, int C, double* waveTotals)
+	{
+	const int base = threadIdx.x * C;
+	double run = 0.0;
+	for (int k=0 ; k<C ; k++)
+		{ if (base + k < L) { run += lds[base+k];  lds[base+k] = run; } }
+
+	// exclusive scan of the per-thread totals: wave shuffle scan, then across the 4 waves
+	double incl = run;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	for (int d=1 ; d<64 ; d*=2)
+		{
+		double up = __shfl_up (incl, d, 64);
+		if (lane >= d) incl += up;
+		}
+	if (lane == 63) waveTotals[wave] = incl;
+	__syncthreads ();
+	double offset = incl - run;
+	for (int w=0 ; w<wave ; w++) offset += waveTotals[w];
+	for (int k=0 ; k<C ; k++)
+		{ if (base + k < L) lds[base+k] += offset; }
+	__syncthreads ();
+	}
+
+// ------------------------------------------------------------- sliding sum ----
+// out[c] = (sum of v over [c-lft, c+rgt] inside the vector) / denom, with
+// rgt = hOff = (W-1)/2 and lft = W-1-hOff (sum.c:436-455: the running sum after
+// step ix holds v[ix-W+1 .. ix] and is stored at centre ix-hOff).
+__global__ __launch_bounds__(SU_THREADS)
+void sliding_sum_kernel (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t ntiles,
+                         int tile, int W, int lft, double denom, int C)
+	{
+	extern __shared__ __attribute__((aligned(16))) double suLds[];
+	__shared__ double waveTotals[SU_THREADS/64];
+
+	const uint32_t t         = gdsp_xcd_tile (blockIdx.x, ntiles);
+	const int64_t  tileStart = (int64_t) t * tile;
+	// stage one extra leading zero so that P[-1] = 0 needs no special case
+	const int      sh        = ((lft + 1) & 1);
+	const int64_t  g0        = tileStart - lft - 1 - sh;          // even
+	const int      L         = (tile + W + sh + 1) & ~1;
+
+	if ((g0 >= 0) && (g0 + L <= (int64_t) n))
+		{
+		const double2* src = reinterpret_cast<const double2*> (in + g0);
+		double2*       dst = reinterpret_cast<double2*> (suLds);
+		for (int p=threadIdx.x ; p<L/2 ; p+=SU_THREADS) dst[p] = src[p];
+		}
+	else
+		{
+		for (int p=threadIdx.x ; p<L ; p+=SU_THREADS)
+			{
+			int64_t g = g0 + p;
+			suLds[p] = ((g >= 0) && (g < (int64_t) n))? in[g] : 0.0;
+			}
+		}
+	__syncthreads ();
+	// x[k] = staged value of global tileStart-lft-1+k, k=0 is the extra leading element;
+	// it must not count towards the first window, so it is cleared before the scan
+	if (threadIdx.x == 0) { for (int k=0 ; k<=sh ; k++) suLds[k] = 0.0; }
+	__syncthreads ();
+
+	block_prefix_sum (suLds, L, C, waveTotals);
+
+	const double* P = suLds + sh;                 // P[k] = sum of staged x[1..k]
+	for (int o = 2*threadIdx.x ; o < tile ; o += 2*SU_THREADS)
+		{
+		const int64_t g = tileStart + o;
+		if (g >= (int64_t) n) break;
+		double s0 = (P[o + W]     - P[o])     / denom;
+		double s1 = (P[o + 1 + W] - P[o + 1]) / denom;
+		if (g + 1 < (int64_t) n) *reinterpret_cast<double2*> (out + g) = make_double2 (s0, s1);
+		else                     out[g] = s0;
+		}
+	}
+
+// -------------------------------------------------------------- window sum ----
+#define WS_SEQ_MAX 8192
+// one thread per window, ascending adds (bit-identical to sum.c:230-249)
+__global__ __launch_bounds__(SU_THREADS)
+void window_sum_seq_kernel (double* __restrict__ v, uint32_t n, uint32_t W, uint32_t nwin,
+                            double denom, int useActual, double zeroVal)
+	{
+	const uint32_t w = blockIdx.x * SU_THREADS + threadIdx.x;
+	if (w >= nwin) return;
+	const uint64_t s = (uint64_t) w * W;
+	uint64_t       e = s + W;  if (e > n) e = n;
+	double acc = v[s];
+	for (uint64_t ix=s+1 ; ix<e ; ix++) acc += v[ix];
+	v[s] = useActual? acc / (double) (e - s) : acc / denom;
+	for (uint64_t ix=s+1 ; ix<e ; ix++) v[ix] = zeroVal;
+	}
+
+// one workgroup per (long) window: strided partial sums, then a tree
+__global__ __launch_bounds__(SU_THREADS)
+void window_sum_wide_kernel (double* __restrict__ v, uint32_t n, uint32_t W,
+                             double denom, int useActual, double zeroVal)
+	{
+	__shared__ double part[SU_THREADS];
+	const uint64_t s = (uint64_t) blockIdx.x * W;
+	uint64_t       e = s + W;  if (e > n) e = n;
+	double acc = 0.0;
+	for (uint64_t ix=s+threadIdx.x ; ix<e ; ix+=SU_THREADS) acc += v[ix];
+	part[threadIdx.x] = acc;
+	__syncthreads ();
+	for (int d=SU_THREADS/2 ; d>0 ; d>>=1)
+		{
+		if ((int) threadIdx.x < d) part[threadIdx.x] += part[threadIdx.x + d];
+		__syncthreads ();
+		}
+	const double total = part[0];
+	for (uint64_t ix=s+threadIdx.x ; ix<e ; ix+=SU_THREADS)
+		v[ix] = (ix == s)? (useActual? total / (double) (e - s) : total / denom) : zeroVal;
+	}
+
+// ---------------------------------------------------------- cumulative sum ----
+#define CS_CHUNK 8192                     // bases per workgroup
+#define CS_PER   (CS_CHUNK / SU_THREADS)  // 32 bases per thread
+
+__global__ __launch_bounds__(SU_THREADS)
+void cumsum_totals_kernel (const double* __restrict__ v, uint32_t n, double* __restrict__ totals)
+	{
+	__shared__ double part[SU_THREADS];
+	const uint64_t s = (uint64_t) blockIdx.x * CS_CHUNK;
+	double acc = 0.0;
+	for (int k=0 ; k<CS_PER ; k++)
+		{
+		uint64_t ix = s + (uint64_t) k*SU_THREADS + threadIdx.x;
+		if (ix < n) acc += v[ix];
+		}
+	part[threadIdx.x] = acc;
+	__syncthreads ();
+	for (int d=SU_THREADS/2 ; d>0 ; d>>=1)
+		{
+		if ((int) threadIdx.x < d) part[threadIdx.x] += part[threadIdx.x + d];
+		__syncthreads ();
+		}
+	if (threadIdx.x == 0) totals[blockIdx.x] = part[0];
+	}
+
+// exclusive scan of the chunk totals, one workgroup of 1024
+__global__ __launch_bounds__(1024)
+void cumsum_offsets_kernel (double* __restrict__ totals, uint32_t nchunks)
+	{
+	__shared__ double sums[1024];
+	const uint32_t per = (nchunks + 1023) / 1024;
+	const uint32_t a = threadIdx.x * per, b = (a + per < nchunks)? a + per : nchunks;
+	double acc = 0.0;
+	for (uint32_t i=a ; i<b ; i++) acc += totals[i];
+	sums[threadIdx.x] = acc;
+	__syncthreads ();
+	for (int d=1 ; d<1024 ; d*=2)
+		{
+		double up = ((int) threadIdx.x >= d)? sums[threadIdx.x - d] : 0.0;
+		__syncthreads ();
+		sums[threadIdx.x] += up;
+		__syncthreads ();
+		}
+	double run = sums[threadIdx.x] - acc;          // exclusive offset of this thread's slice
+	for (uint32_t i=a ; i<b ; i++) { double t = totals[i];  totals[i] = run;  run += t; }
+	}
+
+__global__ __launch_bounds__(SU_THREADS)
+void cumsum_apply_kernel (double* __restrict__ v, uint32_t n, const double* __restrict__ offsets)
+	{
+	extern __shared__ __attribute__((aligned(16))) double suLds[];
+	__shared__ double waveTotals[SU_THREADS/64];
+	const uint64_t s = (uint64_t) blockIdx.x * CS_CHUNK;
+	const int      L = CS_CHUNK;
+	for (int p=threadIdx.x ; p<L ; p+=SU_THREADS)
+		{ uint64_t ix = s + p;  suLds[p] = (ix < n)? v[ix] : 0.0; }
+	__syncthreads ();
+	block_prefix_sum (suLds, L, CS_PER + 1, waveTotals);          // 33 values per thread (odd stride)
+	const double off = offsets[blockIdx.x];
+	for (int p=threadIdx.x ; p<L ; p+=SU_THREADS)
+		{ uint64_t ix = s + p;  if (ix < n) v[ix] = off + suLds[p]; }
+	}
+
+extern "C" {
+
+int gdsp_sliding_sum (const double* d_in, double* d_out, uint32_t n, uint32_t W, double denom, void* stream)
+	{
+	if (n == 0) return GDSP_OK;
+	GDSP_REQUIRE ((d_in != NULL) && (d_out != NULL), "NULL vector");
+	GDSP_REQUIRE (d_in != d_out, "out-of-place operator: d_out must not alias d_in");
+	GDSP_REQUIRE (gdsp_aligned16 (d_in) && gdsp_aligned16 (d_out), "vectors must be 16-byte aligned");
+	GDSP_REQUIRE (W >= 1, "window must be >= 1");
+	GDSP_REQUIRE (denom != 0.0, "denominator can't be zero");
+
+	// a window longer than the vector plus its own reach sees everything anyway
+	uint64_t Weff = W, hOff = (W - 1) / 2, lft = W - 1 - hOff;
+	const int tile = 4096;
+	const size_t maxDoubles = 18432;                       // 144 KiB of LDS
+	if (Weff + tile + 4 > maxDoubles)
+		{
+		gdsp_set_error ("gdsp_sliding_sum: window of %u bases exceeds what one LDS tile holds (max %zu)",
+		                W, maxDoubles - tile - 4);
+		return GDSP_EINVAL;
+		}
+	const int L = (int) (tile + Weff + 2);
+	int C = (L + SU_THREADS - 1) / SU_THREADS;  if ((C & 1) == 0) C++;
+	const uint32_t ntiles = (uint32_t) (((uint64_t) n + tile - 1) / tile);
+	const size_t   bytes  = ((size_t) L + 2) * sizeof(double);
+	if (bytes > 64*1024)
+		GDSP_HIP_TRY (hipFuncSetAttribute ((const void*) sliding_sum_kernel,
+		                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int) (maxDoubles*sizeof(double))));
+	hipLaunchKernelGGL (sliding_sum_kernel, dim3(ntiles), dim3(SU_THREADS), bytes, gdsp_stream (stream),
+	                    d_in, d_out, n, ntiles, tile, (int) Weff, (int) lft, denom, C);
+	GDSP_LAUNCH_CHECK ();
+	return GDSP_OK;
+	}
+
+int gdsp_window_sum (double* d_v, uint32_t n, uint32_t W, double denom, int useActual, double zeroVal, void* stream)
+	{
+	if (n == 0) return GDSP_OK;
+	GDSP_REQUIRE (d_v != NULL, "NULL vector");
+	GDSP_REQUIRE (W >= 1, "window must be >= 1");
+	GDSP_REQUIRE (useActual || (denom != 0.0), "denominator can't be zero");
+	if (W > n) W = n;
+	const uint32_t nwin = (uint32_t) (((uint64_t) n + W - 1) / W);
+	if (W <= WS_SEQ_MAX)
+		hipLaunchKernelGGL (window_sum_seq_kernel, dim3((nwin + SU_THREADS - 1)/SU_THREADS), dim3(SU_THREADS), 0,
+		                    gdsp_stream (stream), d_v, n, W, nwin, denom, useActual, zeroVal);
+	else
+		hipLaunchKernelGGL (window_sum_wide_kernel, dim3(nwin), dim3(SU_THREADS), 0,
+		                    gdsp_stream (stream), d_v, n, W, denom, useActual, zeroVal);
+	GDSP_LAUNCH_CHECK ();
+	return GDSP_OK;
+	}
+
+size_t gdsp_cumulative_sum_work (uint32_t n)
+	{ return ((((size_t) n + CS_CHUNK - 1) / CS_CHUNK) + 1) * sizeof(double); }
+
+int gdsp_cumulative_sum (double* d_v, uint32_t n, void* d_work, void* stream)
+	{
+	if (n == 0) return GDSP_OK;
+	GDSP_REQUIRE ((d_v != NULL) && (d_work != NULL), "NULL pointer");
+	const uint32_t nchunks = (uint32_t) (((uint64_t) n + CS_CHUNK - 1) / CS_CHUNK);
+	double*        totals  = (double*) d_work;
+	hipStream_t    s       = gdsp_stream (stream);
+	hipLaunchKernelGGL (cumsum_totals_kernel,  dim3(nchunks), dim3(SU_THREADS), 0, s, d_v, n, totals);
+	hipLaunchKernelGGL (cumsum_offsets_kernel, dim3(1),       dim3(1024),       0, s, totals, nchunks);
+	GDSP_HIP_TRY (hipFuncSetAttribute ((const void*) cumsum_apply_kernel,
+	                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024));
+	hipLaunchKernelGGL (cumsum_apply_kernel,   dim3(nchunks), dim3(SU_THREADS),
+	                    (CS_CHUNK + SU_THREADS) * sizeof(double), s, d_v, n, totals);
+	GDSP_LAUNCH_CHECK ();
+	return GDSP_OK;
+	}
+
+} // extern "C"

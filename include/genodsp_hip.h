@@ -1,0 +1,194 @@
+/* genodsp_hip.h -- C ABI of libgenodsp_hip.so, the MI355X (gfx950) device side
+ * of the genodsp hot path.
+ *
+ * Every entry point is what a genodsp operator's `apply` (genodsp_interface.h:76-93
+ * in the reference) would call once its chromosome vector lives in HBM: plain
+ * pointers and sizes, no C++ or torch types.  `d_` pointers are device memory
+ * (hipMalloc, or any allocation a HIP stream can address, 16-byte aligned);
+ * `h_` pointers are host memory.  `stream` is a hipStream_t passed as void*
+ * (NULL = the default stream).  Calls only enqueue work unless stated
+ * otherwise.  Lengths are u32 like the reference's (genodsp_interface.h:45).
+ *
+ * Return value: 0 on success, a GDSP_E* code otherwise; gdsp_last_error()
+ * gives the message.  The library never falls back to a CPU path.
+ */
+#ifndef GENODSP_HIP_H
+#define GENODSP_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GDSP_OK        0
+#define GDSP_EINVAL    1   /* bad argument                         */
+#define GDSP_EHIP      2   /* a HIP runtime call or launch failed  */
+#define GDSP_ENOMEM    3
+
+/* FIR arithmetic: EXACT rounds the product and the sum separately, ascending tap
+ * order, and is bit-identical to the reference's loop (sum.c:659-662);
+ * FMA fuses them (one rounding per tap instead of two). */
+#define GDSP_FIR_EXACT 0
+#define GDSP_FIR_FMA   1
+
+/* interval overlap operators, values as genodsp_interface.h:157-159 */
+#define GDSP_OVERLAP_SUM 0
+#define GDSP_OVERLAP_MIN 1
+#define GDSP_OVERLAP_MAX 2
+
+const char* gdsp_last_error (void);
+const char* gdsp_version    (void);
+
+/* ---- runtime plumbing (what genodsp.c:865-878 / :1890-2037 do with calloc) ---- */
+int gdsp_device_count   (int* count);
+int gdsp_set_device     (int device);
+int gdsp_malloc         (void** d_ptr, size_t bytes);
+int gdsp_free           (void* d_ptr);
+int gdsp_host_alloc     (void** h_ptr, size_t bytes);          /* pinned staging  */
+int gdsp_host_free      (void* h_ptr);
+int gdsp_memcpy_h2d     (void* d_dst, const void* h_src, size_t bytes, void* stream);
+int gdsp_memcpy_d2h     (void* h_dst, const void* d_src, size_t bytes, void* stream);
+int gdsp_memcpy_d2d     (void* d_dst, const void* d_src, size_t bytes, void* stream);
+int gdsp_stream_create  (void** stream);
+int gdsp_stream_destroy (void* stream);
+int gdsp_stream_sync    (void* stream);
+int gdsp_event_create   (void** event);
+int gdsp_event_destroy  (void* event);
+int gdsp_event_record   (void* event, void* stream);
+int gdsp_event_elapsed_ms (void* start, void* stop, float* ms); /* syncs on stop   */
+int gdsp_fill           (double* d_v, uint32_t n, double val, void* stream);
+
+/* ---- sum.c ---------------------------------------------------------------------- */
+
+/* Host: the reference's Hann taps (sum.c:632-645), W odd >= 3. */
+int gdsp_hann_taps (uint32_t W, double* h_taps);
+
+/* op_smooth_apply (sum.c:616-676): zero-padded W-tap FIR, out-of-place. */
+typedef struct gdsp_fir_plan gdsp_fir_plan;
+int gdsp_fir_plan_create  (gdsp_fir_plan** plan, const double* h_taps, uint32_t W);
+int gdsp_fir_plan_destroy (gdsp_fir_plan* plan);
+int gdsp_fir_apply        (const gdsp_fir_plan* plan, const double* d_in, double* d_out,
+                           uint32_t n, int mode, void* stream);
+/* convenience: Hann plan for W cached inside the library (per device) */
+int gdsp_smooth           (const double* d_in, double* d_out, uint32_t n, uint32_t W,
+                           int mode, void* stream);
+
+/* op_sliding_sum_apply (sum.c:420-463): centred window sum / denom, out-of-place.
+ * Bit-identical to the reference whenever every partial sum is exact (integer
+ * or dyadic signals); otherwise within the running-sum rounding bound. */
+int gdsp_sliding_sum      (const double* d_in, double* d_out, uint32_t n, uint32_t W,
+                           double denom, void* stream);
+/* op_window_sum_apply (sum.c:211-252), in place. */
+int gdsp_window_sum       (double* d_v, uint32_t n, uint32_t W, double denom, int useActual,
+                           double zeroVal, void* stream);
+/* op_cumulative_sum_apply (sum.c:776-792), in place; d_work >= gdsp_cumulative_sum_work(n) bytes. */
+size_t gdsp_cumulative_sum_work (uint32_t n);
+int gdsp_cumulative_sum   (double* d_v, uint32_t n, void* d_work, void* stream);
+
+/* ---- minmax.c ------------------------------------------------------------------- */
+
+/* op_local_maxima_apply / op_local_minima_apply (minmax.c:1183-1227, :981-1022) */
+int gdsp_local_extrema (const double* d_in, double* d_out, uint32_t n, uint32_t N,
+                        int wantMax, double fill, void* stream);
+/* op_best_local_max_apply / _min_ (minmax.c:1616-1721, :1369-1474): sliding max/min */
+int gdsp_best_extrema  (const double* d_in, double* d_out, uint32_t n, uint32_t W,
+                        int wantMax, void* stream);
+
+/* ---- morphology.c --------------------------------------------------------------- */
+
+/* All four binarise with v > T and write only one/zero.  Out-of-place
+ * (d_out may not alias d_in). */
+int gdsp_dilate (const double* d_in, double* d_out, uint32_t n, uint32_t left, uint32_t right,
+                 double T, double one, double zero, void* stream);   /* :882-1072  */
+int gdsp_erode  (const double* d_in, double* d_out, uint32_t n, uint32_t left, uint32_t right,
+                 double T, double one, double zero, void* stream);   /* :1331-1454 */
+int gdsp_close  (const double* d_in, double* d_out, uint32_t n, double closingLength,
+                 double T, double one, double zero, void* stream);   /* :231-319   */
+int gdsp_open   (const double* d_in, double* d_out, uint32_t n, double openingLength,
+                 double T, double one, double zero, void* stream);   /* :529-605   */
+
+/* ---- logical.c, mask.c, add.c (in place) ---------------------------------------- */
+int gdsp_binarize     (double* d_v, uint32_t n, double T, int tiesAbove, double one, double zero,
+                       void* stream);                                 /* logical.c:216-268 */
+int gdsp_clip         (double* d_v, uint32_t n, int haveMin, double minVal, int haveMax,
+                       double maxVal, void* stream);                  /* mask.c:850-924    */
+int gdsp_erase        (double* d_v, uint32_t n, int haveMin, double minVal, int haveMax,
+                       double maxVal, int keepInside, double zero, void* stream); /* mask.c:1147-1243 */
+int gdsp_add_constant (double* d_v, uint32_t n, double c, void* stream);   /* add.c:726-741   */
+int gdsp_abs          (double* d_v, uint32_t n, void* stream);             /* add.c:1038-1049 */
+int gdsp_invert       (double* d_v, uint32_t n, double mid, void* stream); /* add.c:927-937   */
+/* add.c:909-923 / percentile.c:434-530: d_minmax[0]=min(d_minmax[0], min over sample),
+ * d_minmax[1]=max(...), d_minmax[2]+=count (as double); sample = every window-th value
+ * with lo <= v <= hi.  Initialise with gdsp_minmax_init. */
+int gdsp_minmax_init   (double* d_minmax, void* stream);
+int gdsp_minmax_update (const double* d_v, uint32_t n, uint32_t window, double lo, double hi,
+                        double* d_minmax, void* stream);
+
+/* ---- percentile.c:392-751 -------------------------------------------------------- */
+
+/* Exact order statistic by radix select on the order-preserving 64-bit image of
+ * the doubles (-0.0 folded onto +0.0: the reference's comparator, genodsp.c:2262-2270,
+ * cannot tell them apart).  The signal is left untouched (the reference scrambles
+ * it, percentile.c:34-36).  One pass = gdsp_select_hist_init, then one
+ * gdsp_select_histogram per chromosome on each GPU, then a SUM of the bins over
+ * GPUs (min/max of the two trailing words) -- the only collective on the whole
+ * path -- then gdsp_select_pick on the host to find the bucket holding rank k.
+ *   sample  : every window-th value with !(v < lo) && !(v > hi)   (percentile.c:559-561)
+ *   digit   : key bits [shift, shift+bits), bits <= GDSP_SELECT_MAX_BITS
+ *   prefix  : only keys whose bits above the digit equal prefix's are counted
+ *   d_hist  : (1<<bits) u64 counts, then the smallest and the largest matching key
+ *             (when those two are equal every remaining candidate is that value). */
+#define GDSP_SELECT_MAX_BITS 13
+int gdsp_select_hist_init (uint64_t* d_hist, int bits, void* stream);
+int gdsp_select_histogram (const double* d_v, uint32_t n, uint32_t window, double lo, double hi,
+                           int shift, int bits, uint64_t prefix, uint64_t* d_hist, void* stream);
+/* Host: bucket holding 0-based rank k among the counted keys, and the rank inside it. */
+int gdsp_select_pick      (const uint64_t* h_hist, int bits, uint64_t k, uint32_t* bucket, uint64_t* kWithin);
+/* Host: key image <-> double */
+double   gdsp_key_to_double (uint64_t key);
+uint64_t gdsp_double_to_key (double v);
+/* Host: the reference's rank formula, percentile.c:587-589 and :688-710 */
+uint32_t gdsp_percentile_rank (uint32_t numValues, uint32_t pThousandths);
+
+/* ---- genodsp.c read_intervals / add.c / multiply.c ------------------------------ */
+
+/* Interval-driven writes.  The host routes intervals to this chromosome, applies
+ * origin and clipping rules, and bins their indices (file order kept) into tiles of
+ * gdsp_interval_tile() bases with gdsp_bin_intervals; the device then applies, to
+ * every base, the intervals covering it IN FILE ORDER -- bit-identical to the
+ * reference's `for ix in [start,end)` loops for any values.
+ *   gdsp_apply_intervals: read_intervals genodsp.c:1305-1331 (sum/min/max, and the
+ *     first-touch rule when `clear`), op_add/op_subtract add.c:282-283, :575-576
+ *     (pass negated values for subtract).
+ *   gdsp_scale_intervals: op_multiply multiply.c:326-345, op_divide :706-740; bases
+ *     under no interval become 0 (multiply) or +-infinityVal (divide). */
+uint32_t gdsp_interval_tile (void);
+int gdsp_bin_intervals   (uint32_t n, const uint32_t* h_start, const uint32_t* h_end, uint32_t count,
+                          uint32_t* h_tileOffsets, uint32_t* h_tileList, uint64_t* listLen);
+int gdsp_apply_intervals (double* d_v, uint32_t n, const uint32_t* d_start, const uint32_t* d_end,
+                          const double* d_val, const uint32_t* d_tileOffsets, const uint32_t* d_tileList,
+                          int overlapOp, int clear, double missingVal, void* stream);
+int gdsp_scale_intervals (double* d_v, uint32_t n, const uint32_t* d_start, const uint32_t* d_end,
+                          const double* d_val, const uint32_t* d_tileOffsets, const uint32_t* d_tileList,
+                          int divide, double infinityVal, void* stream);
+
+/* ---- genodsp.c report_intervals:1561-1691 --------------------------------------- */
+
+/* Run-length encode one chromosome on the device.  d_runs receives up to cap
+ * (start,end) u32 pairs and d_vals the run values; *d_count the number of runs
+ * found (may exceed cap: call again with more room).  uncovered: 0 hide, 1 show, -1 NA. */
+size_t gdsp_report_runs_work (uint32_t n);
+int gdsp_report_runs (const double* d_v, uint32_t n, int collapse, int uncovered,
+                      uint32_t* d_runStart, uint32_t* d_runEnd, double* d_runVal, uint32_t cap,
+                      uint32_t* d_count, void* d_work, void* stream);
+
+/* ---- synthetic coverage signal for benchmarks and parity tests (not in the reference) */
+int gdsp_synth_coverage (double* d_out, uint64_t seed, uint32_t chromIndex, uint32_t start,
+                         uint32_t count, int mode, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GENODSP_HIP_H */

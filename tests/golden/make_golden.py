@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/golden.npz + golden.json from the UNMODIFIED reference.
+
+Runs only where oracle/_ref has been built from /root/reference (`make -C oracle ref`).
+Each case pushes seeded f64 vectors through the reference's own parse + apply
+functions (oracle/ref_harness.c) and records inputs and outputs at full precision;
+CLI cases record the reference binary's stdout/stderr for small text inputs.
+The fixtures are data only: no reference source is stored.
+
+    python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+from oracle import cpu, ref  # noqa: E402
+
+SEED = 20240611
+rng = np.random.default_rng(SEED)
+arrays = {}
+cases = []
+
+
+def signal(kind, n, chrom_index=0):
+    if kind == "depth":      # integer read depth, piecewise constant (our synthetic generator)
+        return cpu.synth_coverage(SEED, chrom_index, 0, n, 0)
+    if kind == "real":       # depth * U(0.5,1.5)
+        return cpu.synth_coverage(SEED, chrom_index, 0, n, 1)
+    if kind == "noise":      # signed reals
+        return rng.standard_normal(n) * 7.0
+    if kind == "blocky":     # small integers in short runs, with zeros
+        return np.repeat(rng.integers(0, 4, n // 5 + 1), 5)[:n].astype(np.float64)
+    if kind == "islands":    # sparse islands of depth separated by longer gaps
+        v = np.zeros(n)
+        pos = 0
+        while pos < n:
+            gap = int(rng.integers(1, 40))
+            run = int(rng.integers(1, 25))
+            v[pos + gap:pos + gap + run] = float(rng.integers(1, 9))
+            pos += gap + run
+        return v
+    raise ValueError(kind)
+
+
+def vector_case(name, chroms, pipeline, inputs, want_globals=()):
+    """chroms: [(name, length)], inputs: {chrom: vector}."""
+    g = ref.Genome(chroms)
+    for c, v in inputs.items():
+        g.set(c, v)
+    g.run(pipeline)
+    rec = {"name": name, "kind": "vector", "chroms": chroms, "pipeline": pipeline, "globals": {}}
+    for c, _ in chroms:
+        arrays["%s/in/%s" % (name, c)] = np.asarray(inputs[c], np.float64)
+        arrays["%s/out/%s" % (name, c)] = g.get(c)
+    for gl in want_globals:
+        val = g.get_global(gl)
+        rec["globals"][gl] = None if val is None else float(val).hex()
+    rec["sorted"] = g.sorted_names()
+    g.close()
+    cases.append(rec)
+
+
+def one(name, kind, n, pipeline):
+    vector_case(name, [("chrA", n)], pipeline, {"chrA": signal(kind, n)})
+
+
+# ---- Hann taps (sum.c:632-645) read back through an impulse at full precision
+for W in (3, 5, 11, 101, 1001):
+    n = 3 * W + 7
+    v = np.zeros(n)
+    v[n // 2] = 1.0
+    one("hann_impulse_W%d" % W, "depth", n, "= smooth W=%d" % W)
+    arrays["hann_impulse_W%d/in/chrA" % W] = v
+    g = ref.Genome([("chrA", n)])
+    g.set("chrA", v)
+    g.run("= smooth W=%d" % W)
+    arrays["hann_impulse_W%d/out/chrA" % W] = g.get("chrA")
+    g.close()
+
+# ---- smooth
+for kind in ("depth", "real", "noise"):
+    for W, n in ((5, 400), (21, 700), (101, 2600), (101, 5003), (301, 1500)):
+        one("smooth_%s_W%d_n%d" % (kind, W, n), kind, n, "= smooth W=%d" % W)
+one("smooth_default_window", "real", 900, "= smooth")
+one("smooth_even_window_raised", "real", 500, "= smooth W=10")
+one("smooth_tiny_vector", "real", 60, "= smooth W=101")          # n > hOff=50: still defined
+
+# ---- local extrema / sliding extrema
+for kind in ("depth", "real", "blocky"):
+    for N in (3, 11, 41, 201):
+        one("localmax_%s_N%d" % (kind, N), kind, 1500, "= localmax N=%d" % N)
+        one("localmin_%s_N%d" % (kind, N), kind, 1500, "= localmin N=%d" % N)
+    for W in (3, 10, 100, 1001):
+        one("bestmax_%s_W%d" % (kind, W), kind, 2500, "= bestmax W=%d" % W)
+        one("bestmin_%s_W%d" % (kind, W), kind, 2500, "= bestmin W=%d" % W)
+one("localmax_fill", "real", 700, "= localmax N=5 --zero=-1")
+one("localmin_fill", "real", 700, "= localmin N=5 --infinity=99")
+one("smooth_then_localmax", "depth", 4000, "= smooth W=101 = localmax N=11")
+
+# ---- window sums
+for kind in ("depth", "blocky", "real"):
+    for W in (4, 101, 1000):
+        one("slidingsum_%s_W%d" % (kind, W), kind, 3000, "= slidingsum W=%d" % W)
+    one("slidingsum_%s_denom" % kind, kind, 1000, "= slidingsum W=25 --denom=W")
+    one("sum_%s_W100" % kind, kind, 2350, "= sum W=100")
+    one("sum_%s_actual" % kind, kind, 2350, "= sum W=64 --denom=actual --zero=-2")
+    one("sum_%s_chrom" % kind, kind, 1234, "= sum --window=chromosome")
+    one("cumsum_%s" % kind, kind, 3000, "= cumulativesum")
+
+# ---- morphology (islands keeps erode clear of the reference's u32 underflow: no run
+#      ends left of the erosion length because every vector starts with a gap > left)
+for L in (1, 2, 7, 20, 61):
+    v = signal("islands", 3000)
+    v[:L + 2] = 0.0
+    for op in ("dilate", "erode", "close", "open"):
+        vector_case("%s_islands_L%d" % (op, L), [("chrA", 3000)], "= %s %d" % (op, L), {"chrA": v})
+v = signal("depth", 4000)
+v[:600] = 0.0
+vector_case("dilate_erode_binarize", [("chrA", 4000)], "= dilate 1001 = erode 1001 = binarize", {"chrA": v})
+vector_case("dilate_threshold_vals", [("chrA", 4000)], "= dilate 30 --threshold=20 --one=5 --zero=-1", {"chrA": v})
+vector_case("dilate_left_right", [("chrA", 4000)], "= dilate --left=7 --right=2", {"chrA": v})
+vector_case("erode_left_right", [("chrA", 4000)], "= erode --left=3 --right=9 --threshold=10", {"chrA": v})
+vector_case("close_threshold", [("chrA", 4000)], "= close 150 --threshold=30", {"chrA": v})
+vector_case("open_threshold", [("chrA", 4000)], "= open 150 --threshold=10 --one=2", {"chrA": v})
+
+# ---- elementwise
+one("binarize_default", "noise", 999, "= binarize")
+one("binarize_T", "depth", 999, "= binarize 20")
+one("binarize_above", "depth", 999, "= binarize 20 --ties:above --one=3 --zero=-3")
+one("clip_both", "noise", 999, "= clip --min=-2.5 --max=4")
+one("clip_min", "noise", 999, "= clip --min=-2.5")
+one("clip_max", "noise", 999, "= clip --max=4")
+for flags in ("--min=-1 --max=3", "--min=-1", "--max=3", "--min=-1 --max=3 --keep:inside --zero=7",
+              "--min=-1 --keep:inside", "--max=3 --keep:inside"):
+    one("erase_" + flags.replace(" ", "_").replace("-", "").replace("=", "").replace(":", ""),
+        "noise", 999, "= erase " + flags)
+one("addconst", "real", 999, "= addconst 1.75")
+one("addconst_zero", "real", 999, "= addconst 0")
+one("abs", "noise", 999, "= abs")
+vector_case("invert_genome", [("c1", 500), ("c2", 800), ("c3", 300)], "= invert",
+            {"c1": signal("noise", 500), "c2": signal("noise", 800), "c3": signal("noise", 300)})
+vector_case("invert_mid", [("c1", 500)], "= invert 2.5", {"c1": signal("noise", 500)})
+
+# ---- percentile: named globals; --preserve is not needed because outputs are not compared
+chroms3 = [("c1", 2000), ("c2", 3500), ("c3", 1200)]
+sig3 = {"c1": signal("depth", 2000, 0), "c2": signal("depth", 3500, 1), "c3": signal("depth", 1200, 2)}
+sig3r = {"c1": signal("real", 2000, 0), "c2": signal("real", 3500, 1), "c3": signal("real", 1200, 2)}
+vector_case("percentile99_depth", chroms3, "= percentile 99 --quiet", sig3, ["percentile99"])
+vector_case("percentile99_nz_depth", chroms3, "= percentile 99 --min=1/inf --quiet", sig3, ["percentile99"])
+vector_case("percentile_range_depth", chroms3, "= percentile 50..100by10 --min=1/inf --quiet", sig3,
+            ["percentile%d" % p for p in (50, 60, 70, 80, 90, 100)])
+vector_case("percentile_real", chroms3, "= percentile 0.5..99.5by9 --quiet", sig3r,
+            ["percentile%s" % p for p in ("0.5", "9.5", "18.5", "27.5", "36.5", "45.5", "54.5", "63.5",
+                                          "72.5", "81.5", "90.5", "99.5")])
+vector_case("percentile_window", chroms3, "= percentile 75 --window=7 --max=30 --quiet", sig3r, ["percentile75"])
+vector_case("percentile_0_100", chroms3, "= percentile 0,100 --quiet", sig3r, ["percentile0", "percentile100"])
+
+# ---- ingest + report through text (genodsp.c:1187-1350, :1561-1691), reference CLI
+def cli_case(name, chrom_text, args, stdin_text):
+    chrom_path = "/tmp/golden_%s.chroms" % name
+    with open(chrom_path, "w") as f:
+        f.write(chrom_text)
+    rc, out, err = ref.run_cli(["--chromosomes=" + chrom_path] + args, stdin_text)
+    cases.append({"name": name, "kind": "cli", "chroms_text": chrom_text, "args": args,
+                  "stdin": stdin_text, "returncode": rc, "stdout": out, "stderr": err})
+
+
+APPENDIX_C_IV = "chr1 10 20\nchr1 15 30\nchr2 0 5\nchrX 1 2\n# comment\ntrack foo\nchr1 15 18 extra\n"
+APPENDIX_C_CH = "chr1 100\nchr2 50\n"
+cli_case("cli_coverage", APPENDIX_C_CH, ["--novalue"], APPENDIX_C_IV)
+cli_case("cli_smooth5", APPENDIX_C_CH, ["--novalue", "--precision=6", "=", "smooth", "--window=5"], APPENDIX_C_IV)
+cli_case("cli_smooth_localmax", APPENDIX_C_CH,
+         ["--novalue", "--precision=6", "=", "smooth", "W=5", "=", "localmax", "N=11"], APPENDIX_C_IV)
+cli_case("cli_dilate6", APPENDIX_C_CH, ["--novalue", "=", "dilate", "6"], APPENDIX_C_IV)
+cli_case("cli_erode6", APPENDIX_C_CH, ["--novalue", "=", "erode", "6"], APPENDIX_C_IV)
+cli_case("cli_dilate_erode_binarize", APPENDIX_C_CH,
+         ["--novalue", "=", "dilate", "7", "=", "erode", "7", "=", "binarize", "0.5"], APPENDIX_C_IV)
+cli_case("cli_percentile99", APPENDIX_C_CH, ["--novalue", "=", "percentile", "99"], APPENDIX_C_IV)
+cli_case("cli_show_uncovered", APPENDIX_C_CH, ["--novalue", "--uncovered:show"], APPENDIX_C_IV)
+cli_case("cli_NA_uncovered", APPENDIX_C_CH, ["--novalue", "--uncovered:NA"], APPENDIX_C_IV)
+cli_case("cli_nocollapse_origin1", APPENDIX_C_CH, ["--novalue", "--nocollapse", "--origin=one"], APPENDIX_C_IV)
+
+# config 1 of BASELINE.json: coverage depth (--novalue) on 1 chromosome x 1 Mbp
+def coverage_intervals(n, seed):
+    r = np.random.default_rng(seed)
+    lines, pos = [], 0
+    while True:
+        pos += int(r.integers(1, 200))
+        length = int(r.integers(20, 300))
+        start = max(0, pos - int(r.integers(0, 120)))
+        if start + length > n:
+            break
+        lines.append("chrS\t%d\t%d" % (start, start + length))
+    return "\n".join(lines) + "\n"
+
+
+cli_case("cli_config1_coverage_1Mbp", "chrS 1000000\n", ["--novalue"], coverage_intervals(1000000, 1))
+
+# valued intervals with overlaps, non-integer values: file-order accumulation
+def valued_intervals(n, seed, count):
+    r = np.random.default_rng(seed)
+    lines = []
+    for _ in range(count):
+        s = int(r.integers(0, n - 50))
+        e = s + int(r.integers(1, 50))
+        lines.append("chrV %d %d %.3f" % (s, e, r.random() * 3))
+    return "\n".join(lines) + "\n"
+
+
+cli_case("cli_valued_overlaps", "chrV 5000\n", ["--precision=12", "--nocollapse"], valued_intervals(5000, 2, 800))
+
+np.savez_compressed(os.path.join(HERE, "golden.npz"), **arrays)
+with open(os.path.join(HERE, "golden.json"), "w") as f:
+    json.dump({"seed": SEED, "cases": cases}, f, indent=1)
+print("wrote %d cases, %d arrays" % (len(cases), len(arrays)))

@@ -1,0 +1,396 @@
+"""GPU: the HIP path (through the C ABI) against the golden vectors and the CPU oracle.
+
+Bars (BASELINE.json north_star): interval/index/predicate outputs bit-exact; smooth
+bit-exact in EXACT mode and within one rounding per floating-point op in FMA mode;
+running-sum operators bit-exact on exactly-summable signals (read depth) and within
+the reference's own accumulated rounding on arbitrary reals (bound stated inline).
+"""
+import numpy as np
+import pytest
+
+from backends import GpuBackend, OracleBackend
+from conftest import bits_equal, first_diff, golden
+from oracle import cpu
+from pipeline import Runner
+
+pytestmark = pytest.mark.gpu
+
+EPS = 2.0 ** -53
+SEED = 20240611
+VECTOR_CASES = golden().vector_cases()
+# running-sum ops on non-dyadic reals cannot be bit-reproduced by any parallel evaluation
+TOLERANT = ("slidingsum_real", "cumsum_real", "sum_real_chrom")
+
+
+@pytest.fixture(scope="module")
+def gd():
+    import genodsp_amd
+    assert genodsp_amd.device_count() >= 1
+    return genodsp_amd
+
+
+def _tolerant(name):
+    return any(name.startswith(t) for t in TOLERANT)
+
+
+@pytest.mark.parametrize("case", VECTOR_CASES, ids=[c["name"] for c in VECTOR_CASES])
+def test_hip_matches_reference_golden_vectors(case, gold, gd):
+    chroms = [tuple(c) for c in case["chroms"]]
+    r = Runner(GpuBackend(), chroms, gold.inputs(case)).run(case["pipeline"])
+    if "percentile" in case["pipeline"]:
+        # non-destructive here (the reference scrambles the signal): inputs must be intact
+        for c, _ in chroms:
+            assert bits_equal(r.result(c), gold.inputs(case)[c])
+    else:
+        want = gold.outputs(case)
+        for c, _ in chroms:
+            got = r.result(c)
+            if _tolerant(case["name"]):
+                x = gold.inputs(case)[c]
+                bound = 4 * x.size * EPS * np.abs(np.cumsum(np.abs(x))).max()
+                assert np.abs(got - want[c]).max() <= bound
+            else:
+                assert bits_equal(got, want[c]), "%s %s first differing index %s" % (
+                    case["name"], c, first_diff(got, want[c]))
+    for name, hexval in case["globals"].items():
+        assert float.fromhex(hexval) == r.globals[name], (name, float.fromhex(hexval), r.globals[name])
+
+
+# ------------------------------------------------------------------ smooth ----
+
+def _signal(kind, n, rng):
+    if kind == "depth":
+        return cpu.synth_coverage(SEED, 3, 0, n, 0)
+    if kind == "real":
+        return cpu.synth_coverage(SEED, 3, 0, n, 1)
+    return rng.standard_normal(n) * 5
+
+
+@pytest.mark.parametrize("n", [1, 2, 50, 51, 52, 101, 2303, 2304, 2305, 2404, 4608, 100003, 1000000])
+@pytest.mark.parametrize("kind", ["depth", "real", "noise"])
+def test_smooth_w101_exact_is_bit_identical(n, kind, gd):
+    rng = np.random.default_rng(n)
+    x = _signal(kind, n, rng)
+    got = gd.smooth(gd.DeviceVector.from_numpy(x), 101, mode=gd.FIR_EXACT).numpy()
+    want = cpu.smooth(x, 101)
+    assert bits_equal(got, want), first_diff(got, want)
+
+
+@pytest.mark.parametrize("W", [3, 5, 9, 11, 51, 99, 103, 301, 1001, 1027, 2053, 5001])
+@pytest.mark.parametrize("n", [1, 7, 2304, 30011])
+def test_smooth_generic_windows_exact(W, n, gd):
+    rng = np.random.default_rng(W * 7 + n)
+    x = _signal("real", n, rng)
+    got = gd.smooth(gd.DeviceVector.from_numpy(x), W, mode=gd.FIR_EXACT).numpy()
+    want = cpu.smooth(x, W)
+    assert bits_equal(got, want), first_diff(got, want)
+
+
+def test_smooth_max_window_50001_exact(gd):
+    """Largest window the reference accepts (sum.c:478): 49 LDS stages of taps."""
+    rng = np.random.default_rng(5)
+    x = _signal("real", 30011, rng)
+    got = gd.smooth(gd.DeviceVector.from_numpy(x), 50001, mode=gd.FIR_EXACT).numpy()
+    want = cpu.smooth(x, 50001)
+    assert bits_equal(got, want), first_diff(got, want)
+
+
+@pytest.mark.parametrize("W,n", [(101, 100003), (101, 2304), (21, 5000), (1001, 20000)])
+@pytest.mark.parametrize("kind", ["depth", "real", "noise"])
+def test_smooth_fma_within_one_rounding_per_op(W, n, kind, gd):
+    """FMA mode fuses each tap's multiply and add.  Both it and the reference's unfused
+    loop err by at most one rounding of the running sum per tap, so they differ by at
+    most W * 2^-52 * sum_k |w_k v_k| at any output."""
+    rng = np.random.default_rng(n + W)
+    x = _signal(kind, n, rng)
+    taps = cpu.hann_window(W)
+    got = gd.smooth(gd.DeviceVector.from_numpy(x), W, mode=gd.FIR_FMA).numpy()
+    want = cpu.smooth(x, W)
+    scale = cpu.fir(np.abs(x), taps)
+    assert np.all(np.abs(got - want) <= W * 2 * EPS * scale)
+    # and it is no further from an extended-precision evaluation than the reference is
+    xl = np.concatenate([np.zeros(W // 2), x, np.zeros(W // 2)]).astype(np.longdouble)
+    truth = np.array([np.dot(taps.astype(np.longdouble), xl[i:i + W]) for i in range(0, n, max(1, n // 400))])
+    sel = np.arange(0, n, max(1, n // 400))
+    assert np.abs(got[sel] - truth).max() <= np.abs(want[sel] - truth).max() * 1.5 + 1e-300
+
+
+def test_fir_plan_custom_taps(gd):
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal(9000)
+    taps = rng.standard_normal(101)
+    plan = gd.FirPlan(taps)
+    got = plan.apply(gd.DeviceVector.from_numpy(x)).numpy()
+    plan.close()
+    assert bits_equal(got, cpu.fir(x, taps))
+    taps7 = rng.standard_normal(7)
+    plan = gd.FirPlan(taps7)
+    got = plan.apply(gd.DeviceVector.from_numpy(x)).numpy()
+    plan.close()
+    assert bits_equal(got, cpu.fir(x, taps7))
+
+
+def test_smooth_rejects_bad_arguments(gd):
+    v = gd.DeviceVector.from_numpy(np.ones(100))
+    with pytest.raises(gd.GdspError):
+        gd.smooth(v, 100)                    # even
+    with pytest.raises(gd.GdspError):
+        gd.smooth(v, 50003)                  # beyond sum.c:478
+    with pytest.raises(gd.GdspError):
+        gd.smooth(v, 101, out=v)             # aliasing
+
+
+# -------------------------------------------------- extrema, morphology ----
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4095, 4096, 4097, 70001])
+@pytest.mark.parametrize("N", [3, 5, 11, 31, 33, 101, 999])
+def test_local_extrema_bit_exact(n, N, gd):
+    rng = np.random.default_rng(n * 13 + N)
+    for kind in ("depth", "noise"):
+        x = _signal(kind, n, rng)
+        d = gd.DeviceVector.from_numpy(x)
+        assert bits_equal(gd.localmax(d, N).numpy(), cpu.local_extrema(x, N, 1, 0.0))
+        assert bits_equal(gd.localmin(d, N).numpy(), cpu.local_extrema(x, N, 0, cpu.DBL_MAX))
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 4096, 4097, 50021])
+@pytest.mark.parametrize("W", [3, 4, 10, 32, 33, 100, 1001, 4000])
+def test_best_extrema_bit_exact(n, W, gd):
+    rng = np.random.default_rng(n * 17 + W)
+    for kind in ("depth", "noise"):
+        x = _signal(kind, n, rng)
+        d = gd.DeviceVector.from_numpy(x)
+        assert bits_equal(gd.best_extrema(d, W, True).numpy(), cpu.best_extrema(x, W, 1))
+        assert bits_equal(gd.best_extrema(d, W, False).numpy(), cpu.best_extrema(x, W, 0))
+
+
+def _islands(n, rng, max_gap=60, max_run=40):
+    v = np.zeros(n)
+    pos = 0
+    while pos < n:
+        gap = int(rng.integers(1, max_gap))
+        run = int(rng.integers(1, max_run))
+        v[pos + gap:pos + gap + run] = float(rng.integers(1, 9))
+        pos += gap + run
+    return v
+
+
+@pytest.mark.parametrize("n", [1, 2, 127, 128, 129, 16384, 16385, 100000, 300007])
+@pytest.mark.parametrize("L", [1, 2, 3, 10, 63, 64, 65, 1001, 5000])
+def test_morphology_bit_exact(n, L, gd):
+    rng = np.random.default_rng(n + L)
+    x = _islands(n, rng, max_gap=3 * L + 5, max_run=3 * L + 5)
+    if n > 3:
+        x[rng.integers(0, n, 3)] = 0.5                     # values either side of the threshold
+    d = gd.DeviceVector.from_numpy(x)
+    left, right = gd.split_length(L)
+    for T in (0.0, 0.75):
+        assert bits_equal(gd.dilate(d, left, right, T).numpy(), cpu.dilate(x, left, right, T)), ("dilate", T)
+        assert bits_equal(gd.erode(d, left, right, T).numpy(), cpu.erode(x, left, right, T)), ("erode", T)
+        assert bits_equal(gd.close(d, L, T).numpy(), cpu.close(x, L, T)), ("close", T)
+        assert bits_equal(gd.open_(d, L, T).numpy(), cpu.open_(x, L, T)), ("open", T)
+    assert bits_equal(gd.dilate(d, 0, L, 0.0, 7.0, -1.0).numpy(), cpu.dilate(x, 0, L, 0.0, 7.0, -1.0))
+    assert bits_equal(gd.erode(d, L, 0, 0.0, 7.0, -1.0).numpy(), cpu.erode(x, L, 0, 0.0, 7.0, -1.0))
+
+
+def test_morphology_all_set_and_all_clear(gd):
+    for n in (1, 500, 40000):
+        ones, zeros = np.ones(n), np.zeros(n)
+        for x in (ones, zeros):
+            d = gd.DeviceVector.from_numpy(x)
+            assert bits_equal(gd.dilate(d, 5, 6).numpy(), cpu.dilate(x, 5, 6))
+            assert bits_equal(gd.erode(d, 5, 6).numpy(), cpu.erode(x, 5, 6))
+            assert bits_equal(gd.close(d, 10).numpy(), cpu.close(x, 10))
+            assert bits_equal(gd.open_(d, 10).numpy(), cpu.open_(x, 10))
+
+
+def test_morphology_fractional_and_huge_lengths(gd):
+    rng = np.random.default_rng(3)
+    x = _islands(50000, rng)
+    d = gd.DeviceVector.from_numpy(x)
+    for L in (0.0, 0.5, 7.5, 39.999, 1e9):
+        assert bits_equal(gd.close(d, L).numpy(), cpu.close(x, L)), L
+        assert bits_equal(gd.open_(d, L).numpy(), cpu.open_(x, L)), L
+
+
+# -------------------------------------------------------------- pointwise ----
+
+@pytest.mark.parametrize("n", [1, 2, 3, 1023, 1024, 1025, 262145, 2000001])
+def test_pointwise_bit_exact(n, gd):
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(n) * 4
+    x[::7] = 0.0
+    if n > 10:
+        x[3] = -0.0
+        x[5] = np.nan
+        x[8] = np.inf
+    up = lambda: gd.DeviceVector.from_numpy(x)
+    assert bits_equal(gd.binarize(up(), 0.5).numpy(), cpu.binarize(x, 0.5))
+    assert bits_equal(gd.binarize(up(), 0.0, True, 3.0, -3.0).numpy(), cpu.binarize(x, 0.0, True, 3.0, -3.0))
+    assert bits_equal(gd.clip(up(), -1.0, 2.0).numpy(), cpu.clip(x, -1.0, 2.0))
+    assert bits_equal(gd.clip(up(), -1.0, None).numpy(), cpu.clip(x, -1.0, None))
+    assert bits_equal(gd.clip(up(), None, 2.0).numpy(), cpu.clip(x, None, 2.0))
+    for lo, hi in ((-1.0, 2.0), (-1.0, None), (None, 2.0)):
+        for inside in (False, True):
+            assert bits_equal(gd.erase(up(), lo, hi, inside, 9.0).numpy(), cpu.erase(x, lo, hi, inside, 9.0))
+    assert bits_equal(gd.add_constant(up(), 1.1).numpy(), cpu.add_constant(x, 1.1))
+    assert bits_equal(gd.add_constant(up(), 0.0).numpy(), x)
+    assert bits_equal(gd.abs_(up()).numpy(), cpu.abs_(x))
+    assert bits_equal(gd.invert(up(), 0.3).numpy(), cpu.invert(x, 0.3))
+    assert bits_equal(gd.fill(up(), 2.5).numpy(), np.full(n, 2.5))
+
+
+def test_genome_minmax_and_invert_default(gd):
+    rng = np.random.default_rng(8)
+    vecs = [rng.standard_normal(n) * 3 for n in (5000, 70001, 33)]
+    dv = [gd.DeviceVector.from_numpy(v) for v in vecs]
+    lo, hi, cnt = gd.genome_minmax(dv)
+    assert (lo, hi) == cpu.genome_minmax(vecs)
+    assert cnt == sum(v.size for v in vecs)
+
+
+# ------------------------------------------------------------------- sums ----
+
+@pytest.mark.parametrize("n", [1, 2, 100, 4096, 4097, 123457])
+@pytest.mark.parametrize("W", [3, 4, 100, 101, 1000, 4001])
+def test_sliding_sum(n, W, gd):
+    rng = np.random.default_rng(n + W)
+    x = _signal("depth", n, rng)
+    got = gd.sliding_sum(gd.DeviceVector.from_numpy(x), W).numpy()
+    assert bits_equal(got, cpu.sliding_sum(x, W))                       # exact sums: bit-identical
+    got = gd.sliding_sum(gd.DeviceVector.from_numpy(x), W, denom=float(W)).numpy()
+    assert bits_equal(got, cpu.sliding_sum(x, W, float(W)))
+    y = _signal("real", n, rng)
+    got = gd.sliding_sum(gd.DeviceVector.from_numpy(y), W).numpy()
+    want = cpu.sliding_sum(y, W)
+    # reference: one accumulator, 2 roundings per step along the whole vector; ours: a tile prefix
+    bound = EPS * np.abs(y).max() * (2.0 * (n + W) * W + 2.0 * (4096 + W + 2) ** 2)
+    assert np.abs(got - want).max() <= bound
+
+
+@pytest.mark.parametrize("n", [1, 5, 100, 2350, 100003])
+@pytest.mark.parametrize("W", [3, 7, 64, 100, 8192, 8193, 50000])
+def test_window_sum(n, W, gd):
+    rng = np.random.default_rng(n * 3 + W)
+    for kind in ("depth", "real"):
+        x = _signal(kind, n, rng)
+        got = gd.window_sum(gd.DeviceVector.from_numpy(x), W, 1.0, False, 0.0).numpy()
+        want = cpu.window_sum(x, min(W, n))
+        if kind == "depth" or W <= 8192:
+            assert bits_equal(got, want), (kind, first_diff(got, want))
+        else:
+            assert np.allclose(got, want, rtol=1e-12, atol=0)
+        got = gd.window_sum(gd.DeviceVector.from_numpy(x), W, 1.0, True, -1.0).numpy()
+        want = cpu.window_sum(x, min(W, n), use_actual=True, zero=-1.0)
+        if kind == "depth" or W <= 8192:
+            assert bits_equal(got, want)
+
+
+@pytest.mark.parametrize("n", [1, 2, 8191, 8192, 8193, 1000003])
+def test_cumulative_sum(n, gd):
+    rng = np.random.default_rng(n)
+    x = _signal("depth", n, rng)
+    assert bits_equal(gd.cumulative_sum(gd.DeviceVector.from_numpy(x)).numpy(), cpu.cumulative_sum(x))
+    y = _signal("real", n, rng)
+    got = gd.cumulative_sum(gd.DeviceVector.from_numpy(y)).numpy()
+    want = cpu.cumulative_sum(y)
+    assert np.abs(got - want).max() <= 2 * n * EPS * np.abs(want).max()
+
+
+# -------------------------------------------------------------- percentile ----
+
+@pytest.mark.parametrize("kind", ["depth", "real", "noise"])
+def test_percentile_exact_order_statistic(kind, gd):
+    rng = np.random.default_rng(17)
+    lens = [300007, 150001, 70000, 5]
+    vecs = [_signal(kind, n, rng) if kind == "noise" else
+            cpu.synth_coverage(SEED, i, 0, n, 0 if kind == "depth" else 1) for i, n in enumerate(lens)]
+    dv = [gd.DeviceVector.from_numpy(v) for v in vecs]
+    pts = [0, 1, 500, 25000, 50000, 90000, 99000, 99999, 100000]
+    for window, lo, hi in ((1, -cpu.DBL_MAX, cpu.DBL_MAX), (1, 2.2250738585072014e-308, cpu.DBL_MAX),
+                           (7, -1.0, 30.0)):
+        cnt, got = gd.percentile(dv, pts, window, lo, hi)
+        wcnt, want = cpu.percentile(vecs, pts, window, lo, hi)
+        assert cnt == wcnt
+        assert list(got) == list(want), (window, lo, hi)
+    for d, v in zip(dv, vecs):
+        assert bits_equal(d.numpy(), v)                    # untouched
+
+
+def test_percentile_empty_sample(gd):
+    dv = [gd.DeviceVector.from_numpy(np.zeros(1000))]
+    cnt, got = gd.percentile(dv, [50000], 1, 1.0, 2.0)
+    assert cnt == 0 and got == []
+
+
+# --------------------------------------------------------------- intervals ----
+
+def _random_intervals(n, count, rng, max_len=400, integer=True):
+    s = rng.integers(0, n, count).astype(np.uint32)
+    e = np.minimum(n, s + rng.integers(1, max_len, count)).astype(np.uint32)
+    val = rng.integers(1, 5, count).astype(np.float64) if integer else rng.random(count) * 3 - 0.5
+    return s, e, val
+
+
+@pytest.mark.parametrize("n", [1, 1000, 1024, 1025, 250007])
+def test_apply_intervals_file_order_bit_exact(n, gd):
+    rng = np.random.default_rng(n)
+    for integer in (True, False):
+        s, e, val = _random_intervals(n, 50 + n // 20, rng, integer=integer)
+        base = rng.random(n) if not integer else np.zeros(n)
+        for op in (cpu.OVERLAP_SUM, cpu.OVERLAP_MIN, cpu.OVERLAP_MAX):
+            for clear, missing in ((False, 0.0), (True, 0.0), (True, -1.0)):
+                got = gd.apply_intervals(gd.DeviceVector.from_numpy(base), s, e, val, op, clear, missing).numpy()
+                start = np.full(n, missing) if clear else base
+                want = cpu.apply_intervals(start, s, e, val, op, clear, missing)
+                assert bits_equal(got, want), (integer, op, clear, missing, first_diff(got, want))
+
+
+def test_apply_intervals_empty(gd):
+    base = np.arange(5000, dtype=np.float64)
+    z = np.zeros(0, np.uint32)
+    got = gd.apply_intervals(gd.DeviceVector.from_numpy(base), z, z, np.zeros(0), cpu.OVERLAP_SUM).numpy()
+    assert bits_equal(got, base)
+    got = gd.apply_intervals(gd.DeviceVector.from_numpy(base), z, z, np.zeros(0), cpu.OVERLAP_SUM, True, 3.0).numpy()
+    assert bits_equal(got, np.full(5000, 3.0))
+
+
+@pytest.mark.parametrize("n", [1, 1024, 3000, 100001])
+def test_scale_intervals_bit_exact(n, gd):
+    rng = np.random.default_rng(n + 1)
+    cuts = np.unique(rng.integers(0, n + 1, 40))
+    s, e = cuts[:-1:2].astype(np.uint32), cuts[1::2].astype(np.uint32)
+    k = min(s.size, e.size)
+    s, e = s[:k], e[:k]
+    val = rng.random(k) * 4 + 0.25
+    base = rng.standard_normal(n)
+    base[::5] = 0.0
+    for divide in (False, True):
+        got = gd.scale_intervals(gd.DeviceVector.from_numpy(base), s, e, val, divide).numpy()
+        assert bits_equal(got, cpu.scale_intervals(base, s, e, val, divide))
+
+
+# ------------------------------------------------------------------ report ----
+
+@pytest.mark.parametrize("n", [1, 2, 15, 16, 17, 4096, 4097, 100003])
+def test_report_runs_bit_exact(n, gd):
+    rng = np.random.default_rng(n)
+    for kind in ("depth", "blocky"):
+        x = cpu.synth_coverage(SEED, 1, 0, n, 0) if kind == "depth" else \
+            np.repeat(rng.integers(0, 3, n // 3 + 1), 3)[:n].astype(np.float64)
+        d = gd.DeviceVector.from_numpy(x)
+        for collapse in (True, False):
+            for uncovered in (0, 1, -1):
+                gs, ge, gv = gd.report_runs(d, collapse, uncovered)
+                ws, we, wv = cpu.report_runs(x, collapse, uncovered)
+                assert np.array_equal(gs, ws) and np.array_equal(ge, we) and bits_equal(gv, wv), (
+                    kind, collapse, uncovered)
+
+
+# --------------------------------------------------------------- synthetic ----
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_synth_signal_matches_cpu_generator(mode, gd):
+    for chrom, start, count in ((0, 0, 100000), (5, 123456789, 4097), (23, 4000000000 - 50, 50)):
+        got = gd.synth_coverage(SEED, chrom, start, count, mode).numpy()
+        assert bits_equal(got, cpu.synth_coverage(SEED, chrom, start, count, mode))
