@@ -140,7 +140,8 @@ def main():
         achieved = BYTES_PER_BASE * bases_rank / (dev_ms_per_step * 1e-3) / 1e9
         flops = 2.0 * WINDOW * bases_rank / (dev_ms_per_step * 1e-3) / 1e12
         return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(),
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": measured_traffic(BYTES_PER_BASE * bases_rank / launches),
                 "kernel": "fir_fixed_kernel<101,9>", "avg_launch_ms": round(avg_launch_ms, 4),
                 "launches_per_step": launches,
                 "algorithmic_bytes_per_launch": int(BYTES_PER_BASE * bases_rank / launches),
@@ -177,13 +178,16 @@ def main():
         dist.destroy_process_group()
 
 
-def measured_traffic():
-    """HBM bytes per launch from the PMC passes committed under profiles/ (null until measured)."""
+def measured_traffic(algorithmic_bytes_per_launch):
+    """HBM bytes per launch: the FETCH_SIZE/WRITE_SIZE ratio to algorithmic bytes measured for this
+    kernel with rocprofv3 --pmc (profiles/traffic.json, gfx950 corrections applied there) scaled to
+    this run's average launch; null when no such measurement is committed."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(path):
-        with open(path) as f:
-            return json.load(f).get("fir_fixed_kernel_bytes_per_launch")
-    return None
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        ratio = json.load(f).get("hbm_bytes_over_algorithmic")
+    return None if ratio is None else int(ratio * algorithmic_bytes_per_launch)
 
 
 def spot_check(gd, vin, vout, mine, lengths, stream):

@@ -236,7 +236,9 @@ def test_pointwise_bit_exact(n, gd):
     assert bits_equal(gd.add_constant(up(), 1.1).numpy(), cpu.add_constant(x, 1.1))
     assert bits_equal(gd.add_constant(up(), 0.0).numpy(), x)
     assert bits_equal(gd.abs_(up()).numpy(), cpu.abs_(x))
-    assert bits_equal(gd.invert(up(), 0.3).numpy(), cpu.invert(x, 0.3))
+    got, want = gd.invert(up(), 0.3).numpy(), cpu.invert(x, 0.3)
+    nan = np.isnan(want)                                # the sign bit of a propagated NaN is not pinned
+    assert np.array_equal(np.isnan(got), nan) and bits_equal(got[~nan], want[~nan])
     assert bits_equal(gd.fill(up(), 2.5).numpy(), np.full(n, 2.5))
 
 
