@@ -385,7 +385,7 @@ class BinnedIntervals:
 
 def apply_intervals(v, start, end, val, overlap=OVERLAP_SUM, clear=False, missing=0.0, stream=None):
     b = BinnedIntervals(v.n, start, end, val)
-    call("gdsp_apply_intervals", v.ptr, v.n, *b._args(), overlap, int(clear), float(missing), _sp(stream))
+    call("gdsp_apply_intervals", v.ptr, v.n, *b._args(), overlap, 3 if clear else 0, float(missing), _sp(stream))
     sync(stream)
     return v
 

@@ -18,6 +18,10 @@
 // min/max/first-touch ("clear") rules.  Tiles without intervals are skipped,
 // or just filled when the vector is being cleared.  Traffic: 16 B/base for
 // touched tiles (8 B when clearing) plus 16 B per (interval, tile) pair.
+// `clear` carries two bits so that a long interval stream can be applied in
+// batches: GDSP_CLEAR_FILL starts every base from the missing value (first
+// batch), GDSP_CLEAR_FIRST_TOUCH keeps the reference's "a base still holding the
+// missing value is assigned, not accumulated" rule (every batch).
 
 #include "gdsp_common.h"
 
@@ -38,7 +42,9 @@ void intervals_kernel (double* __restrict__ v, uint32_t n,
 	const uint32_t tile  = blockIdx.x;
 	const uint32_t lo    = tileOffsets[tile], hi = tileOffsets[tile+1];
 	const bool     scale = (OP == IV_MUL) || (OP == IV_DIV);
-	if ((lo == hi) && !clear && !scale) return;          // untouched tile
+	const bool     touch = (clear & GDSP_CLEAR_FIRST_TOUCH) != 0;   // "still missing -> assign"
+	const bool     fill  = (clear & GDSP_CLEAR_FILL) != 0;          // start from the missing value
+	if ((lo == hi) && !fill && !scale) return;           // untouched tile
 
 	const uint64_t base = (uint64_t) tile * IV_TILE;
 	uint32_t pos[IV_PER];
@@ -49,7 +55,7 @@ void intervals_kernel (double* __restrict__ v, uint32_t n,
 		{
 		pos[k]     = (uint32_t) (base + (uint64_t) k*IV_THREADS + threadIdx.x);   // coalesced per k
 		covered[k] = false;
-		x[k]       = clear? missingVal : ((pos[k] < n)? v[pos[k]] : 0.0);
+		x[k]       = fill? missingVal : ((pos[k] < n)? v[pos[k]] : 0.0);
 		}
 
 	for (uint32_t j=lo ; j<hi ; j++)
@@ -64,7 +70,7 @@ void intervals_kernel (double* __restrict__ v, uint32_t n,
 				{
 				if (scale)                                                    // multiply.c:340-341, :735-736
 					{ x[k] = (OP == IV_MUL)? x[k] * a : x[k] / a;  covered[k] = true; }
-				else if (clear && (x[k] == missingVal)) x[k] = a;             // genodsp.c:1311,1319,1327
+				else if (touch && (x[k] == missingVal)) x[k] = a;             // genodsp.c:1311,1319,1327
 				else if (OP == IV_SUM) x[k] = x[k] + a;                        // genodsp.c:1328
 				else if (OP == IV_MIN) { if (a < x[k]) x[k] = a; }             // genodsp.c:1312
 				else                   { if (a > x[k]) x[k] = a; }             // genodsp.c:1320

@@ -1,0 +1,973 @@
+/* genodsp_hip.c -- host driver of the MI355X genodsp: the `= operator` pipeline CLI.
+ *
+ *   genodsp_hip --chromosomes=<file> [options] (= <operator> [args])*   < intervals > intervals
+ *
+ * Command line, interval text in/out, named variables and the operator table are
+ * those of the reference driver (rsharris/genodsp genodsp.c; lines cited inline),
+ * so a pipeline written for `genodsp` runs unchanged.  What differs is underneath:
+ * every chromosome is a pair of f64 arrays in HBM (the vector and its partner, so
+ * out-of-place operators finish with a pointer flip instead of the reference's
+ * copy-back pass, e.g. sum.c:672-673), operators launch kernels of
+ * libgenodsp_hip.so on a stream, intervals are parsed into pinned staging buffers
+ * and applied on the device in file order, and output runs are found on the device
+ * so that only (start,end,value) triples come back over PCIe.  With --gpus=N whole
+ * chromosomes are dealt to N devices longest-first (LPT); no operator except
+ * percentile/invert needs anything from another device.
+ *
+ * There is no CPU compute path here: if the HIP library or a GPU is missing the
+ * program stops with a message.
+ */
+#include <stdlib.h>
+#include <stdio.h>
+#include <string.h>
+#include <stdarg.h>
+#include <float.h>
+#include "genodsp_interface.h"
+#include "genodsp_hip.h"
+#include "utilities.h"
+#include "host_services.h"
+
+#define programName            "genodsp_hip"
+#define programVersion         "0.1 (MI355X/gfx950; genodsp 0.0.10 command set)"
+#define specialPipeChar        '='
+
+/* ------------------------------------------------------------ operator table */
+/* same names, aliases and order as the reference's dspTable (genodsp.c:117-174);
+ * operators outside the hot-path scope (clump, map, mask, or/and, minover...) are
+ * not in this build and are reported as such */
+dspprototypes(op_window_sum)     dspprototypes(op_sliding_sum)   dspprototypes(op_smooth)
+dspprototypes(op_cumulative_sum) dspprototypes(op_percentile)    dspprototypes(op_add)
+dspprototypes(op_subtract)       dspprototypes(op_add_constant)  dspprototypes(op_invert)
+dspprototypes(op_multiply)       dspprototypes(op_divide)        dspprototypes(op_absolute_value)
+dspprototypes(op_clip)           dspprototypes(op_erase)         dspprototypes(op_binarize)
+dspprototypes(op_local_minima)   dspprototypes(op_local_maxima)  dspprototypes(op_best_local_min)
+dspprototypes(op_best_local_max) dspprototypes(op_close)         dspprototypes(op_open)
+dspprototypes(op_dilate)         dspprototypes(op_erode)         dspprototypes(op_input)
+dspprototypes(op_output)         dspprototypes(op_show_variables)
+
+static dspinfo dspTable[] =
+	{dspinforecord("sum"           , op_window_sum)     , dspinfoalias ("window_sum")     ,
+	 dspinforecord("slidingsum"    , op_sliding_sum)    , dspinfoalias ("sliding_sum")    ,
+	 dspinforecord("smooth"        , op_smooth)         ,
+	 dspinforecord("cumulativesum" , op_cumulative_sum) , dspinfoalias ("cumulative")     , dspinfoalias ("integrate"),
+	 dspinforecord("percentile"    , op_percentile)     ,
+	 dspinforecord("add"           , op_add)            ,
+	 dspinforecord("subtract"      , op_subtract)       ,
+	 dspinforecord("addconst"      , op_add_constant)   , dspinfoalias ("add_const")      ,
+	 dspinforecord("invert"        , op_invert)         ,
+	 dspinforecord("multiply"      , op_multiply)       ,
+	 dspinforecord("divide"        , op_divide)         ,
+	 dspinforecord("abs"           , op_absolute_value) ,
+	 dspinforecord("clip"          , op_clip)           ,
+	 dspinforecord("erase"         , op_erase)          ,
+	 dspinforecord("binarize"      , op_binarize)       ,
+	 dspinforecord("localmin"      , op_local_minima)   , dspinfoalias ("local_min")      ,
+	 dspinforecord("localmax"      , op_local_maxima)   , dspinfoalias ("local_max")      ,
+	 dspinforecord("bestmin"       , op_best_local_min) , dspinfoalias ("best_min")       ,
+	 dspinfoalias ("bestlocalmin")                      , dspinfoalias ("best_local_min") ,
+	 dspinforecord("bestmax"       , op_best_local_max) , dspinfoalias ("best_max")       ,
+	 dspinfoalias ("bestlocalmax")                      , dspinfoalias ("best_local_max") ,
+	 dspinforecord("close"         , op_close)          ,
+	 dspinforecord("open"          , op_open)           ,
+	 dspinforecord("dilate"        , op_dilate)         ,
+	 dspinforecord("erode"         , op_erode)          ,
+	 dspinforecord("input"         , op_input)          ,
+	 dspinforecord("output"        , op_output)         ,
+	 dspinforecord("variables"     , op_show_variables) };
+#define dspTableLen (sizeof(dspTable)/sizeof(dspinfo))
+
+static const char* notInThisBuild[] =
+	{ "clump", "anticlump", "anti_clump", "skimp", "mask", "masknot", "mask_not", "or", "and",
+	  "maxover", "max_over", "minover", "min_over", "minwith", "min_with", "maxwith", "max_with", "map", NULL };
+
+/* ------------------------------------------------------------------- globals */
+spec*  chromsOfInterest = NULL;
+spec** chromsSorted     = NULL;
+int    trackOperations  = false;
+int    reportComments   = false;
+u32    reportInputProgress = 0;
+
+static dspop* pipeline = NULL, *tailOp = NULL;
+static int valColumn      = 4-1;                 /* genodsp.c:48-56 defaults */
+static int noOutputValues = false;
+static int valPrecision   = 0;
+static int collapseRuns   = true;
+static int showUncovered  = uncovered_hide;
+static int clipToLength   = false;
+static int originOne      = false;
+static int inhibitOutput  = false;
+static int numDevices     = 1;
+int        firMode        = GDSP_FIR_EXACT;      /* --smooth=exact|fma (see ops_sum.c) */
+
+/* a chromosome as the driver sees it: the public spec first, device state after */
+typedef struct xspec
+	{
+	spec     pub;
+	valtype* partner;     /* second HBM buffer, same length */
+	int      device;
+	} xspec;
+
+typedef struct devstate
+	{
+	void*    stream;
+	valtype* scratch[4];  /* lazily allocated, longest-local-chromosome sized */
+	int      scratchInUse[4];
+	u32      maxLength;   /* longest chromosome on this device */
+	} devstate;
+
+static devstate devs[64];
+static int      currentDevice = 0;
+
+void check_gdsp (int status, const char* what)
+	{
+	if (status == GDSP_OK) return;
+	fprintf (stderr, "[%s] %s: %s\n", programName, what, gdsp_last_error ());
+	exit (EXIT_FAILURE);
+	}
+
+/* ------------------------------------------------------------------ chastise */
+static opfunc_usage chastiseUsage     = NULL;
+static char*        chastiseUsageName = NULL;
+
+static void usage (void)
+	{
+	fprintf (stderr,
+	"usage: [cat <file>] | %s --chromosomes=<filename> [options] [operations]\n\n"
+	"  --chromosomes=<filename>  (required) chromosome names and lengths, two columns\n"
+	"  <name>:<length>           ... or give chromosomes directly (also <name>:<start>:<end>)\n"
+	"  --value=<col>             column of the interval value (default 4)\n"
+	"  --novalue                 intervals carry no value (each counts 1)\n"
+	"  --nooutputvalue           write intervals without their value\n"
+	"  --precision=<number>      digits after the decimal point in output (default 0)\n"
+	"  --nocollapse              one output line per base, no run collapsing\n"
+	"  --uncovered:hide|show|NA  how zero-valued stretches are written (default hide)\n"
+	"  --cliptochromosome        clip intervals to the chromosome instead of failing\n"
+	"  --origin=one|zero         interval coordinate convention (default zero, half-open)\n"
+	"  --nooutput                do not write the resulting signal\n"
+	"  --window=<length>         (W=) default window size for windowed operators\n"
+	"  --gpus=<n>                shard whole chromosomes over n GPUs (default 1)\n"
+	"  --smooth=exact|fma        arithmetic of `smooth`: exact = bit-identical to genodsp\n"
+	"                            (default); fma = fused multiply-add, one rounding per tap\n"
+	"  --help[=<operator>]  ?  ?<operator>   operator help\n"
+	"  --report=comments  --progress=input:<n>  --progress=operations  --version\n\n"
+	"Overlapping input intervals are summed. Input comes from stdin unless the first\n"
+	"operator is \"input\". Operations have the form  = <operator> [arguments].\n", programName);
+	exit (EXIT_FAILURE);
+	}
+
+void chastise (const char* format, ...)          /* genodsp.c:193-209 */
+	{
+	va_list args;
+	va_start (args, format);
+	if (format != NULL) vfprintf (stderr, format, args);
+	va_end (args);
+	if (chastiseUsage != NULL)
+		{
+		(*chastiseUsage) (chastiseUsageName, stderr, "  ");
+		exit (EXIT_FAILURE);
+		}
+	usage ();
+	}
+
+static void usage_operations (void)
+	{
+	fprintf (stderr, "Operations (general form is %c <operator> [arguments]):\n", specialPipeChar);
+	for (u32 i=0 ; i<dspTableLen ; i++)
+		{ if (dspTable[i].funcShort != NULL) (*dspTable[i].funcShort) (dspTable[i].name, 12, stderr, "  "); }
+	exit (EXIT_FAILURE);
+	}
+
+static dspinfo* find_operator (const char* name)  /* alias rows resolve to the row above, genodsp.c:666-673 */
+	{
+	dspinfo* real = NULL;
+	for (u32 i=0 ; i<dspTableLen ; i++)
+		{
+		if (dspTable[i].funcShort != NULL) real = &dspTable[i];
+		if (strcmp (name, dspTable[i].name) == 0) return real;
+		}
+	return NULL;
+	}
+
+/* ------------------------------------------------------------- named globals */
+typedef struct namedglobal { struct namedglobal* next;  char* name;  valtype v; } namedglobal;
+static namedglobal* namedGlobalHead = NULL;
+
+static namedglobal* find_named_global (const char* name)
+	{
+	for (namedglobal* g=namedGlobalHead ; g!=NULL ; g=g->next)
+		{ if (strcmp (name, g->name) == 0) return g; }
+	return NULL;
+	}
+
+void set_named_global (char* name, valtype val)   /* newest first, like genodsp.c:2093-2104 */
+	{
+	namedglobal* g = find_named_global (name);
+	if (g == NULL)
+		{
+		g = (namedglobal*) malloc (sizeof(namedglobal));
+		if (g == NULL) { fprintf (stderr, "out of memory for named global \"%s\"\n", name);  exit (EXIT_FAILURE); }
+		g->name = copy_string (name);
+		g->next = namedGlobalHead;
+		namedGlobalHead = g;
+		}
+	g->v = val;
+	}
+
+valtype get_named_global (char* name, valtype defaultVal)
+	{ namedglobal* g = find_named_global (name);  return (g == NULL)? defaultVal : g->v; }
+
+int named_global_exists (char* name, valtype* val)
+	{
+	namedglobal* g = find_named_global (name);
+	if (g == NULL) return false;
+	if (val != NULL) *val = g->v;
+	return true;
+	}
+
+void report_named_globals (FILE* f, char* indent)  /* genodsp.c:2176-2199 */
+	{
+	int w = 1;
+	if (indent == NULL) indent = "";
+	for (namedglobal* g=namedGlobalHead ; g!=NULL ; g=g->next)
+		{ int n = (int) strlen (g->name);  if (n > w) w = n; }
+	if (w > 20) w = 20;
+	for (namedglobal* g=namedGlobalHead ; g!=NULL ; g=g->next)
+		fprintf (f, "%s%*s = " valtypeFmt "\n", indent, w, g->name, g->v);
+	}
+
+/* progress line that overwrites itself unless it ends in a newline (genodsp.c:2219-2238) */
+void tracking_report (const char* format, ...)
+	{
+	static int prevLen = 0;
+	char    line[1001];
+	va_list args;
+	va_start (args, format);
+	line[0] = 0;
+	if (format != NULL) vsnprintf (line, sizeof(line), format, args);
+	va_end (args);
+	int len = (int) strlen (line);
+	int nl  = (len > 0) && (line[len-1] == '\n');
+	if (nl) line[--len] = 0;
+	fprintf (stderr, "%s", line);
+	if (prevLen > len) fprintf (stderr, "%*s", prevLen - len, "");
+	if (nl) { fprintf (stderr, "\n");  prevLen = 0; }
+	else    { fprintf (stderr, "\r");  prevLen = len; }
+	}
+
+/* --------------------------------------------------------------- chromosomes */
+static int add_chromosome_spec (char* name, u32 chromStart, u32 chromLength)   /* genodsp.c:1014-1060 */
+	{
+	spec* tail = NULL;
+	if (chromLength == 0) return true;
+	for (spec* s=chromsOfInterest ; s!=NULL ; s=s->next)
+		{ tail = s;  if (strcmp (name, s->chrom) == 0) return false; }
+	xspec* x = (xspec*) calloc (1, sizeof(xspec));
+	if (x == NULL) { fprintf (stderr, "out of memory for chromosome \"%s\"\n", name);  exit (EXIT_FAILURE); }
+	x->pub.chrom  = copy_string (name);
+	x->pub.start  = chromStart;
+	x->pub.length = chromLength;
+	if (tail == NULL) chromsOfInterest = &x->pub;  else tail->next = &x->pub;
+	return true;
+	}
+
+spec* find_chromosome_spec (char* chrom)
+	{
+	for (spec* s=chromsOfInterest ; s!=NULL ; s=s->next)
+		{ if (strcmp (chrom, s->chrom) == 0) return s; }
+	return NULL;
+	}
+
+static void read_chromosome_lengths (char* filename)      /* genodsp.c:728-814 */
+	{
+	char line[1001];
+	u32  lineNumber = 0;
+	FILE* f = fopen (filename, "rt");
+	if (f == NULL) { fprintf (stderr, "can't open \"%s\" for reading\n", filename);  exit (EXIT_FAILURE); }
+	while (fgets (line, sizeof(line), f) != NULL)
+		{
+		lineNumber++;
+		size_t len = strlen (line);
+		if ((len == sizeof(line)-1) && (line[len-1] != '\n'))
+			{ fprintf (stderr, "problem at line %u, line is longer than internal buffer\n", lineNumber);  exit (EXIT_FAILURE); }
+		char* scan = skip_whitespace (line);
+		if ((*scan == 0) || (*scan == '#')) continue;
+		char* chrom = line;
+		char* mark = skip_darkspace (chrom);
+		scan = skip_whitespace (mark);
+		if (*mark != 0) *mark = 0;
+		if (*scan == 0)
+			{ fprintf (stderr, "problem at line %u, line contains no chromosome length\n", lineNumber);  exit (EXIT_FAILURE); }
+		char* field = scan;
+		mark = skip_darkspace (scan);
+		if (*mark != 0) *mark = 0;
+		if (!add_chromosome_spec (chrom, 0, (u32) string_to_u32 (field)))
+			{ fprintf (stderr, "problem at line %u, chromosome \"%s\" appears more than once\n", lineNumber, chrom);  exit (EXIT_FAILURE); }
+		}
+	fclose (f);
+	}
+
+static int longest_first (const void* a, const void* b)
+	{
+	u32 x = (*(spec* const*) a)->length, y = (*(spec* const*) b)->length;
+	return (x < y) - (x > y);
+	}
+
+static void sort_chromosomes_by_length (void)             /* genodsp.c:1113-1145 */
+	{
+	int n = 0;
+	for (spec* s=chromsOfInterest ; s!=NULL ; s=s->next) n++;
+	chromsSorted = (spec**) malloc ((n+1) * sizeof(spec*));
+	if (chromsSorted == NULL) { fprintf (stderr, "out of memory\n");  exit (EXIT_FAILURE); }
+	n = 0;
+	for (spec* s=chromsOfInterest ; s!=NULL ; s=s->next) chromsSorted[n++] = s;
+	chromsSorted[n] = NULL;
+	qsort (chromsSorted, n, sizeof(spec*), longest_first);
+	}
+
+/* ------------------------------------------------------------ device services */
+void select_device_of (spec* s)
+	{
+	int d = ((xspec*) s)->device;
+	if (d != currentDevice) { check_gdsp (gdsp_set_device (d), "select device");  currentDevice = d; }
+	}
+
+void* op_stream (void) { return devs[currentDevice].stream; }
+
+valtype* partner_vector (char* vName)
+	{
+	spec* s = find_chromosome_spec (vName);
+	return (s == NULL)? NULL : ((xspec*) s)->partner;
+	}
+
+void flip_vector (char* vName)
+	{
+	spec* s = find_chromosome_spec (vName);
+	if (s == NULL) return;
+	valtype* t = s->valVector;  s->valVector = ((xspec*) s)->partner;  ((xspec*) s)->partner = t;
+	}
+
+valtype* get_scratch_vector (void)                        /* genodsp.c:1904-1940, on the current device */
+	{
+	devstate* d = &devs[currentDevice];
+	for (int i=0 ; i<4 ; i++)
+		{
+		if (d->scratchInUse[i]) continue;
+		if (d->scratch[i] == NULL)
+			{
+			/* longest local chromosome, but never less than what the select histograms need */
+			size_t n = (d->maxLength > 16384)? d->maxLength : 16384;
+			check_gdsp (gdsp_malloc ((void**) &d->scratch[i], n * sizeof(valtype)), "allocate scratch vector");
+			}
+		d->scratchInUse[i] = true;
+		return d->scratch[i];
+		}
+	fprintf (stderr, "[%s] internal error: out of scratch vectors\n", programName);
+	exit (EXIT_FAILURE);
+	}
+
+void release_scratch_vector (valtype* v)
+	{
+	devstate* d = &devs[currentDevice];
+	for (int i=0 ; i<4 ; i++) { if (d->scratch[i] == v) { d->scratchInUse[i] = false;  return; } }
+	}
+
+void sync_all_devices (void)
+	{
+	for (int d=0 ; d<numDevices ; d++)
+		{
+		check_gdsp (gdsp_set_device (d), "select device");
+		check_gdsp (gdsp_stream_sync (devs[d].stream), "synchronise");
+		}
+	check_gdsp (gdsp_set_device (currentDevice), "select device");
+	}
+
+int device_count_in_use (void) { return numDevices; }
+int device_index_of (spec* s)  { return ((xspec*) s)->device; }
+
+/* deal chromosomes to devices longest-first onto the least loaded (LPT), then allocate */
+static void allocate_vectors (void)
+	{
+	u64 load[64] = { 0 };
+	for (int i=0 ; chromsSorted[i]!=NULL ; i++)
+		{
+		int best = 0;
+		for (int d=1 ; d<numDevices ; d++) { if (load[d] < load[best]) best = d; }
+		((xspec*) chromsSorted[i])->device = best;
+		load[best] += chromsSorted[i]->length;
+		if (chromsSorted[i]->length > devs[best].maxLength) devs[best].maxLength = chromsSorted[i]->length;
+		}
+	for (int d=0 ; d<numDevices ; d++)
+		{
+		check_gdsp (gdsp_set_device (d), "select device");
+		check_gdsp (gdsp_stream_create (&devs[d].stream), "create stream");
+		}
+	for (int i=0 ; chromsSorted[i]!=NULL ; i++)
+		{
+		spec*  s = chromsSorted[i];
+		xspec* x = (xspec*) s;
+		if (trackOperations)
+			tracking_report ("allocate(%s / %s bytes)\n", s->chrom, ucommatize (s->length));
+		check_gdsp (gdsp_set_device (x->device), "select device");
+		currentDevice = x->device;
+		size_t bytes = ((size_t) s->length + 2) * sizeof(valtype);
+		check_gdsp (gdsp_malloc ((void**) &s->valVector, bytes), "allocate chromosome vector");
+		check_gdsp (gdsp_malloc ((void**) &x->partner,   bytes), "allocate chromosome vector");
+		check_gdsp (gdsp_fill (s->valVector, s->length, 0.0, devs[x->device].stream), "clear chromosome vector");
+		}
+	if (trackOperations) tracking_report ("allocate(--done--)\n");
+	}
+
+/* ---------------------------------------------------------------- text ingest */
+int read_interval (FILE* f, char* buffer, int bufferLen, int valCol,     /* genodsp.c:1384-1534 */
+                   char** _chrom, u32* _start, u32* _end, valtype* _val)
+	{
+	static u64 lineNumber = 0;
+	static int missingEol = false;
+	char *scan, *mark, *field;
+
+	for (;;)
+		{
+		if (fgets (buffer, bufferLen, f) == NULL) return false;
+		lineNumber++;
+		if (missingEol)
+			{ fprintf (stderr, "problem at line %s, line is longer than internal buffer\n", ucommatize (lineNumber-1));  exit (EXIT_FAILURE); }
+		size_t len = strlen (buffer);
+		if (len != 0) missingEol = (buffer[len-1] != '\n');
+		if (strcmp_prefix (buffer, "track ") == 0) continue;
+
+		int progressNow = (reportInputProgress != 0)
+		               && ((lineNumber == 1) || (lineNumber % reportInputProgress == 0));
+		scan = skip_whitespace (buffer);
+		if (*scan == 0)
+			{ if (progressNow) fprintf (stderr, "progress: input line %s\n", ucommatize (lineNumber));  continue; }
+		if (*scan == '#')
+			{
+			if (reportComments)   fprintf (stderr, "input line %s: %s", ucommatize (lineNumber), scan);
+			else if (progressNow) fprintf (stderr, "progress: input line %s\n", ucommatize (lineNumber));
+			continue;
+			}
+		if (progressNow) fprintf (stderr, "progress: input line %s\n", ucommatize (lineNumber));
+		break;
+		}
+
+	char* chrom = scan = buffer;
+	if (*scan == ' ')
+		{ fprintf (stderr, "problem at line %s, line contains no chromosome or begins with whitespace\n", ucommatize (lineNumber));  exit (EXIT_FAILURE); }
+	mark = skip_darkspace (scan);  scan = skip_whitespace (mark);  if (*mark != 0) *mark = 0;
+	if (*scan == 0)
+		{ fprintf (stderr, "problem at line %s, line contains no interval start\n", ucommatize (lineNumber));  exit (EXIT_FAILURE); }
+	field = scan;
+	mark = skip_darkspace (scan);  scan = skip_whitespace (mark);  if (*mark != 0) *mark = 0;
+	u32 start = (u32) string_to_u32 (field);
+	if (*scan == 0)
+		{ fprintf (stderr, "problem at line %s, line contains no interval end\n", ucommatize (lineNumber));  exit (EXIT_FAILURE); }
+	field = scan;
+	mark = skip_darkspace (scan);  scan = skip_whitespace (mark);  if (*mark != 0) *mark = 0;
+	u32 end = (u32) string_to_u32 (field);
+
+	valtype val = 1.0;
+	if ((valCol != -1) && (_val != NULL))
+		{
+		for (int col=3 ; col<=valCol ; col++)
+			{
+			if (*scan == 0)
+				{ fprintf (stderr, "problem at line %s, line contains no interval value\n", ucommatize (lineNumber));  exit (EXIT_FAILURE); }
+			field = scan;
+			mark = skip_darkspace (scan);  scan = skip_whitespace (mark);
+			}
+		if (*mark != 0) *mark = 0;
+		val = string_to_valtype (field);
+		}
+	if (_chrom != NULL) *_chrom = chrom;
+	if (_start != NULL) *_start = start;
+	if (_end   != NULL) *_end   = end;
+	if (_val   != NULL) *_val   = val;
+	return true;
+	}
+
+/* Pending intervals per chromosome, in file order, flushed to the device in
+ * batches: pinned staging -> hipMemcpyAsync -> gdsp_apply_intervals. */
+#define BATCH_INTERVALS (8*1024*1024)
+
+typedef struct pending { u32* start;  u32* end;  valtype* val;  u32 count, cap; } pending;
+static pending* pend = NULL;          /* indexed like chromsSorted */
+static int      numChroms = 0;
+static u64      pendTotal = 0;
+
+/* staging shared by all flushes (pinned) and its device mirror, per device */
+typedef struct staging
+	{
+	size_t   ivCap, offCap, listCap;
+	u32     *h_start, *h_end, *h_off, *h_list;   valtype* h_val;
+	u32     *d_start, *d_end, *d_off, *d_list;   valtype* d_val;
+	} staging;
+static staging stage[64];
+
+static int sorted_index (spec* s)
+	{ for (int i=0 ; chromsSorted[i]!=NULL ; i++) { if (chromsSorted[i] == s) return i; }  return -1; }
+
+void ib_begin (void)
+	{
+	if (pend == NULL)
+		{
+		for (numChroms=0 ; chromsSorted[numChroms]!=NULL ; numChroms++) ;
+		pend = (pending*) calloc (numChroms, sizeof(pending));
+		}
+	for (int i=0 ; i<numChroms ; i++) pend[i].count = 0;
+	pendTotal = 0;
+	}
+
+void ib_add (spec* s, u32 start, u32 end, valtype val)
+	{
+	pending* p = &pend[sorted_index (s)];
+	if (p->count == p->cap)
+		{
+		p->cap   = (p->cap == 0)? 1024 : 2*p->cap;
+		p->start = (u32*)     realloc (p->start, p->cap * sizeof(u32));
+		p->end   = (u32*)     realloc (p->end,   p->cap * sizeof(u32));
+		p->val   = (valtype*) realloc (p->val,   p->cap * sizeof(valtype));
+		if ((p->start == NULL) || (p->end == NULL) || (p->val == NULL))
+			{ fprintf (stderr, "out of memory buffering intervals\n");  exit (EXIT_FAILURE); }
+		}
+	p->start[p->count] = start;  p->end[p->count] = end;  p->val[p->count] = val;
+	p->count++;
+	pendTotal++;
+	}
+
+u64 ib_pending (void) { return pendTotal; }
+
+static void grow (void** h, void** d, size_t* cap, size_t want, size_t elem)
+	{
+	if (want <= *cap) return;
+	size_t n = (*cap == 0)? 4096 : *cap;
+	while (n < want) n *= 2;
+	if (*h != NULL) check_gdsp (gdsp_host_free (*h), "free staging");
+	if (*d != NULL) check_gdsp (gdsp_free (*d), "free staging");
+	check_gdsp (gdsp_host_alloc (h, n * elem), "allocate pinned staging");
+	check_gdsp (gdsp_malloc (d, n * elem), "allocate device staging");
+	*cap = n;
+	}
+
+/* stage one chromosome's pending intervals on its device and return the device arrays */
+static void stage_chromosome (int ci, staging** out)
+	{
+	spec*    s  = chromsSorted[ci];
+	pending* p  = &pend[ci];
+	select_device_of (s);
+	staging* st = &stage[currentDevice];
+	void*    stream = op_stream ();
+	u32      ntiles = (u32) (((u64) s->length + gdsp_interval_tile () - 1) / gdsp_interval_tile ());
+	u64      listLen = 0;
+
+	check_gdsp (gdsp_stream_sync (stream), "synchronise before restaging");   /* the previous flush is done with the buffers */
+	/* three arrays share ivCap: grow them together */
+	if ((size_t) p->count + 1 > st->ivCap)
+		{
+		size_t cap = st->ivCap, c2 = st->ivCap, c3 = st->ivCap;
+		grow ((void**) &st->h_start, (void**) &st->d_start, &cap, (size_t) p->count + 1, sizeof(u32));
+		grow ((void**) &st->h_end,   (void**) &st->d_end,   &c2,  (size_t) p->count + 1, sizeof(u32));
+		grow ((void**) &st->h_val,   (void**) &st->d_val,   &c3,  (size_t) p->count + 1, sizeof(valtype));
+		st->ivCap = cap;
+		}
+	grow ((void**) &st->h_off, (void**) &st->d_off, &st->offCap, (size_t) ntiles + 1, sizeof(u32));
+
+	memcpy (st->h_start, p->start, (size_t) p->count * sizeof(u32));
+	memcpy (st->h_end,   p->end,   (size_t) p->count * sizeof(u32));
+	memcpy (st->h_val,   p->val,   (size_t) p->count * sizeof(valtype));
+	check_gdsp (gdsp_bin_intervals (s->length, st->h_start, st->h_end, p->count, st->h_off, NULL, &listLen), "bin intervals");
+	grow ((void**) &st->h_list, (void**) &st->d_list, &st->listCap, (size_t) listLen + 1, sizeof(u32));
+	check_gdsp (gdsp_bin_intervals (s->length, st->h_start, st->h_end, p->count, st->h_off, st->h_list, &listLen), "bin intervals");
+
+	if (p->count != 0)
+		{
+		check_gdsp (gdsp_memcpy_h2d (st->d_start, st->h_start, (size_t) p->count * sizeof(u32),     stream), "stage intervals");
+		check_gdsp (gdsp_memcpy_h2d (st->d_end,   st->h_end,   (size_t) p->count * sizeof(u32),     stream), "stage intervals");
+		check_gdsp (gdsp_memcpy_h2d (st->d_val,   st->h_val,   (size_t) p->count * sizeof(valtype), stream), "stage intervals");
+		}
+	check_gdsp (gdsp_memcpy_h2d (st->d_off, st->h_off, ((size_t) ntiles + 1) * sizeof(u32), stream), "stage intervals");
+	if (listLen != 0)
+		check_gdsp (gdsp_memcpy_h2d (st->d_list, st->h_list, (size_t) listLen * sizeof(u32), stream), "stage intervals");
+	*out = st;
+	}
+
+/* apply and forget the pending intervals; `everyChromosome` also visits chromosomes
+ * without intervals (needed when clearing, or for multiply/divide's gap rule) */
+void ib_flush_apply (int overlapOp, int clearFlags, valtype missingVal, int everyChromosome)
+	{
+	for (int ci=0 ; ci<numChroms ; ci++)
+		{
+		if ((pend[ci].count == 0) && !everyChromosome) continue;
+		staging* st;
+		stage_chromosome (ci, &st);
+		spec* s = chromsSorted[ci];
+		check_gdsp (gdsp_apply_intervals (s->valVector, s->length, st->d_start, st->d_end, st->d_val, st->d_off, st->d_list,
+		                                  overlapOp, clearFlags, missingVal, op_stream ()), "apply intervals");
+		pend[ci].count = 0;
+		}
+	pendTotal = 0;
+	}
+
+void ib_flush_scale (int divide, valtype infinityVal)
+	{
+	for (int ci=0 ; ci<numChroms ; ci++)
+		{
+		staging* st;
+		stage_chromosome (ci, &st);
+		spec* s = chromsSorted[ci];
+		check_gdsp (gdsp_scale_intervals (s->valVector, s->length, st->d_start, st->d_end, st->d_val, st->d_off, st->d_list,
+		                                  divide, infinityVal, op_stream ()), "scale by intervals");
+		pend[ci].count = 0;
+		}
+	pendTotal = 0;
+	}
+
+/* read_intervals, genodsp.c:1187-1350: same routing, origin, clipping and failure rules;
+ * the per-base loops run on the device in file order */
+void read_intervals (FILE* f, int valCol, int origin1, int overlapOp, int clear, valtype missingVal)
+	{
+	char     line[1001], prevChrom[1001];
+	char*    chrom;
+	spec*    s = NULL;
+	u32      start, end, o = origin1? 1 : 0;
+	valtype  val;
+	int      clearFlags = clear? GDSP_CLEAR_BOTH : 0;
+
+	if (trackOperations) { for (int i=0 ; chromsSorted[i]!=NULL ; i++) chromsSorted[i]->flag = false; }
+	ib_begin ();
+	prevChrom[0] = 0;
+	while (read_interval (f, line, sizeof(line), valCol, &chrom, &start, &end, &val))
+		{
+		if (strcmp (chrom, prevChrom) != 0)
+			{ s = find_chromosome_spec (chrom);  safe_strncpy (prevChrom, chrom, sizeof(prevChrom)-1); }
+		if (s == NULL) continue;
+		if (trackOperations && !s->flag) { tracking_report ("input(%s)\n", chrom);  s->flag = true; }
+
+		start -= o;
+		u32 adjStart = start, adjEnd = end;
+		if (clipToLength)
+			{
+			if (start > s->start + s->length) adjStart = start = s->start + s->length;
+			if (end   > s->start + s->length) adjEnd   = end   = s->start + s->length;
+			}
+		if (s->start == 0)
+			{
+			if (end > s->length)
+				{
+				fprintf (stderr, "%s %d %d is beyond the end of the chromosome (L=%d)\n", chrom, start, end, s->length);
+				exit (EXIT_FAILURE);
+				}
+			}
+		else
+			{
+			if (end <= s->start) continue;
+			adjEnd   = end - s->start;
+			adjStart = (start <= s->start)? 0 : start - s->start;
+			if (adjStart >= s->length) continue;
+			if (adjEnd   >= s->length) adjEnd = s->length;
+			}
+		ib_add (s, adjStart, adjEnd, val);
+		if (ib_pending () >= BATCH_INTERVALS)
+			{
+			ib_flush_apply (overlapOp, clearFlags, missingVal, (clearFlags & GDSP_CLEAR_FILL) != 0);
+			clearFlags &= ~GDSP_CLEAR_FILL;            /* later batches keep only the first-touch rule */
+			}
+		}
+	ib_flush_apply (overlapOp, clearFlags, missingVal, (clearFlags & GDSP_CLEAR_FILL) != 0);
+	if (trackOperations) tracking_report ("input(--done--)\n");
+	}
+
+/* ---------------------------------------------------------------- text output */
+/* report_intervals, genodsp.c:1561-1691: runs come from the device
+ * (gdsp_report_runs), the NA bookkeeping and formatting are done here */
+void report_intervals (FILE* f, int precision, int noValues, int collapse, int uncovered, int origin1)
+	{
+	u32 o = origin1? 1 : 0;
+	for (spec* s=chromsOfInterest ; s!=NULL ; s=s->next)
+		{
+		if (trackOperations) tracking_report ("output(%s)\n", s->chrom);
+		select_device_of (s);
+		void* stream = op_stream ();
+		u32   count = 0;
+		u32*  d_count;  void* d_work;
+		check_gdsp (gdsp_malloc ((void**) &d_count, 16), "allocate run count");
+		check_gdsp (gdsp_malloc (&d_work, gdsp_report_runs_work (s->length)), "allocate run workspace");
+		check_gdsp (gdsp_report_runs (s->valVector, s->length, collapse, uncovered, NULL, NULL, NULL, 0, d_count, d_work, stream), "count runs");
+		check_gdsp (gdsp_memcpy_d2h (&count, d_count, sizeof(u32), stream), "fetch run count");
+		check_gdsp (gdsp_stream_sync (stream), "synchronise");
+
+		u32 *runStart = NULL, *runEnd = NULL;  valtype* runVal = NULL;
+		if (count != 0)
+			{
+			u32 *d_s, *d_e;  valtype* d_v;
+			check_gdsp (gdsp_malloc ((void**) &d_s, (size_t) count * sizeof(u32)), "allocate runs");
+			check_gdsp (gdsp_malloc ((void**) &d_e, (size_t) count * sizeof(u32)), "allocate runs");
+			check_gdsp (gdsp_malloc ((void**) &d_v, (size_t) count * sizeof(valtype)), "allocate runs");
+			check_gdsp (gdsp_report_runs (s->valVector, s->length, collapse, uncovered, d_s, d_e, d_v, count, d_count, d_work, stream), "find runs");
+			runStart = (u32*) malloc ((size_t) count * sizeof(u32));
+			runEnd   = (u32*) malloc ((size_t) count * sizeof(u32));
+			runVal   = (valtype*) malloc ((size_t) count * sizeof(valtype));
+			if ((runStart == NULL) || (runEnd == NULL) || (runVal == NULL)) { fprintf (stderr, "out of memory for output runs\n");  exit (EXIT_FAILURE); }
+			check_gdsp (gdsp_memcpy_d2h (runStart, d_s, (size_t) count * sizeof(u32), stream), "fetch runs");
+			check_gdsp (gdsp_memcpy_d2h (runEnd,   d_e, (size_t) count * sizeof(u32), stream), "fetch runs");
+			check_gdsp (gdsp_memcpy_d2h (runVal,   d_v, (size_t) count * sizeof(valtype), stream), "fetch runs");
+			check_gdsp (gdsp_stream_sync (stream), "synchronise");
+			gdsp_free (d_s);  gdsp_free (d_e);  gdsp_free (d_v);
+			}
+		gdsp_free (d_count);  gdsp_free (d_work);
+
+		u32 prevOutputEnd = 0;
+		for (u32 r=0 ; r<count ; r++)
+			{
+			u32 outputStart = s->start + runStart[r], outputEnd = s->start + runEnd[r];
+			if ((uncovered == uncovered_NA) && (outputStart != prevOutputEnd))
+				fprintf (f, "%s\t%d\t%d\tNA\n", s->chrom, prevOutputEnd+o, outputStart);
+			if (noValues) fprintf (f, "%s\t%d\t%d\n", s->chrom, outputStart+o, outputEnd);
+			else          fprintf (f, "%s\t%d\t%d\t" valtypeFmtPrec "\n", s->chrom, outputStart+o, outputEnd, precision, runVal[r]);
+			prevOutputEnd = outputEnd;
+			}
+		if ((uncovered == uncovered_NA) && (s->start + s->length != prevOutputEnd))
+			fprintf (f, "%s\t%d\t%d\tNA\n", s->chrom, prevOutputEnd+o, s->start + s->length);
+		free (runStart);  free (runEnd);  free (runVal);
+		}
+	if (trackOperations) tracking_report ("output(--done--)\n");
+	}
+
+/* ------------------------------------------------------------- option parsing */
+static int process_operator_options (int argc, char** argv)    /* genodsp.c:634-723 */
+	{
+	int   consumed = 0;
+	char* arg = argv[0];
+	char* dspName;
+
+	if ((arg[0] == specialPipeChar) && (arg[1] == 0)) { argv++;  argc--;  consumed++;  dspName = argv[0]; }
+	else dspName = skip_whitespace (arg+1);
+
+	dspinfo* info = find_operator (dspName);
+	if (info == NULL)
+		{
+		for (int i=0 ; notInThisBuild[i]!=NULL ; i++)
+			{
+			if (strcmp (dspName, notInThisBuild[i]) == 0)
+				{
+				fprintf (stderr, "\"%s\" is a genodsp operation outside this build's GPU hot path (see DESIGN.md)\n", dspName);
+				exit (EXIT_FAILURE);
+				}
+			}
+		chastise ("\"%s\" is not a known operation\n", dspName);
+		}
+	argv++;  argc--;  consumed++;
+
+	int dspArgC = 0;
+	while ((dspArgC < argc) && (argv[dspArgC][0] != specialPipeChar)) { dspArgC++;  consumed++; }
+
+	chastiseUsage = info->funcUsage;  chastiseUsageName = info->name;
+	dspop* op = (*info->funcParse) (info->name, dspArgC, argv);
+	chastiseUsage = NULL;  chastiseUsageName = NULL;
+
+	op->name      = copy_string (info->name);
+	op->funcApply = info->funcApply;
+	op->funcFree  = info->funcFree;
+	op->next      = NULL;
+	if (tailOp == NULL) pipeline = op;  else tailOp->next = op;
+	tailOp = op;
+	return consumed;
+	}
+
+static void help_for (char* name)
+	{
+	dspinfo* info = find_operator (name);
+	if (info == NULL) { fprintf (stderr, "\"%s\" is not a known operation\n", name);  exit (EXIT_FAILURE); }
+	fprintf (stderr, "=== %s ===\n", info->name);
+	(*info->funcUsage) (info->name, stderr, "  ");
+	exit (EXIT_SUCCESS);
+	}
+
+static void parse_options (int _argc, char** _argv)            /* genodsp.c:284-629 */
+	{
+	int    argc = _argc - 1;
+	char** argv = _argv + 1;
+	char*  chromsFilename = NULL;
+
+	if (argc == 0) chastise (NULL);
+	for ( ; argc > 0 ; argv++, argc--)
+		{
+		char* arg    = argv[0];
+		char* argVal = strchr (arg, '=');
+		if (argVal != NULL) argVal++;
+
+		if (arg[0] == specialPipeChar)
+			{
+			if ((argc == 1) && (arg[1] == 0))
+				chastise ("%c at end of command line, with no operation\n", specialPipeChar);
+			int consumed = process_operator_options (argc, argv);
+			argv += consumed - 1;  argc -= consumed - 1;
+			continue;
+			}
+		if ((strcmp_prefix (arg, "--chromosomes=") == 0) || (strcmp_prefix (arg, "--chroms=") == 0))
+			{ chromsFilename = argVal;  continue; }
+		if ((strcmp (arg, "--novalue") == 0) || (strcmp (arg, "--novalues") == 0) || (strcmp (arg, "--value=none") == 0))
+			{ valColumn = -1;  set_named_global ("valColumn", (valtype) valColumn);  continue; }
+		if (strcmp_prefix (arg, "--value=") == 0)
+			{
+			valColumn = string_to_int (argVal) - 1;
+			if (valColumn == -1) chastise ("value column can't be 0 (\"%s\")\n", arg);
+			if (valColumn < 0)   chastise ("value column can't be negative (\"%s\")\n", arg);
+			if (valColumn < 3)   chastise ("value column can't be 1, 2 or 3 (\"%s\")\n", arg);
+			set_named_global ("valColumn", (valtype) valColumn);
+			continue;
+			}
+		if ((strcmp (arg, "--nooutputvalue") == 0) || (strcmp (arg, "--nooutputvalues") == 0))
+			{ noOutputValues = true;  set_named_global ("noOutputValues", (valtype) noOutputValues);  continue; }
+		if (strcmp_prefix (arg, "--precision=") == 0)
+			{
+			valPrecision = string_to_int (argVal);
+			if (valPrecision < 0) chastise ("precision can't be negative (\"%s\")\n", arg);
+			set_named_global ("valPrecision", (valtype) valPrecision);
+			continue;
+			}
+		if (strcmp (arg, "--nocollapse") == 0)
+			{ collapseRuns = false;  set_named_global ("collapseRuns", (valtype) collapseRuns);  continue; }
+		if ((strcmp (arg, "--uncovered:hide") == 0) || (strcmp (arg, "--hide:uncovered") == 0))
+			{ showUncovered = uncovered_hide;  set_named_global ("showUncovered", (valtype) showUncovered);  continue; }
+		if ((strcmp (arg, "--uncovered:show") == 0) || (strcmp (arg, "--show:uncovered") == 0))
+			{ showUncovered = uncovered_show;  set_named_global ("showUncovered", (valtype) showUncovered);  continue; }
+		if ((strcmp (arg, "--uncovered:NA") == 0) || (strcmp (arg, "--uncovered:mark") == 0)
+		 || (strcmp (arg, "--mark:uncovered") == 0) || (strcmp (arg, "--markgaps") == 0))
+			{ showUncovered = uncovered_NA;  set_named_global ("showUncovered", (valtype) showUncovered);  continue; }
+		if ((strcmp (arg, "--cliptochromosome") == 0) || (strcmp (arg, "--cliptochrom") == 0)
+		 || (strcmp (arg, "--cliptolength") == 0) || (strcmp (arg, "--clip") == 0))
+			{ clipToLength = true;  continue; }
+		if ((strcmp (arg, "--origin=one") == 0) || (strcmp (arg, "--origin=1") == 0))
+			{ originOne = true;  set_named_global ("originOne", (valtype) originOne);  continue; }
+		if ((strcmp (arg, "--origin=zero") == 0) || (strcmp (arg, "--origin=0") == 0))
+			{ originOne = false;  set_named_global ("originOne", (valtype) originOne);  continue; }
+		if (strcmp (arg, "--nooutput") == 0) { inhibitOutput = true;  continue; }
+		if ((strcmp_prefix (arg, "--window=") == 0) || (strcmp_prefix (arg, "W=") == 0) || (strcmp_prefix (arg, "--W=") == 0))
+			{
+			int w = string_to_unitized_int (argVal, /*thousands*/ true);
+			if (w == 0) chastise ("window size can't be zero (\"%s\")\n", arg);
+			if (w < 0)  chastise ("window size can't be negative (\"%s\")\n", arg);
+			set_named_global ("windowSize", (valtype) w);
+			continue;
+			}
+		if (strcmp_prefix (arg, "--gpus=") == 0)
+			{
+			numDevices = string_to_int (argVal);
+			if ((numDevices < 1) || (numDevices > 64)) chastise ("--gpus must be between 1 and 64 (\"%s\")\n", arg);
+			continue;
+			}
+		if (strcmp (arg, "--smooth=exact") == 0) { firMode = GDSP_FIR_EXACT;  continue; }
+		if (strcmp (arg, "--smooth=fma")   == 0) { firMode = GDSP_FIR_FMA;    continue; }
+		if (strcmp (arg, "?") == 0) usage_operations ();
+		if ((strcmp_prefix (arg, "--help=") == 0) || (strcmp_prefix (arg, "?=") == 0))
+			{
+			if (strcmp (argVal, "*") != 0) help_for (argVal);
+			goto help_for_all;
+			}
+		if (strcmp_prefix (arg, "?") == 0) help_for (arg+1);
+		if (strcmp (arg, "--help") == 0)
+			{
+		help_for_all:
+			for (u32 i=0 ; i<dspTableLen ; i++)
+				{
+				if (dspTable[i].funcShort == NULL) continue;
+				fprintf (stderr, "=== %s ===\n", dspTable[i].name);
+				(*dspTable[i].funcUsage) (dspTable[i].name, stderr, "  ");
+				}
+			exit (EXIT_SUCCESS);
+			}
+		if ((strcmp (arg, "--report=comments") == 0) || (strcmp (arg, "--report:comments") == 0))
+			{ reportComments = true;  continue; }
+		if ((strcmp_prefix (arg, "--progress=input:") == 0) || (strcmp_prefix (arg, "--progress:input=") == 0)
+		 || (strcmp_prefix (arg, "--progress:input:") == 0))
+			{
+			if (strcmp_prefix (argVal, "input:") == 0) argVal = strchr (arg, ':') + 1;
+			reportInputProgress = string_to_unitized_int (argVal, /*thousands*/ true);
+			continue;
+			}
+		if ((strcmp (arg, "--progress=operations") == 0) || (strcmp (arg, "--progress:operations") == 0)
+		 || (strcmp (arg, "--debug=operations") == 0))
+			{ trackOperations = true;  continue; }
+		if (strcmp (arg, "--version") == 0)
+			{ fprintf (stderr, "%s (version %s)\n", programName, programVersion);  exit (EXIT_SUCCESS); }
+		if (strcmp_prefix (arg, "--") == 0) chastise ("Can't understand \"%s\"\n", arg);
+
+		/* <chromosome>:<length> or <chromosome>:<start>:<end> */
+		char* c1 = strchr (arg, ':');
+		if (c1 == NULL)
+			{
+			fprintf (stderr, "\"%s\" contains no chromosome length\n(expected \"chromosome:length\" or \"chromosome:start:end\")\n", arg);
+			exit (EXIT_FAILURE);
+			}
+		char* c2 = strchr (c1+1, ':');
+		u32 chromStart = 0, chromLength;
+		*(c1++) = 0;
+		if (c2 == NULL) chromLength = (u32) string_to_u32 (c1);
+		else { *(c2++) = 0;  chromStart = (u32) string_to_u32 (c1);  chromLength = (u32) string_to_u32 (c2) - chromStart; }
+		if (!add_chromosome_spec (arg, chromStart, chromLength)) chastise ("can't specify %s more than once\n", arg);
+		}
+	if (chromsFilename != NULL) read_chromosome_lengths (chromsFilename);
+	if (chromsOfInterest == NULL) chastise ("gotta give me some chromosome names\n");
+	}
+
+/* ----------------------------------------------------------------------- main */
+int main (int argc, char** argv)
+	{
+	set_named_global ("valColumn",     (valtype) valColumn);       /* genodsp.c:835-840 */
+	set_named_global ("valPrecision",  (valtype) valPrecision);
+	set_named_global ("collapseRuns",  (valtype) collapseRuns);
+	set_named_global ("showUncovered", (valtype) showUncovered);
+	set_named_global ("originOne",     (valtype) originOne);
+	parse_options (argc, argv);
+
+	int available = 0;
+	check_gdsp (gdsp_device_count (&available), "count GPUs");
+	if (available < numDevices)
+		{ fprintf (stderr, "[%s] %d GPU(s) requested, %d visible\n", programName, numDevices, available);  return EXIT_FAILURE; }
+
+	sort_chromosomes_by_length ();
+	allocate_vectors ();
+
+	/* stdin is the signal unless the first operator is `input` (genodsp.c:891-893) */
+	if ((pipeline == NULL) || (strcmp (pipeline->name, "input") != 0))
+		read_intervals (stdin, valColumn, originOne, ri_overlapSum, /*clear*/ false, 0.0);
+
+	/* batching loop, genodsp.c:900-936: maximal runs of per-chromosome operators go
+	 * chromosome by chromosome (longest first); whole-genome operators get one call */
+	u32 maxLength = 0;
+	for (int i=0 ; chromsSorted[i]!=NULL ; i++) { if (chromsSorted[i]->length > maxLength) maxLength = chromsSorted[i]->length; }
+	dspop* firstOp = pipeline;
+	while (firstOp != NULL)
+		{
+		dspop* stopOp;
+		for (stopOp=firstOp ; stopOp!=NULL ; stopOp=stopOp->next) { if (stopOp->atRandom) break; }
+		if (stopOp != firstOp)
+			{
+			for (int i=0 ; chromsSorted[i]!=NULL ; i++)
+				{
+				spec* s = chromsSorted[i];
+				select_device_of (s);
+				for (dspop* op=firstOp ; op!=stopOp ; op=op->next)
+					{
+					if (trackOperations) fprintf (stderr, "%s(%s)\n", op->name, s->chrom);
+					(*op->funcApply) (op, s->chrom, s->length, s->valVector);
+					}
+				}
+			}
+		if (stopOp == NULL) firstOp = NULL;
+		else
+			{
+			if (trackOperations) tracking_report ("%s(*)\n", stopOp->name);
+			(*stopOp->funcApply) (stopOp, "*", maxLength, NULL);
+			firstOp = stopOp->next;
+			}
+		}
+
+	if (!inhibitOutput)
+		report_intervals (stdout, valPrecision, noOutputValues, collapseRuns, showUncovered, originOne);
+	sync_all_devices ();
+
+	for (dspop* op=pipeline, *next ; op!=NULL ; op=next)
+		{ next = op->next;  free (op->name);  (*op->funcFree) (op); }
+	return EXIT_SUCCESS;
+	}

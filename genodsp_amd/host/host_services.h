@@ -1,0 +1,43 @@
+/* host_services.h -- driver internals shared with the operator files (not part of the
+ * plugin surface in include/genodsp_interface.h). */
+#ifndef host_services_H
+#define host_services_H
+
+#include "genodsp_interface.h"
+
+extern int firMode;                         /* GDSP_FIR_EXACT or GDSP_FIR_FMA (--smooth=) */
+
+/* pending-interval batches: collect in file order, apply on the owning device */
+void ib_begin       (void);
+void ib_add         (spec* s, u32 start, u32 end, valtype val);
+u64  ib_pending     (void);
+void ib_flush_apply (int overlapOp, int clearFlags, valtype missingVal, int everyChromosome);
+void ib_flush_scale (int divide, valtype infinityVal);
+
+void sync_all_devices    (void);
+int  device_count_in_use (void);
+int  device_index_of     (spec* s);
+
+/* ops_common.c: helpers shared by the operator files */
+void* new_op           (char* name, size_t bytes, int atRandom);   /* zeroed control record */
+u32   window_arg       (char* name, char* arg, char* argVal, const char* what);
+/* "--x=<value|variable>": number now, or a named variable resolved at first apply */
+void  value_or_variable (char* argVal, valtype* val, char** varName);
+void  resolve_variable  (dspop* op, char** varName, valtype* val, const char* role);
+
+/* argument helpers used by every operator's parse function */
+#define OP_SHORT(fn, text)                                                            \
+void fn##_short (char* name, int nameWidth, FILE* f, char* indent)                    \
+	{                                                                                 \
+	int fillW = nameWidth-2 - (int) strlen (name);                                    \
+	if (indent == NULL) indent = "";                                                  \
+	if (fillW > 0) fprintf (f, "%s%s:%*s", indent, name, fillW+1, " ");               \
+	else           fprintf (f, "%s%s: ", indent, name);                               \
+	fprintf (f, text "\n");                                                           \
+	}
+
+#define is_opt3(arg, long_, short_)                                                   \
+	((strcmp_prefix (arg, "--" long_ "=") == 0) || (strcmp_prefix (arg, short_ "=") == 0) \
+	 || (strcmp_prefix (arg, "--" short_ "=") == 0))
+
+#endif

@@ -1,0 +1,261 @@
+/* ops_percentile.c -- percentile (device shim): exact order statistics of the sampled
+ * genome, published as named variables percentile<p>.
+ *
+ * Argument rules, rank formula, variable names and messages follow percentile.c:131-375,
+ * :587-589, :657-710, :756-780 in the reference.  The reference sorts the genome in place
+ * (destroying it, percentile.c:34-36, hence its --preserve option); here the k-th smallest
+ * is found by radix select on the device (gdsp_select_histogram) and the signal is left
+ * untouched, so --preserve is accepted and does nothing.  With several GPUs every device
+ * histograms its own chromosomes; the histograms are summed (here on the host, one process
+ * drives all devices; bench.py and the Python binding do the same sum with an RCCL
+ * all-reduce when every GPU has its own process). */
+#include <stdlib.h>
+#include <stdio.h>
+#include <string.h>
+#include <float.h>
+#include "genodsp_interface.h"
+#include "genodsp_hip.h"
+#include "utilities.h"
+#include "host_services.h"
+
+#define percentileStepUnits 1000                  /* resolution 0.001 %, percentile.c:15 */
+
+typedef struct dspop_percentile
+	{
+	dspop   common;
+	u32     percentileLo, percentileHi, percentileStep;
+	valtype minAllowed, maxAllowed;
+	u32     windowSize;
+	int     valPrecision, quiet, reportForBash;
+	char   *preserveFilename, *mapFilename;
+	} dspop_percentile;
+
+OP_SHORT (op_percentile, "compute percentiles of the current set of interval values")
+
+void op_percentile_usage (char* name, FILE* f, char* indent)
+	{
+	if (indent == NULL) indent = "";
+	fprintf (f, "%sCompute percentiles over all chromosomes; each result is stored in a named\n", indent);
+	fprintf (f, "%svariable (percentile99, percentile99.5, ...) that later operators can use as a\n", indent);
+	fprintf (f, "%sthreshold. The signal is not modified.\n\n", indent);
+	fprintf (f, "%susage: %s <percentile> [options]\n", indent, name);
+	fprintf (f, "%s  <low>[..<high>][by<step>]  one percentile or a range of them\n", indent);
+	fprintf (f, "%s  <low>,<high>             exactly two percentiles\n", indent);
+	fprintf (f, "%s  --step=<value>           step through a range (default 1)\n", indent);
+	fprintf (f, "%s  --window=<length>        (W=) look at one base per window\n", indent);
+	fprintf (f, "%s  --min=<value> --max=<value>  ignore values outside this range\n", indent);
+	fprintf (f, "%s  --precision=<number>     digits when reporting values\n", indent);
+	fprintf (f, "%s  --map=<filename>         write \"value percentile\" lines to a file\n", indent);
+	fprintf (f, "%s  --report:bash            print results as shell assignments on stdout\n", indent);
+	fprintf (f, "%s  --quiet                  do not report results on stderr\n", indent);
+	fprintf (f, "%s  --preserve=<filename>    accepted for compatibility; nothing needs preserving\n", indent);
+	}
+
+static u32 to_thousandths (valtype pct)           /* percentile.c:296-302 */
+	{
+	if (pct <   0.0) return 0;
+	if (pct > 100.0) return 100*percentileStepUnits;
+	return (u32) (int) (percentileStepUnits*pct + .5);
+	}
+
+dspop* op_percentile_parse (char* name, int argc, char** argv)
+	{
+	dspop_percentile* op = (dspop_percentile*) new_op (name, sizeof(dspop_percentile), true);
+	int haveRange = false;
+	op->percentileStep = percentileStepUnits;
+	op->minAllowed     = -valtypeMax;
+	op->maxAllowed     =  valtypeMax;
+	op->windowSize     = 1;
+	op->valPrecision   = (int) get_named_global ("valPrecision", 0);
+
+	for ( ; argc > 0 ; argv++, argc--)
+		{
+		char* arg = argv[0];
+		char* argVal = strchr (arg, '=');  if (argVal != NULL) argVal++;
+		char* stepText = NULL;
+
+		if (strcmp_prefix (arg, "--step=") == 0) { stepText = argVal;  goto set_step; }
+		if (is_opt3 (arg, "window", "W"))
+			{
+			int w = string_to_unitized_int (argVal, /*thousands*/ true);
+			if (w == 0) w = 1;
+			if (w < 0) chastise ("[%s] window size can't be negative (\"%s\")\n", name, arg);
+			op->windowSize = (u32) w;
+			continue;
+			}
+		if (strcmp_prefix (arg, "--min=") == 0) { op->minAllowed = string_to_valtype (argVal);  continue; }
+		if (strcmp_prefix (arg, "--max=") == 0) { op->maxAllowed = string_to_valtype (argVal);  continue; }
+		if (strcmp_prefix (arg, "--precision=") == 0)
+			{
+			op->valPrecision = string_to_int (argVal);
+			if (op->valPrecision < 0) chastise ("[%s] precision can't be negative (\"%s\")\n", name, arg);
+			continue;
+			}
+		if (strcmp_prefix (arg, "--preserve=") == 0)
+			{ if (op->preserveFilename == NULL) op->preserveFilename = copy_string (argVal);  continue; }
+		if ((strcmp_prefix (arg, "--map=") == 0) || (strcmp_prefix (arg, "--mapping=") == 0))
+			{ if (op->mapFilename == NULL) op->mapFilename = copy_string (argVal);  continue; }
+		if ((strcmp (arg, "--report:bash") == 0) || (strcmp (arg, "--bash") == 0)) { op->reportForBash = true;  continue; }
+		if ((strcmp (arg, "--quiet") == 0) || (strcmp (arg, "--silent") == 0))     { op->quiet = true;  continue; }
+		if (strcmp_prefix (arg, "--debug") == 0) continue;
+		if (strcmp_prefix (arg, "--") == 0) chastise ("[%s] Can't understand \"%s\"\n", name, arg);
+
+		if (haveRange) chastise ("[%s] Can't understand \"%s\"\n", name, arg);
+			{
+			valtype lo, hi;
+			char*   text  = copy_string (arg);
+			char*   comma = strchr (text, ',');
+			if (comma != NULL)                                 /* <low>,<high> */
+				{
+				*(comma++) = 0;
+				lo = string_to_valtype (text);  hi = string_to_valtype (comma);
+				if (lo > hi) { valtype t = hi;  hi = lo;  lo = t; }
+				op->percentileLo = to_thousandths (lo);  op->percentileHi = to_thousandths (hi);
+				op->percentileStep = (op->percentileLo < op->percentileHi)? op->percentileHi - op->percentileLo : 1;
+				}
+			else                                               /* <low>[..<high>][by<step>] */
+				{
+				char* dots = strstr (text, "..");
+				if (dots != NULL)
+					{
+					*dots = 0;  dots += 2;
+					char* by = strstr (dots, "by");
+					if (by != NULL) { *by = 0;  stepText = arg + (by + 2 - text); }
+					lo = string_to_valtype (text);  hi = string_to_valtype (dots);
+					}
+				else lo = hi = string_to_valtype (text);
+				if (lo > hi) { valtype t = hi;  hi = lo;  lo = t; }
+				op->percentileLo = to_thousandths (lo);  op->percentileHi = to_thousandths (hi);
+				}
+			free (text);
+			haveRange = true;
+			if (stepText == NULL) continue;
+			}
+	set_step:
+			{
+			valtype st = string_to_valtype (stepText);
+			if (st == 0) chastise ("[%s] step can't be zero (\"%s\")\n", name, arg);
+			if (st < 0)  chastise ("[%s] step can't be negative (\"%s\")\n", name, arg);
+			if (st < .001) st = .001;
+			op->percentileStep = (u32) (percentileStepUnits*st + .5);
+			}
+		}
+	if (!haveRange) { fprintf (stderr, "[%s] no range of percentiles was provided\n", name);  exit (EXIT_FAILURE); }
+	if (op->reportForBash && op->quiet) chastise ("[%s] Can't use both --report:bash and --quiet\n", name);
+	return (dspop*) op;
+	}
+
+void op_percentile_free (dspop* _op)
+	{
+	dspop_percentile* op = (dspop_percentile*) _op;
+	if (op->preserveFilename != NULL) free (op->preserveFilename);
+	if (op->mapFilename      != NULL) free (op->mapFilename);
+	free (op);
+	}
+
+static void percentile_name (char* varName, u32 percentile)     /* percentile.c:756-780 */
+	{
+	if (percentile % percentileStepUnits == 0)
+		{ sprintf (varName, "percentile%d", percentile / percentileStepUnits);  return; }
+	float pPct = percentile / ((float) percentileStepUnits);
+	int   precision = 1;
+	for (u32 denom=percentileStepUnits/10 ; denom>=1 ; precision++, denom/=10)
+		{ if (percentile % denom == 0) { sprintf (varName, "percentile%.*f", precision, pPct);  return; } }
+	sprintf (varName, "percentile%f", pPct);
+	}
+
+/* digit schedule over the 64-bit key: sign+exponent, then the mantissa in 13-bit digits */
+static const int digitShift[] = { 52, 39, 26, 13, 0 };
+static const int digitBits[]  = { 12, 13, 13, 13, 13 };
+#define NUM_DIGITS 5
+#define MAX_BINS   (1 << GDSP_SELECT_MAX_BITS)
+
+/* one select pass over every chromosome on every device; h_hist gets the summed counts
+ * followed by the smallest and largest matching key */
+static void histogram_pass (dspop_percentile* op, int digit, u64 prefix, u64* h_hist)
+	{
+	const int bits = digitBits[digit], nbins = 1 << bits;
+	u64*  d_hist[64] = { NULL };
+	u64   part[MAX_BINS + 2];
+
+	for (int b=0 ; b<nbins+2 ; b++) h_hist[b] = 0;
+	h_hist[nbins] = ~(u64) 0;
+	int seen[64] = { 0 };
+	for (int i=0 ; chromsSorted[i]!=NULL ; i++)
+		{
+		spec* s = chromsSorted[i];
+		select_device_of (s);
+		int d = device_index_of (s);
+		if (!seen[d])
+			{
+			d_hist[d] = (u64*) get_scratch_vector ();
+			check_gdsp (gdsp_select_hist_init (d_hist[d], bits, op_stream ()), "percentile");
+			seen[d] = true;
+			}
+		check_gdsp (gdsp_select_histogram (s->valVector, s->length, op->windowSize, op->minAllowed, op->maxAllowed,
+		                                   digitShift[digit], bits, prefix, d_hist[d], op_stream ()), "percentile");
+		}
+	for (int i=0 ; chromsSorted[i]!=NULL ; i++)
+		{
+		spec* s = chromsSorted[i];
+		int d = device_index_of (s);
+		if (!seen[d]) continue;
+		select_device_of (s);
+		check_gdsp (gdsp_memcpy_d2h (part, d_hist[d], (size_t) (nbins + 2) * sizeof(u64), op_stream ()), "percentile");
+		check_gdsp (gdsp_stream_sync (op_stream ()), "percentile");
+		release_scratch_vector ((valtype*) d_hist[d]);
+		seen[d] = false;
+		for (int b=0 ; b<nbins ; b++) h_hist[b] += part[b];                 /* the sum over GPUs */
+		if (part[nbins]   < h_hist[nbins])   h_hist[nbins]   = part[nbins];
+		if (part[nbins+1] > h_hist[nbins+1]) h_hist[nbins+1] = part[nbins+1];
+		}
+	}
+
+void op_percentile_apply (dspop* _op, arg_dont_complain(char* vName), arg_dont_complain(u32 vLen), arg_dont_complain(valtype* v))
+	{
+	dspop_percentile* op = (dspop_percentile*) _op;
+	static u64 first[MAX_BINS + 2], hist[MAX_BINS + 2];
+	char  varName[100];
+	FILE* mapF = (op->mapFilename != NULL)? fopen (op->mapFilename, "wt") : NULL;
+
+	histogram_pass (op, 0, 0, first);                   /* shared by every requested percentile */
+	u64 numValues = 0;
+	for (int b=0 ; b<(1 << digitBits[0]) ; b++) numValues += first[b];
+	if (numValues == 0)
+		{
+		fprintf (stderr, "[%s] percentile can't be computed;  no input values meet the criteria\n", _op->name);
+		if (mapF != NULL) fclose (mapF);
+		return;
+		}
+
+	for (u32 pt=op->percentileLo ; pt<=op->percentileHi ; pt+=op->percentileStep)
+		{
+		u64     k = gdsp_percentile_rank ((u32) numValues, pt);
+		u64     prefix = 0;
+		valtype pVal = 0;
+		int     found = false;
+		for (int digit=0 ; digit<NUM_DIGITS ; digit++)
+			{
+			const int bits = digitBits[digit], nbins = 1 << bits;
+			u64* h = first;
+			if (digit > 0) { histogram_pass (op, digit, prefix, hist);  h = hist; }
+			if (h[nbins] == h[nbins+1]) { pVal = gdsp_key_to_double (h[nbins]);  found = true;  break; }
+			u32 bucket;  u64 within;
+			check_gdsp (gdsp_select_pick (h, bits, k, &bucket, &within), "percentile");
+			prefix |= ((u64) bucket) << digitShift[digit];
+			k = within;
+			}
+		if (!found) pVal = gdsp_key_to_double (prefix);
+
+		float pPct = pt / ((float) percentileStepUnits);
+		percentile_name (varName, pt);
+		set_named_global (varName, pVal);
+		if (op->reportForBash)
+			fprintf (stdout, "%s=" valtypeFmtPrec " # bash command\n", varName, op->valPrecision, pVal);
+		else if (!op->quiet)
+			fprintf (stderr, "percentile %.3f is " valtypeFmtPrec "\n", pPct, op->valPrecision, pVal);
+		if (mapF != NULL) fprintf (mapF, valtypeFmtPrec " %.3f\n", op->valPrecision, pVal, pPct);
+		if (op->percentileStep == 0) break;
+		}
+	if (mapF != NULL) fclose (mapF);
+	}

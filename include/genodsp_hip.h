@@ -164,6 +164,9 @@ uint32_t gdsp_percentile_rank (uint32_t numValues, uint32_t pThousandths);
  *     (pass negated values for subtract).
  *   gdsp_scale_intervals: op_multiply multiply.c:326-345, op_divide :706-740; bases
  *     under no interval become 0 (multiply) or +-infinityVal (divide). */
+#define GDSP_CLEAR_FIRST_TOUCH 1   /* a base still equal to missingVal is assigned (genodsp.c:1311) */
+#define GDSP_CLEAR_FILL        2   /* every base starts from missingVal (genodsp.c:1225-1240)       */
+#define GDSP_CLEAR_BOTH        3   /* what read_intervals(clear=true) does                          */
 uint32_t gdsp_interval_tile (void);
 int gdsp_bin_intervals   (uint32_t n, const uint32_t* h_start, const uint32_t* h_end, uint32_t count,
                           uint32_t* h_tileOffsets, uint32_t* h_tileList, uint64_t* listLen);
