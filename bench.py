@@ -39,18 +39,6 @@ FP64_VALU_PEAK_TFLOPS = 78.6     # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 BYTES_PER_BASE = 16              # 8 B read + 8 B write per base for smooth
 
 
-def lpt_shards(lengths, nranks):
-    """Longest-processing-time greedy: chromosome index lists per rank."""
-    order = sorted(range(len(lengths)), key=lambda i: -lengths[i])
-    load = [0] * nranks
-    shards = [[] for _ in range(nranks)]
-    for i in order:
-        r = min(range(nranks), key=lambda k: load[k])
-        shards[r].append(i)
-        load[r] += lengths[i]
-    return shards
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -85,6 +73,7 @@ def main():
     names = [c for c, _ in GENOME]
     lengths = [max(1, int(n * args.scale)) for _, n in GENOME]
     total_bases = sum(lengths)
+    lpt_shards = gd.lpt_shards
     mine = lpt_shards(lengths, world)[rank]
 
     # ---- resident signal: in/out vector per chromosome of this rank, generated in HBM

@@ -306,42 +306,41 @@ def genome_minmax(vecs, window=1, lo=-DBL_MAX, hi=DBL_MAX, stream=None):
 SELECT_DIGITS = [(52, 12), (39, 13), (26, 13), (13, 13), (0, 13)]
 
 
-def percentile(vecs, p_thousandths, window=1, lo=-DBL_MAX, hi=DBL_MAX, allreduce=None, stream=None):
-    """Exact percentiles of the sampled genome (percentile.c:392-751), non-destructive.
+def radix_select(histogram, p_thousandths, allreduce=None):
+    """Host side of the exact order statistic (percentile.c:587-710), shared by every backend.
 
-    vecs: this rank's chromosome vectors.  allreduce(np_u64_array, op) -> array sums
-    ("sum") or min/maxes ("min"/"max") over ranks; None on a single GPU.
+    histogram(shift, bits, prefix) -> np.uint64 array of (1<<bits)+2 words for THIS rank's
+    chromosomes: the digit counts, then the smallest and the largest matching key.
+    allreduce(array, op) -> the "sum" / "min" / "max" of the array over ranks (None: one rank).
     Returns (count, [values])."""
     L = lib()
     results = []
     count = None
     first = None           # the prefix-free first pass is shared by every requested percentile
+
+    def reduced(shift, bits, prefix):
+        nb = 1 << bits
+        h = np.array(histogram(shift, bits, prefix), dtype=np.uint64)
+        if allreduce is not None:
+            h[:nb] = allreduce(h[:nb].copy(), "sum")
+            h[nb:nb + 1] = allreduce(h[nb:nb + 1].copy(), "min")
+            h[nb + 1:] = allreduce(h[nb + 1:].copy(), "max")
+        return h
+
     for pt in p_thousandths:
-        prefix = 0
-        value = None
-        k = None
+        prefix, value, k = 0, None, None
         for di, (shift, bits) in enumerate(SELECT_DIGITS):
             nb = 1 << bits
-            if di == 0 and first is not None:
-                hist = first
-            else:
-                dh = DeviceBuffer((nb + 2) * 8)
-                call("gdsp_select_hist_init", C.c_void_p(dh.ptr), bits, _sp(stream))
-                for v in vecs:
-                    call("gdsp_select_histogram", v.ptr, v.n, window, float(lo), float(hi), shift, bits,
-                         C.c_uint64(prefix), C.c_void_p(dh.ptr), _sp(stream))
-                hist = dh.download(np.uint64, nb + 2, stream=stream)
-                if allreduce is not None:
-                    hist[:nb] = allreduce(hist[:nb].copy(), "sum")
-                    hist[nb:nb + 1] = allreduce(hist[nb:nb + 1].copy(), "min")
-                    hist[nb + 1:] = allreduce(hist[nb + 1:].copy(), "max")
-                if di == 0:
-                    first = hist
             if di == 0:
-                count = int(hist[:nb].sum())
+                if first is None:
+                    first = reduced(shift, bits, 0)
+                    count = int(first[:nb].sum())
                 if count == 0:
                     return 0, []
+                hist = first
                 k = L.gdsp_percentile_rank(count, int(pt))
+            else:
+                hist = reduced(shift, bits, prefix)
             if hist[nb] == hist[nb + 1]:           # one distinct candidate left
                 value = L.gdsp_key_to_double(int(hist[nb]))
                 break
@@ -353,6 +352,34 @@ def percentile(vecs, p_thousandths, window=1, lo=-DBL_MAX, hi=DBL_MAX, allreduce
             value = L.gdsp_key_to_double(prefix)
         results.append(value)
     return count, results
+
+
+def percentile(vecs, p_thousandths, window=1, lo=-DBL_MAX, hi=DBL_MAX, allreduce=None, stream=None):
+    """Exact percentiles of the sampled genome (percentile.c:392-751), non-destructive.
+    vecs: this rank's chromosome vectors; allreduce: see radix_select.  Returns (count, [values])."""
+    def histogram(shift, bits, prefix):
+        nb = 1 << bits
+        dh = DeviceBuffer((nb + 2) * 8)
+        call("gdsp_select_hist_init", C.c_void_p(dh.ptr), bits, _sp(stream))
+        for v in vecs:
+            call("gdsp_select_histogram", v.ptr, v.n, window, float(lo), float(hi), shift, bits,
+                 C.c_uint64(prefix), C.c_void_p(dh.ptr), _sp(stream))
+        return dh.download(np.uint64, nb + 2, stream=stream)
+
+    return radix_select(histogram, p_thousandths, allreduce)
+
+
+def lpt_shards(lengths, nranks):
+    """Deal chromosomes longest-first onto the least loaded rank (what genodsp_hip --gpus=N and
+    bench.py do); returns a list of chromosome-index lists, one per rank."""
+    order = sorted(range(len(lengths)), key=lambda i: -lengths[i])
+    load = [0] * nranks
+    shards = [[] for _ in range(nranks)]
+    for i in order:
+        r = min(range(nranks), key=lambda k: load[k])
+        shards[r].append(i)
+        load[r] += lengths[i]
+    return shards
 
 
 # ------------------------------------- genodsp.c / add.c / multiply.c ------

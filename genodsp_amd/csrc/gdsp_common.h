@@ -47,6 +47,42 @@ __device__ __forceinline__ uint32_t gdsp_xcd_tile (uint32_t b, uint32_t nblocks)
 	return (b % GDSP_NUM_XCD) * per + (b / GDSP_NUM_XCD);
 	}
 
+// Stage v[g0 .. g0+L) into LDS (zero / `pad` outside [0,n)).  g0 and L are even and v is
+// 16-byte aligned, so interior tiles move as 16-byte words; up to STAGE_DEPTH loads per lane
+// are issued before the first LDS store so that a workgroup keeps ~32 KiB in flight.
+#define GDSP_STAGE_DEPTH 8
+template <int THREADS>
+__device__ __forceinline__ void gdsp_stage_f64 (double* lds, const double* __restrict__ v, uint32_t n,
+                                                int64_t g0, int L, double pad)
+	{
+	if ((g0 >= 0) && (g0 + L <= (int64_t) n))
+		{
+		const double2* src = reinterpret_cast<const double2*> (v + g0);
+		double2*       dst = reinterpret_cast<double2*> (lds);
+		const int      np  = L / 2;
+		for (int base=0 ; base<np ; base+=GDSP_STAGE_DEPTH*THREADS)
+			{
+			double2 r[GDSP_STAGE_DEPTH];
+			// every lane loads unconditionally (index clamped): a predicated load would get its
+			// own branch and an s_waitcnt vmcnt(0), serialising the whole batch
+#pragma unroll
+			for (int u=0 ; u<GDSP_STAGE_DEPTH ; u++)
+				{ int p = base + u*THREADS + (int) threadIdx.x;  r[u] = src[(p < np)? p : np-1]; }
+#pragma unroll
+			for (int u=0 ; u<GDSP_STAGE_DEPTH ; u++)
+				{ int p = base + u*THREADS + (int) threadIdx.x;  if (p < np) dst[p] = r[u]; }
+			}
+		}
+	else
+		{
+		for (int p=threadIdx.x ; p<L ; p+=THREADS)
+			{
+			int64_t g = g0 + p;
+			lds[p] = ((g >= 0) && (g < (int64_t) n))? v[g] : pad;
+			}
+		}
+	}
+
 // order-preserving image of a double (radix select): -0.0 folded onto +0.0
 __host__ __device__ __forceinline__ uint64_t gdsp_key_of (double v)
 	{

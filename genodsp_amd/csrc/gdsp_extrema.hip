@@ -31,28 +31,9 @@
 
 template <bool MAX> __device__ __forceinline__ bool ex_beats (double a, double b)
 	{ return MAX? (a > b) : (a < b); }
+// extreme of two values with NaN never winning: v_max_f64 / v_min_f64 (IEEE maxNum/minNum)
 template <bool MAX> __device__ __forceinline__ double ex_pick (double a, double b)
-	{ return (ex_beats<MAX> (b, a) || (a != a))? b : a; }   // keeps a on ties; a NaN never wins
-
-// stage [g0, g0+L) of v into lds, `pad` outside the vector; g0 even, L even
-__device__ __forceinline__ void ex_stage (double* lds, const double* __restrict__ v, uint32_t n,
-                                          int64_t g0, int L, double pad)
-	{
-	if ((g0 >= 0) && (g0 + L <= (int64_t) n))
-		{
-		const double2* src = reinterpret_cast<const double2*> (v + g0);
-		double2*       dst = reinterpret_cast<double2*> (lds);
-		for (int p=threadIdx.x ; p<L/2 ; p+=EX_THREADS) dst[p] = src[p];
-		}
-	else
-		{
-		for (int p=threadIdx.x ; p<L ; p+=EX_THREADS)
-			{
-			int64_t g = g0 + p;
-			lds[p] = ((g >= 0) && (g < (int64_t) n))? v[g] : pad;
-			}
-		}
-	}
+	{ return MAX? fmax (a, b) : fmin (a, b); }
 
 // LOCAL: localmin/localmax semantics; otherwise bestmin/bestmax
 template <bool MAX, bool LOCAL, bool DIRECT>
@@ -69,7 +50,7 @@ void extrema_kernel (const double* __restrict__ in, double* __restrict__ out, ui
 	const int      span      = (int) (lft + rgt + 1);
 	const int      L         = (tile + span - 1 + sh + 1) & ~1;
 
-	ex_stage (lds, in, n, g0, L, pad);
+	gdsp_stage_f64<EX_THREADS> (lds, in, n, g0, L, pad);
 	__syncthreads ();
 
 	const double* x = lds + sh;                  // x[o + k], k in [0,span): window of output o

@@ -171,20 +171,7 @@ void fir_generic_kernel (const double* __restrict__ in, double* __restrict__ out
 		const int      L   = (T + (int) kcR + R + sh + 1) & ~1;
 
 		if (k0 != 0) __syncthreads ();
-		if ((g0 >= 0) && (g0 + L <= (int64_t) n))
-			{
-			const double2* src = reinterpret_cast<const double2*> (in + g0);
-			double2*       dst = reinterpret_cast<double2*> (ldsDyn);
-			for (int p=threadIdx.x ; p<L/2 ; p+=FIR_THREADS) dst[p] = src[p];
-			}
-		else
-			{
-			for (int p=threadIdx.x ; p<L ; p+=FIR_THREADS)
-				{
-				int64_t g = g0 + p;
-				ldsDyn[p] = ((g >= 0) && (g < (int64_t) n))? in[g] : 0.0;
-				}
-			}
+		gdsp_stage_f64<FIR_THREADS> (ldsDyn, in, n, g0, L, 0.0);
 		__syncthreads ();
 
 		const double* x = ldsDyn + sh + threadIdx.x * R;

@@ -26,7 +26,7 @@
 #define MO_THREADS   256
 #define MO_MIN_TILE  16384
 #define MO_MAX_STAGE 262144          // staged bases per workgroup (mask 32 KiB + tables 32 KiB)
-#define MO_STAGE_UNROLL 4
+#define MO_STAGE_UNROLL 8
 #define MO_NONE_HI   0x3fffffff      // "no set bit to the right"
 #define MO_NONE_LO   (-0x3fffffff)   // "no set bit to the left"
 
@@ -91,30 +91,47 @@ void morph_kernel (const double* __restrict__ in, double* __restrict__ out, uint
 	// erode and open ask about the complement (positions NOT in S; outside the vector counts)
 	const bool complement = (OP == MO_ERODE) || (OP == MO_OPEN);
 
-	// ---- stage: 128 bases per wave-step -> two mask words; MO_STAGE_UNROLL steps' loads in flight
-	for (int c0 = wave*MO_STAGE_UNROLL ; 2*c0 < nwords ; c0 += (MO_THREADS/64)*MO_STAGE_UNROLL)
+	// ---- stage: 128 bases per wave-step -> two mask words, MO_STAGE_UNROLL steps' loads in flight.
+	// Tiles whose whole staged range lies inside the vector (all but the two ends) load
+	// unconditionally: a predicated load gets its own branch and an s_waitcnt vmcnt(0), which
+	// would leave one load in flight per wave.
+	const int  nchunks  = nwords / 2;
+	const bool interior = (g0 >= 0) && (g0 + 64*(int64_t) nwords <= (int64_t) n);
+	for (int c0 = wave*MO_STAGE_UNROLL ; c0 < nchunks ; c0 += (MO_THREADS/64)*MO_STAGE_UNROLL)
 		{
-		double x[MO_STAGE_UNROLL], y[MO_STAGE_UNROLL];
-		bool   hx[MO_STAGE_UNROLL], hy[MO_STAGE_UNROLL];
-#pragma unroll
-		for (int u=0 ; u<MO_STAGE_UNROLL ; u++)
+		double2 d[MO_STAGE_UNROLL];
+		bool    hx[MO_STAGE_UNROLL], hy[MO_STAGE_UNROLL];
+		if (interior)
 			{
-			const int64_t g = g0 + 128*(int64_t) (c0+u) + 2*lane;
-			const bool live = (2*(c0+u) < nwords);
-			hx[u] = live && (g >= 0) && (g < (int64_t) n);
-			hy[u] = live && (g + 1 >= 0) && (g + 1 < (int64_t) n);
-			x[u] = 0.0;  y[u] = 0.0;
-			if (hx[u] && hy[u]) { double2 d = *reinterpret_cast<const double2*> (in + g);  x[u] = d.x;  y[u] = d.y; }
-			else                { if (hx[u]) x[u] = in[g];  if (hy[u]) y[u] = in[g+1]; }
+#pragma unroll
+			for (int u=0 ; u<MO_STAGE_UNROLL ; u++)
+				{
+				const int c = (c0+u < nchunks)? c0+u : nchunks-1;      // clamped: duplicates are harmless
+				d[u]  = *reinterpret_cast<const double2*> (in + g0 + 128*(int64_t) c + 2*lane);
+				hx[u] = hy[u] = true;
+				}
+			}
+		else
+			{
+#pragma unroll
+			for (int u=0 ; u<MO_STAGE_UNROLL ; u++)
+				{
+				const int64_t g = g0 + 128*(int64_t) (c0+u) + 2*lane;
+				const bool live = (c0+u < nchunks);
+				hx[u] = live && (g >= 0) && (g < (int64_t) n);
+				hy[u] = live && (g + 1 >= 0) && (g + 1 < (int64_t) n);
+				d[u].x = hx[u]? in[g]   : 0.0;
+				d[u].y = hy[u]? in[g+1] : 0.0;
+				}
 			}
 #pragma unroll
 		for (int u=0 ; u<MO_STAGE_UNROLL ; u++)
 			{
 			const int     c = c0 + u;
 			const int64_t g = g0 + 128*(int64_t) c + 2*lane;
-			const uint64_t E = __ballot (hx[u] && mo_member<OP> (x[u], T, g));
-			const uint64_t O = __ballot (hy[u] && mo_member<OP> (y[u], T, g+1));
-			if ((lane == 0) && (2*c < nwords))
+			const uint64_t E = __ballot (hx[u] && mo_member<OP> (d[u].x, T, g));
+			const uint64_t O = __ballot (hy[u] && mo_member<OP> (d[u].y, T, g+1));
+			if ((lane == 0) && (c < nchunks))
 				{
 				uint64_t wA = mo_spread32 (E)       | (mo_spread32 (O)       << 1);
 				uint64_t wB = mo_spread32 (E >> 32) | (mo_spread32 (O >> 32) << 1);

@@ -2,8 +2,7 @@
 // invert, fill, and the min/max/count reduction behind invert and percentile 0/100.
 //
 // All of these are one load and one store per base (16 B/base) and therefore HBM
-// bound on MI355X: each lane moves 16 bytes per access, four accesses in flight,
-// and the grid is capped so every workgroup streams a long contiguous run.
+// bound on MI355X: each lane moves 16 bytes per access, eight accesses in flight.
 // Comparisons are written in the same form as the reference's so that NaN and
 // signed-zero inputs take the same branch.
 
@@ -11,35 +10,35 @@
 #include "gdsp_common.h"
 
 #define PW_THREADS 256
-#define PW_UNROLL  4
+#define PW_UNROLL  8                                  // 16-byte accesses in flight per lane
+#define PW_TILE    (PW_THREADS * PW_UNROLL * 2)       // 4096 bases = 32 KiB per workgroup
 #define PW_MAX_BLOCKS (256 * 8)
 
+// One workgroup = one contiguous 32 KiB tile: all of its loads are issued before the first
+// store, and tiles are dealt so that each XCD walks a contiguous eighth of the vector
+// (gdsp_xcd_tile).  Measured on MI355X this streams ~25 % faster than a grid-stride loop over
+// the same vector (profiles/r01_ops_throughput.txt).
 template <class F>
 __global__ __launch_bounds__(PW_THREADS)
-void pointwise_kernel (double* __restrict__ v, uint32_t n, F f)
+void pointwise_kernel (double* __restrict__ v, uint32_t n, uint32_t ntiles, F f)
 	{
-	double2*     p      = reinterpret_cast<double2*> (v);
-	const size_t npairs = (size_t) n / 2;
-	const size_t stride = (size_t) gridDim.x * PW_THREADS;
-	size_t       i      = (size_t) blockIdx.x * PW_THREADS + threadIdx.x;
-
-	for ( ; i + (PW_UNROLL-1)*stride < npairs ; i += PW_UNROLL*stride)
+	const uint32_t tile = gdsp_xcd_tile (blockIdx.x, ntiles);
+	const size_t   base = (size_t) tile * PW_TILE;
+	if (base + PW_TILE <= (size_t) n)
 		{
-		double2 d[PW_UNROLL];
+		double2* p = reinterpret_cast<double2*> (v + base) + threadIdx.x;
+		double2  d[PW_UNROLL];
 #pragma unroll
-		for (int u=0 ; u<PW_UNROLL ; u++) d[u] = p[i + u*stride];
+		for (int u=0 ; u<PW_UNROLL ; u++) d[u] = p[u*PW_THREADS];
 #pragma unroll
 		for (int u=0 ; u<PW_UNROLL ; u++) { d[u].x = f (d[u].x);  d[u].y = f (d[u].y); }
 #pragma unroll
-		for (int u=0 ; u<PW_UNROLL ; u++) p[i + u*stride] = d[u];
+		for (int u=0 ; u<PW_UNROLL ; u++) p[u*PW_THREADS] = d[u];
 		}
-	for ( ; i < npairs ; i += stride)
+	else
 		{
-		double2 d = p[i];
-		d.x = f (d.x);  d.y = f (d.y);
-		p[i] = d;
+		for (size_t i = base + threadIdx.x ; i < (size_t) n ; i += PW_THREADS) v[i] = f (v[i]);
 		}
-	if ((n & 1) && (blockIdx.x == 0) && (threadIdx.x == 0)) v[n-1] = f (v[n-1]);
 	}
 
 template <class F>
@@ -48,10 +47,8 @@ static int pointwise_launch (double* d_v, uint32_t n, F f, void* stream)
 	if (n == 0) return GDSP_OK;
 	GDSP_REQUIRE (d_v != NULL, "NULL vector");
 	GDSP_REQUIRE (gdsp_aligned16 (d_v), "vector must be 16-byte aligned");
-	size_t   npairs = (size_t) n / 2;
-	size_t   want   = (npairs + (size_t) PW_THREADS*PW_UNROLL - 1) / ((size_t) PW_THREADS*PW_UNROLL);
-	uint32_t blocks = (uint32_t) (want < 1? 1 : (want > PW_MAX_BLOCKS? PW_MAX_BLOCKS : want));
-	hipLaunchKernelGGL ((pointwise_kernel<F>), dim3(blocks), dim3(PW_THREADS), 0, gdsp_stream (stream), d_v, n, f);
+	const uint32_t ntiles = (uint32_t) (((uint64_t) n + PW_TILE - 1) / PW_TILE);
+	hipLaunchKernelGGL ((pointwise_kernel<F>), dim3(ntiles), dim3(PW_THREADS), 0, gdsp_stream (stream), d_v, n, ntiles, f);
 	GDSP_LAUNCH_CHECK ();
 	return GDSP_OK;
 	}

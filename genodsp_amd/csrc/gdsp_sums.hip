@@ -64,20 +64,7 @@ void sliding_sum_kernel (const double* __restrict__ in, double* __restrict__ out
 	const int64_t  g0        = tileStart - lft - 1 - sh;          // even
 	const int      L         = (tile + W + sh + 1) & ~1;
 
-	if ((g0 >= 0) && (g0 + L <= (int64_t) n))
-		{
-		const double2* src = reinterpret_cast<const double2*> (in + g0);
-		double2*       dst = reinterpret_cast<double2*> (suLds);
-		for (int p=threadIdx.x ; p<L/2 ; p+=SU_THREADS) dst[p] = src[p];
-		}
-	else
-		{
-		for (int p=threadIdx.x ; p<L ; p+=SU_THREADS)
-			{
-			int64_t g = g0 + p;
-			suLds[p] = ((g >= 0) && (g < (int64_t) n))? in[g] : 0.0;
-			}
-		}
+	gdsp_stage_f64<SU_THREADS> (suLds, in, n, g0, L, 0.0);
 	__syncthreads ();
 	// x[k] = staged value of global tileStart-lft-1+k, k=0 is the extra leading element;
 	// it must not count towards the first window, so it is cleared before the scan
