@@ -48,6 +48,9 @@ def main():
                     help="FIR arithmetic of the headline number (the other one is reported too)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink every chromosome (debugging only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["smooth", "peaks", "morph", "percentile"], default="smooth",
+                    help="smooth = BASELINE configs[1] (the metric); the others are configs[2..4], "
+                         "reported in the same shape for DESIGN.md, never the driver's number")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -88,7 +91,7 @@ def main():
         for i in mine:
             gd.smooth(vin[i], WINDOW, out=vout[i], mode=mode, stream=stream.handle)
 
-    def timed(mode, steps, warmup):
+    def timed(mode, steps, warmup, step=step):
         for _ in range(warmup):
             step(mode)
         torch.cuda.synchronize()
@@ -110,6 +113,13 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wall_ms, dev_ms = float(t[0]), float(t[1])
         return wall_ms, dev_ms
+
+    if args.workload != "smooth":
+        other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_bases, vin, vout, stream, timed_fn=timed)
+        barrier()
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     head_mode = gd.FIR_FMA if args.mode == "fma" else gd.FIR_EXACT
     other_mode = gd.FIR_EXACT if args.mode == "fma" else gd.FIR_FMA
@@ -165,6 +175,65 @@ def main():
         print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_bases, vin, vout, stream, timed_fn):
+    """BASELINE configs[2..4] in the bench harness: same signal, same timing discipline."""
+    S = stream.handle
+    tmp = {i: gd.DeviceVector(lengths[i]) for i in mine}
+    mode = gd.FIR_FMA if args.mode == "fma" else gd.FIR_EXACT
+    extra = {}
+    if args.workload == "peaks":          # configs[2]: smooth W=101 = localmax N=11
+        name, bytes_per_base = "smooth W=101 = localmax N=11", 32
+
+        def step(_):
+            for i in mine:
+                gd.smooth(vin[i], WINDOW, out=vout[i], mode=mode, stream=S)
+                gd.localmax(vout[i], 11, out=tmp[i], stream=S)
+    elif args.workload == "morph":        # configs[3]: dilate 1001 = erode 1001 = binarize
+        name, bytes_per_base = "dilate 1001 = erode 1001 = binarize", 48
+        left, right = gd.split_length(1001)
+
+        def step(_):
+            for i in mine:
+                gd.dilate(vin[i], left, right, out=vout[i], stream=S)
+                gd.erode(vout[i], left, right, out=tmp[i], stream=S)
+                gd.binarize(tmp[i], 0.0, stream=S)
+    else:                                 # configs[4]: percentile 99 = binarize --threshold=percentile99
+        name, bytes_per_base = "percentile 99 = binarize --threshold=percentile99", 24
+        for i in mine:
+            gd.call("gdsp_memcpy_d2d", tmp[i].ptr, vin[i].ptr, lengths[i] * 8, gd._sp(S))
+        allreduce = None
+        if dist is not None:
+            def allreduce(arr, op):       # RCCL: the path's only collective (<= 64 KiB per select pass)
+                if op == "sum":
+                    t = torch.from_numpy(arr.view(np.int64).copy()).cuda()
+                    dist.all_reduce(t)
+                    return t.cpu().numpy().view(np.uint64)
+                t = torch.from_numpy((arr ^ np.uint64(1 << 63)).view(np.int64).copy()).cuda()
+                dist.all_reduce(t, op=dist.ReduceOp.MIN if op == "min" else dist.ReduceOp.MAX)
+                return t.cpu().numpy().view(np.uint64) ^ np.uint64(1 << 63)
+
+        def step(_):
+            cnt, vals = gd.percentile([vin[i] for i in mine], [99000], allreduce=allreduce, stream=S)
+            extra["percentile99"], extra["sampled"] = vals[0], cnt
+            for i in mine:
+                gd.binarize(tmp[i], vals[0], stream=S)
+    wall_ms, dev_ms = timed_fn(None, args.steps, args.warmup, step=step)
+    bases_rank = max(sum(lengths[i] for i in sh) for sh in gd.lpt_shards(lengths, world))
+    achieved = bytes_per_base * bases_rank / (dev_ms * 1e-3) / 1e9
+    result = {"metric": "Gbases/sec on %s over 3.1 Gbp" % name, "value": round(total_bases / (wall_ms * 1e-3) / 1e9, 2),
+              "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+              "ms_per_step": round(wall_ms, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+              "dtype": "f64", "data": "synthetic",
+              "config": {"workload": name + " on 24-chrom 3.1 Gbp synthetic signal", "bases": total_bases,
+                         "fir_mode": args.mode, "sharding": "whole chromosomes, LPT over ranks"},
+              "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                           "algorithmic_bytes_per_base": bytes_per_base}}
+    result.update(extra)
+    if rank == 0:
+        print(json.dumps(result))
 
 
 def measured_traffic(algorithmic_bytes_per_launch):

@@ -1,0 +1,149 @@
+"""GPU: the hot path at BASELINE.json's full chromosome size (chr1, 248 956 422 bases, 2 GB).
+
+The oracle cannot run whole chromosomes in test time, so parity at this size is held through
+(1) windows recomputed by the oracle from the regenerated synthetic signal -- both ends of the
+chromosome, tile seams and random interior stretches, bit for bit -- and (2) size-independent
+properties of each operator (mass preservation of the normalised Hann window, idempotence of
+closing, rank bracketing of the order statistic, run-length round trip, interval mass).
+"""
+import numpy as np
+import pytest
+
+from conftest import bits_equal
+from oracle import cpu
+
+pytestmark = pytest.mark.gpu
+
+SEED = 20240611
+N = 248956422          # chr1 of the bench genome
+CHROM = 0
+
+
+@pytest.fixture(scope="module")
+def gd():
+    import genodsp_amd
+    return genodsp_amd
+
+
+@pytest.fixture(scope="module")
+def depth(gd):
+    return gd.synth_coverage(SEED, CHROM, 0, N, 0)
+
+
+@pytest.fixture(scope="module")
+def real(gd):
+    return gd.synth_coverage(SEED, CHROM, 0, N, 1)
+
+
+def windows(rng, length=6000, count=6):
+    seams = [2304 * 54021 - 3000, 4096 * 30000 - 3000, 16384 * 7000 - 3000]     # tile boundaries of the kernels
+    return [0, N - length] + seams + [int(s) for s in rng.integers(0, N - length, count)]
+
+
+def fetch(vec, start, count):
+    return vec.buf.download(np.float64, count, vec.offset + 8 * start)
+
+
+def regenerate(mode, start, count, halo):
+    """signal[start-halo, start+count+halo) clipped to the chromosome, plus the clip offsets"""
+    lo, hi = max(0, start - halo), min(N, start + count + halo)
+    return cpu.synth_coverage(SEED, CHROM, lo, hi - lo, mode), start - lo, hi - (start + count)
+
+
+def stencil_check(got_vec, oracle_fn, mode, halo, rng, exact=True, bound_fn=None):
+    for s in windows(rng):
+        m = 6000
+        x, left, right = regenerate(mode, s, m, halo)
+        # an operator of reach `halo` on the clipped stretch is exact wherever the stretch
+        # extends `halo` beyond the window or reaches the chromosome end
+        want = oracle_fn(x)[left:left + m]
+        got = fetch(got_vec, s, m)
+        if exact:
+            assert bits_equal(got, want), (s, int(np.flatnonzero(got != want)[0]))
+        else:
+            assert np.all(np.abs(got - want) <= bound_fn(x)[left:left + m]), s
+
+
+def test_synthetic_signal_regenerates_on_the_cpu(gd, depth, real):
+    rng = np.random.default_rng(0)
+    for s in windows(rng):
+        assert bits_equal(fetch(depth, s, 6000), cpu.synth_coverage(SEED, CHROM, s, 6000, 0))
+        assert bits_equal(fetch(real, s, 6000), cpu.synth_coverage(SEED, CHROM, s, 6000, 1))
+
+
+def test_smooth_w101_full_chromosome(gd, real):
+    rng = np.random.default_rng(1)
+    taps = cpu.hann_window(101)
+    out = gd.smooth(real, 101, mode=gd.FIR_EXACT)
+    stencil_check(out, lambda x: cpu.smooth(x, 101), 1, 50, rng)
+    # mass: taps sum to ~1, so away from the ends the output carries the input's total
+    lo_in, hi_in, cnt = gd.genome_minmax([real])
+    lo_out, hi_out, _ = gd.genome_minmax([out])
+    assert cnt == N and lo_in <= lo_out and hi_out <= hi_in * (1 + 1e-12)    # a convex combination
+    fma = gd.smooth(real, 101, mode=gd.FIR_FMA)
+    stencil_check(fma, lambda x: cpu.smooth(x, 101), 1, 50, rng, exact=False,
+                  bound_fn=lambda x: 101 * 2.0 ** -52 * cpu.fir(np.abs(x), taps))
+    # the index output of config 3: peaks of the smoothed track
+    peaks = gd.localmax(out, 11)
+    stencil_check(peaks, lambda x: cpu.local_extrema(cpu.smooth(x, 101), 11, 1, 0.0), 1, 55, rng)
+
+
+def test_dilate_erode_binarize_full_chromosome(gd, depth):
+    rng = np.random.default_rng(2)
+    left, right = gd.split_length(1001)
+    d = gd.dilate(depth, left, right)
+    stencil_check(d, lambda x: cpu.dilate(x, left, right), 0, 1001, rng)
+    e = gd.erode(d, left, right)
+    stencil_check(e, lambda x: cpu.erode(cpu.dilate(x, left, right), left, right), 0, 2002, rng)
+    closed = gd.binarize(e.copy())
+    # closing is extensive (keeps every base of the original set) ...
+    s0, e0, _ = gd.report_runs(gd.binarize(depth.copy()))
+    s1, e1, v1 = gd.report_runs(closed)
+    assert np.all(v1 == 1.0)
+    covered0, covered1 = int((e0 - s0).sum()), int((e1 - s1).sum())
+    assert covered1 >= covered0 and s1.size <= s0.size
+    # ... and idempotent up to the shift the reference's split makes: dilate and erode both look
+    # at [i-right, i+left] with left=500, right=501 (morphology.c:919-920), not at mirrored
+    # windows, so every pass moves the set right by right-left = 1 base and changes nothing else
+    again = gd.binarize(gd.erode(gd.dilate(closed, left, right), left, right))
+    s2, e2, _ = gd.report_runs(again)
+    assert s2.size == s1.size
+    assert np.array_equal(s2, s1 + (right - left)) and np.array_equal(e2[:-1], e1[:-1] + (right - left))
+
+
+def test_percentile_rank_bracketing_full_chromosome(gd, depth, real):
+    for vec in (depth, real):
+        for pt in (50000, 99000):
+            cnt, (val,) = gd.percentile([vec], [pt])
+            assert cnt == N
+            k = gd.lib().gdsp_percentile_rank(cnt, pt)
+            # exact order statistic: #(v < val) <= k < #(v <= val); counted with the device reduction
+            _, _, le = gd.genome_minmax([vec], 1, -gd.DBL_MAX, val)
+            below = np.nextafter(val, -np.inf)
+            _, _, lt = gd.genome_minmax([vec], 1, -gd.DBL_MAX, below)
+            assert lt <= k < le, (pt, val, lt, k, le)
+        # the signal is untouched
+        assert bits_equal(fetch(vec, 12345678, 4096),
+                          cpu.synth_coverage(SEED, CHROM, 12345678, 4096, 0 if vec is depth else 1))
+
+
+def test_report_runs_round_trip_full_chromosome(gd, depth):
+    s, e, v = gd.report_runs(depth)
+    assert s.size > 1000000 and np.all(e > s) and np.all(s[1:] >= e[:-1]) and np.all(v != 0)
+    # rebuild the signal from its runs with the ingest kernel: bit-identical round trip
+    rebuilt = gd.apply_intervals(gd.fill(gd.DeviceVector(N), 0.0), s, e, v)
+    rng = np.random.default_rng(3)
+    for w in windows(rng):
+        assert bits_equal(fetch(rebuilt, w, 6000), fetch(depth, w, 6000))
+    lo, hi, cnt = gd.genome_minmax([rebuilt], 1, 2.2250738585072014e-308, gd.DBL_MAX)
+    assert cnt == int((e - s).sum())
+
+
+def test_running_sums_full_chromosome(gd, depth):
+    rng = np.random.default_rng(4)
+    out = gd.sliding_sum(depth, 101)
+    stencil_check(out, lambda x: cpu.sliding_sum(x, 101), 0, 101, rng)        # integer depth: exact
+    total = gd.cumulative_sum(depth.copy())
+    last = fetch(total, N - 1, 1)[0]
+    s, e, v = gd.report_runs(depth)
+    assert last == float(np.sum((e - s).astype(np.float64) * v))              # exact in f64: < 2^53
