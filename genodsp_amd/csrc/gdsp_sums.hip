@@ -86,6 +86,56 @@ void sliding_sum_kernel (const double* __restrict__ in, double* __restrict__ out
 	}
 
 // -------------------------------------------------------------- window sum ----
+#define WS_TILE_MAX_W 2048               // windows up to this long go through the tiled kernel
+#define WS_TILE_BASES 8192               // bases staged per workgroup (whole windows only)
+
+// Tiled form: a workgroup stages K whole windows with coalesced 16-byte loads, one thread
+// then sums one window from LDS in ascending order (bit-identical to sum.c:230-249), and
+// the tile is rewritten with coalesced 16-byte stores.  Rows are padded to an odd pitch so
+// that lanes walking different windows hit different LDS banks.
+__global__ __launch_bounds__(SU_THREADS)
+void window_sum_tile_kernel (double* __restrict__ v, uint32_t n, uint32_t W, uint32_t K, uint32_t ntiles,
+                             double denom, int useActual, double zeroVal)
+	{
+	extern __shared__ __attribute__((aligned(16))) double suLds[];
+	const uint32_t pitch = W | 1;                         // odd
+	double*        res   = suLds + (size_t) K * pitch;    // K results
+	const uint32_t tile  = gdsp_xcd_tile (blockIdx.x, ntiles);
+	const uint64_t base  = (uint64_t) tile * K * W;
+	const uint32_t span  = (uint32_t) ((base + (uint64_t) K*W <= n)? K*W : n - base);   // bases in this tile
+
+	// stage: thread handles bases p, p+256, ...; (row, col) advance without divisions
+	uint32_t row = threadIdx.x / W, col = threadIdx.x % W;
+	const uint32_t dRow = SU_THREADS / W, dCol = SU_THREADS % W;
+	for (uint32_t p=threadIdx.x ; p<span ; p+=SU_THREADS)
+		{
+		suLds[(size_t) row * pitch + col] = v[base + p];
+		row += dRow;  col += dCol;
+		if (col >= W) { col -= W;  row++; }
+		}
+	__syncthreads ();
+
+	for (uint32_t w=threadIdx.x ; w<K ; w+=SU_THREADS)
+		{
+		const uint64_t s = (uint64_t) w * W;
+		if (s >= span) break;
+		const uint32_t len = (uint32_t) ((s + W <= span)? W : span - s);
+		const double*  x   = suLds + (size_t) w * pitch;
+		double acc = x[0];
+		for (uint32_t k=1 ; k<len ; k++) acc += x[k];
+		res[w] = useActual? acc / (double) len : acc / denom;
+		}
+	__syncthreads ();
+
+	row = threadIdx.x / W;  col = threadIdx.x % W;
+	for (uint32_t p=threadIdx.x ; p<span ; p+=SU_THREADS)
+		{
+		v[base + p] = (col == 0)? res[row] : zeroVal;
+		row += dRow;  col += dCol;
+		if (col >= W) { col -= W;  row++; }
+		}
+	}
+
 #define WS_SEQ_MAX 8192
 // one thread per window, ascending adds (bit-identical to sum.c:230-249)
 __global__ __launch_bounds__(SU_THREADS)
@@ -125,28 +175,37 @@ void window_sum_wide_kernel (double* __restrict__ v, uint32_t n, uint32_t W,
 	}
 
 // ---------------------------------------------------------- cumulative sum ----
-#define CS_CHUNK 8192                     // bases per workgroup
-#define CS_PER   (CS_CHUNK / SU_THREADS)  // 32 bases per thread
+// Reduce-then-scan in three launches: chunk totals (8 B/base read), an exclusive scan of
+// the totals (tiny), then a local scan of every chunk plus its offset (8 B read + 8 B
+// write): 24 B/base of traffic for the 16 B/base the operator needs.  All global accesses
+// are 16 bytes per lane.
+#define CS_CHUNK 4096                     // bases per workgroup (32 KiB of LDS in the scan pass)
+#define CS_PER   (CS_CHUNK / SU_THREADS)  // 16 bases per thread
 
 __global__ __launch_bounds__(SU_THREADS)
-void cumsum_totals_kernel (const double* __restrict__ v, uint32_t n, double* __restrict__ totals)
+void cumsum_totals_kernel (const double* __restrict__ v, uint32_t n, uint32_t nchunks, double* __restrict__ totals)
 	{
-	__shared__ double part[SU_THREADS];
-	const uint64_t s = (uint64_t) blockIdx.x * CS_CHUNK;
+	__shared__ double part[SU_THREADS/64];
+	const uint32_t chunk = gdsp_xcd_tile (blockIdx.x, nchunks);
+	const uint64_t s     = (uint64_t) chunk * CS_CHUNK;
 	double acc = 0.0;
-	for (int k=0 ; k<CS_PER ; k++)
+	if (s + CS_CHUNK <= n)
 		{
-		uint64_t ix = s + (uint64_t) k*SU_THREADS + threadIdx.x;
-		if (ix < n) acc += v[ix];
+		const double2* p = reinterpret_cast<const double2*> (v + s) + threadIdx.x;
+		double2 d[CS_PER/2];
+#pragma unroll
+		for (int u=0 ; u<CS_PER/2 ; u++) d[u] = p[u*SU_THREADS];
+#pragma unroll
+		for (int u=0 ; u<CS_PER/2 ; u++) acc += d[u].x + d[u].y;
 		}
-	part[threadIdx.x] = acc;
+	else
+		{
+		for (uint64_t ix=s+threadIdx.x ; ix<n ; ix+=SU_THREADS) acc += v[ix];
+		}
+	for (int off=32 ; off>0 ; off>>=1) acc += __shfl_down (acc, off, 64);
+	if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
 	__syncthreads ();
-	for (int d=SU_THREADS/2 ; d>0 ; d>>=1)
-		{
-		if ((int) threadIdx.x < d) part[threadIdx.x] += part[threadIdx.x + d];
-		__syncthreads ();
-		}
-	if (threadIdx.x == 0) totals[blockIdx.x] = part[0];
+	if (threadIdx.x == 0) totals[chunk] = (part[0] + part[1]) + (part[2] + part[3]);
 	}
 
 // exclusive scan of the chunk totals, one workgroup of 1024
@@ -155,7 +214,7 @@ void cumsum_offsets_kernel (double* __restrict__ totals, uint32_t nchunks)
 	{
 	__shared__ double sums[1024];
 	const uint32_t per = (nchunks + 1023) / 1024;
-	const uint32_t a = threadIdx.x * per, b = (a + per < nchunks)? a + per : nchunks;
+	const uint32_t a = threadIdx.x * per, b = (a + per < nchunks)? a + per : ((a < nchunks)? nchunks : a);
 	double acc = 0.0;
 	for (uint32_t i=a ; i<b ; i++) acc += totals[i];
 	sums[threadIdx.x] = acc;
@@ -172,19 +231,33 @@ void cumsum_offsets_kernel (double* __restrict__ totals, uint32_t nchunks)
 	}
 
 __global__ __launch_bounds__(SU_THREADS)
-void cumsum_apply_kernel (double* __restrict__ v, uint32_t n, const double* __restrict__ offsets)
+void cumsum_apply_kernel (double* __restrict__ v, uint32_t n, uint32_t nchunks, const double* __restrict__ offsets)
 	{
-	extern __shared__ __attribute__((aligned(16))) double suLds[];
+	__shared__ __attribute__((aligned(16))) double csLds[CS_CHUNK + 2];
 	__shared__ double waveTotals[SU_THREADS/64];
-	const uint64_t s = (uint64_t) blockIdx.x * CS_CHUNK;
-	const int      L = CS_CHUNK;
-	for (int p=threadIdx.x ; p<L ; p+=SU_THREADS)
-		{ uint64_t ix = s + p;  suLds[p] = (ix < n)? v[ix] : 0.0; }
+	const uint32_t chunk = gdsp_xcd_tile (blockIdx.x, nchunks);
+	const int64_t  s     = (int64_t) chunk * CS_CHUNK;
+	gdsp_stage_f64<SU_THREADS> (csLds, v, n, s, CS_CHUNK, 0.0);
 	__syncthreads ();
-	block_prefix_sum (suLds, L, CS_PER + 1, waveTotals);          // 33 values per thread (odd stride)
-	const double off = offsets[blockIdx.x];
-	for (int p=threadIdx.x ; p<L ; p+=SU_THREADS)
-		{ uint64_t ix = s + p;  if (ix < n) v[ix] = off + suLds[p]; }
+	block_prefix_sum (csLds, CS_CHUNK, CS_PER + 1, waveTotals);   // 17 values per thread (odd stride)
+	const double off = offsets[chunk];
+	if (s + CS_CHUNK <= (int64_t) n)
+		{
+		double2*       dst = reinterpret_cast<double2*> (v + s);
+		const double2* src = reinterpret_cast<const double2*> (csLds);
+#pragma unroll
+		for (int u=0 ; u<CS_PER/2 ; u++)
+			{
+			double2 d = src[threadIdx.x + u*SU_THREADS];
+			d.x = off + d.x;  d.y = off + d.y;
+			dst[threadIdx.x + u*SU_THREADS] = d;
+			}
+		}
+	else
+		{
+		for (int p=threadIdx.x ; p<CS_CHUNK ; p+=SU_THREADS)
+			{ if (s + p < (int64_t) n) v[s+p] = off + csLds[p]; }
+		}
 	}
 
 extern "C" {
@@ -229,7 +302,18 @@ int gdsp_window_sum (double* d_v, uint32_t n, uint32_t W, double denom, int useA
 	GDSP_REQUIRE (useActual || (denom != 0.0), "denominator can't be zero");
 	if (W > n) W = n;
 	const uint32_t nwin = (uint32_t) (((uint64_t) n + W - 1) / W);
-	if (W <= WS_SEQ_MAX)
+	if (W <= WS_TILE_MAX_W)
+		{
+		const uint32_t K      = WS_TILE_BASES / W;                         // >= 4 whole windows per tile
+		const uint32_t ntiles = (uint32_t) (((uint64_t) n + (uint64_t) K*W - 1) / ((uint64_t) K*W));
+		const size_t   bytes  = ((size_t) K * (W | 1) + K + 2) * sizeof(double);
+		if (bytes > 64*1024)
+			GDSP_HIP_TRY (hipFuncSetAttribute ((const void*) window_sum_tile_kernel,
+			                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024));
+		hipLaunchKernelGGL (window_sum_tile_kernel, dim3(ntiles), dim3(SU_THREADS), bytes, gdsp_stream (stream),
+		                    d_v, n, W, K, ntiles, denom, useActual, zeroVal);
+		}
+	else if (W <= WS_SEQ_MAX)
 		hipLaunchKernelGGL (window_sum_seq_kernel, dim3((nwin + SU_THREADS - 1)/SU_THREADS), dim3(SU_THREADS), 0,
 		                    gdsp_stream (stream), d_v, n, W, nwin, denom, useActual, zeroVal);
 	else
@@ -249,12 +333,10 @@ int gdsp_cumulative_sum (double* d_v, uint32_t n, void* d_work, void* stream)
 	const uint32_t nchunks = (uint32_t) (((uint64_t) n + CS_CHUNK - 1) / CS_CHUNK);
 	double*        totals  = (double*) d_work;
 	hipStream_t    s       = gdsp_stream (stream);
-	hipLaunchKernelGGL (cumsum_totals_kernel,  dim3(nchunks), dim3(SU_THREADS), 0, s, d_v, n, totals);
+	GDSP_REQUIRE (gdsp_aligned16 (d_v), "vector must be 16-byte aligned");
+	hipLaunchKernelGGL (cumsum_totals_kernel,  dim3(nchunks), dim3(SU_THREADS), 0, s, d_v, n, nchunks, totals);
 	hipLaunchKernelGGL (cumsum_offsets_kernel, dim3(1),       dim3(1024),       0, s, totals, nchunks);
-	GDSP_HIP_TRY (hipFuncSetAttribute ((const void*) cumsum_apply_kernel,
-	                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96*1024));
-	hipLaunchKernelGGL (cumsum_apply_kernel,   dim3(nchunks), dim3(SU_THREADS),
-	                    (CS_CHUNK + SU_THREADS) * sizeof(double), s, d_v, n, totals);
+	hipLaunchKernelGGL (cumsum_apply_kernel,   dim3(nchunks), dim3(SU_THREADS), 0, s, d_v, n, nchunks, totals);
 	GDSP_LAUNCH_CHECK ();
 	return GDSP_OK;
 	}
