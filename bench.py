@@ -48,6 +48,7 @@ def main():
                     help="FIR arithmetic of the headline number (the other one is reported too)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink every chromosome (debugging only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--nofuse", action="store_true", help="peaks/morph workloads: one kernel per operator")
     ap.add_argument("--workload", choices=["smooth", "peaks", "morph", "percentile"], default="smooth",
                     help="smooth = BASELINE configs[1] (the metric); the others are configs[2..4], "
                          "reported in the same shape for DESIGN.md, never the driver's number")
@@ -188,17 +189,23 @@ def other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_base
 
         def step(_):
             for i in mine:
-                gd.smooth(vin[i], WINDOW, out=vout[i], mode=mode, stream=S)
-                gd.localmax(vout[i], 11, out=tmp[i], stream=S)
+                if args.nofuse:
+                    gd.smooth(vin[i], WINDOW, out=vout[i], mode=mode, stream=S)
+                    gd.localmax(vout[i], 11, out=tmp[i], stream=S)
+                else:
+                    gd.smooth_local_extrema(vin[i], WINDOW, 11, True, 0.0, out=tmp[i], mode=mode, stream=S)
     elif args.workload == "morph":        # configs[3]: dilate 1001 = erode 1001 = binarize
         name, bytes_per_base = "dilate 1001 = erode 1001 = binarize", 48
         left, right = gd.split_length(1001)
 
         def step(_):
             for i in mine:
-                gd.dilate(vin[i], left, right, out=vout[i], stream=S)
-                gd.erode(vout[i], left, right, out=tmp[i], stream=S)
-                gd.binarize(tmp[i], 0.0, stream=S)
+                if args.nofuse:
+                    gd.dilate(vin[i], left, right, out=vout[i], stream=S)
+                    gd.erode(vout[i], left, right, out=tmp[i], stream=S)
+                    gd.binarize(tmp[i], 0.0, stream=S)
+                else:
+                    gd.dilate_erode(vin[i], left, right, left, right, binarize=(0.0, False, 1.0, 0.0), out=tmp[i], stream=S)
     else:                                 # configs[4]: percentile 99 = binarize --threshold=percentile99
         name, bytes_per_base = "percentile 99 = binarize --threshold=percentile99", 24
         for i in mine:
@@ -227,7 +234,8 @@ def other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_base
               "ms_per_step": round(wall_ms, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
               "dtype": "f64", "data": "synthetic",
               "config": {"workload": name + " on 24-chrom 3.1 Gbp synthetic signal", "bases": total_bases,
-                         "fir_mode": args.mode, "sharding": "whole chromosomes, LPT over ranks"},
+                         "fir_mode": args.mode, "fused": not args.nofuse,
+                         "sharding": "whole chromosomes, LPT over ranks"},
               "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                            "algorithmic_bytes_per_base": bytes_per_base}}

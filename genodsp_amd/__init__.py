@@ -179,6 +179,13 @@ def smooth(v, W=101, out=None, mode=FIR_EXACT, stream=None):
     return out
 
 
+def smooth_local_extrema(v, W, N, want_max, fill, out=None, mode=FIR_EXACT, stream=None):
+    """`= smooth W = localmax|localmin N` fused (bit-identical to the two calls in sequence)."""
+    out = out if out is not None else v.like()
+    call("gdsp_smooth_local_extrema", v.ptr, out.ptr, v.n, W, mode, N, int(want_max), float(fill), _sp(stream))
+    return out
+
+
 def sliding_sum(v, W, denom=1.0, out=None, stream=None):
     out = out if out is not None else v.like()
     call("gdsp_sliding_sum", v.ptr, out.ptr, v.n, W, float(denom), _sp(stream))
@@ -236,6 +243,17 @@ def dilate(v, left, right, T=0.0, one=1.0, zero=0.0, out=None, stream=None):
 def erode(v, left, right, T=0.0, one=1.0, zero=0.0, out=None, stream=None):
     out = out if out is not None else v.like()
     call("gdsp_erode", v.ptr, out.ptr, v.n, left, right, float(T), float(one), float(zero), _sp(stream))
+    return out
+
+
+def dilate_erode(v, d_left, d_right, e_left, e_right, d_T=0.0, d_one=1.0, d_zero=0.0, e_T=0.0, e_one=1.0,
+                 e_zero=0.0, binarize=None, out=None, stream=None):
+    """`= dilate = erode [= binarize]` fused; binarize = (T, ties_above, one, zero) or None."""
+    out = out if out is not None else v.like()
+    b = binarize if binarize is not None else (0.0, False, 1.0, 0.0)
+    call("gdsp_dilate_erode", v.ptr, out.ptr, v.n, d_left, d_right, float(d_T), float(d_one), float(d_zero),
+         e_left, e_right, float(e_T), float(e_one), float(e_zero), int(binarize is not None),
+         float(b[0]), int(b[1]), float(b[2]), float(b[3]), _sp(stream))
     return out
 
 

@@ -54,6 +54,8 @@ SIGNATURES = {
     "gdsp_fir_plan_destroy": (_int, [_vp]),
     "gdsp_fir_apply": (_int, [_vp, _vp, _vp, _u32, _int, _vp]),
     "gdsp_smooth": (_int, [_vp, _vp, _u32, _u32, _int, _vp]),
+    "gdsp_smooth_local_extrema_fusable": (_int, [_u32, _u32]),
+    "gdsp_smooth_local_extrema": (_int, [_vp, _vp, _u32, _u32, _int, _u32, _int, _f64, _vp]),
     "gdsp_sliding_sum": (_int, [_vp, _vp, _u32, _u32, _f64, _vp]),
     "gdsp_window_sum": (_int, [_vp, _u32, _u32, _f64, _int, _f64, _vp]),
     "gdsp_cumulative_sum_work": (_sz, [_u32]),
@@ -62,6 +64,8 @@ SIGNATURES = {
     "gdsp_best_extrema": (_int, [_vp, _vp, _u32, _u32, _int, _vp]),
     "gdsp_dilate": (_int, [_vp, _vp, _u32, _u32, _u32, _f64, _f64, _f64, _vp]),
     "gdsp_erode": (_int, [_vp, _vp, _u32, _u32, _u32, _f64, _f64, _f64, _vp]),
+    "gdsp_dilate_erode": (_int, [_vp, _vp, _u32, _u32, _u32, _f64, _f64, _f64, _u32, _u32, _f64, _f64, _f64,
+                                 _int, _f64, _int, _f64, _f64, _vp]),
     "gdsp_close": (_int, [_vp, _vp, _u32, _f64, _f64, _f64, _f64, _vp]),
     "gdsp_open": (_int, [_vp, _vp, _u32, _f64, _f64, _f64, _f64, _vp]),
     "gdsp_binarize": (_int, [_vp, _u32, _f64, _int, _f64, _f64, _vp]),
@@ -88,7 +92,7 @@ SIGNATURES = {
 }
 
 # functions whose int return is a status code
-_STATUS = {k for k, (r, _) in SIGNATURES.items() if r is _int}
+_STATUS = {k for k, (r, _) in SIGNATURES.items() if r is _int} - {"gdsp_smooth_local_extrema_fusable"}
 
 
 def lib():

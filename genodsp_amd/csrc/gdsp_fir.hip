@@ -140,6 +140,84 @@ void fir_fixed_kernel (const double* __restrict__ in, double* __restrict__ out,
 	fir_store_tile<R> (lds, acc, out, tileStart, n);
 	}
 
+// ------------------------------------------- fixed W fused with localmin/localmax ----
+// `= smooth W=101 = localmax N=11` (BASELINE configs[2]) in one pass: the smoothed tile is
+// already in LDS on its way out, so the neighbourhood test runs there and only the peaks
+// track is written -- 16 B/base for the pair instead of 32.  A workgroup still computes
+// 256*R smoothed values but keeps the inner 256*R - 2h (h = neighbourhood half width); the
+// h values on either side are recomputed by the neighbouring tiles (0.4 % extra FP64 work
+// at N=11).  Smoothed values and comparisons are exactly those of the two separate
+// kernels, so the result is bit-identical to running them one after the other.
+#define FIR_FUSE_MAX_HALF 64
+template <int W, int R, bool FMA, bool MAX>
+__global__ __launch_bounds__(FIR_THREADS)
+void fir_fixed_extrema_kernel (const double* __restrict__ in, double* __restrict__ out,
+                               uint32_t n, uint32_t ntiles, FirTaps<W> taps, int h, double fill)
+	{
+	constexpr int H  = (W - 1) / 2;
+	constexpr int T  = FIR_THREADS * R;
+	constexpr int LP = (T + W - 1 + 1 + 1) & ~1;           // room for the alignment shift
+	__shared__ __attribute__((aligned(16))) double lds[LP];
+
+	const int      sh        = (h + H) & 1;                // keeps the first staged index even
+	const int      stride    = T - 2*h;                    // outputs kept per tile (even)
+	const uint32_t tile      = gdsp_xcd_tile (blockIdx.x, ntiles);
+	const int64_t  keepStart = (int64_t) tile * stride;    // first output this tile stores
+	const int64_t  compStart = keepStart - h;              // first smoothed value it computes
+	const int64_t  g0        = compStart - H - sh;
+
+	gdsp_stage_f64<FIR_THREADS> (lds, in, n, g0, LP, 0.0);
+	__syncthreads ();
+
+	const double* x = lds + sh + threadIdx.x * R;
+	double acc[R];
+#pragma unroll
+	for (int r=0 ; r<R ; r++) acc[r] = 0.0;
+#pragma unroll
+	for (int j=0 ; j<R+W-1 ; j++)
+		{
+		const double xv = x[j];
+#pragma unroll
+		for (int r=0 ; r<R ; r++)
+			{
+			const int k = j - r;
+			if ((k >= 0) && (k < W))
+				{
+				if (FMA) acc[r] = __builtin_fma (taps.w[k], xv, acc[r]);
+				else     acc[r] = acc[r] + taps.w[k] * xv;
+				}
+			}
+		}
+	__syncthreads ();
+
+	// smoothed values into LDS; positions outside the vector can never beat anything
+	const double never = MAX? -INFINITY : INFINITY;
+	double* s = lds;
+#pragma unroll
+	for (int r=0 ; r<R ; r++)
+		{
+		const int64_t g = compStart + (int64_t) threadIdx.x * R + r;
+		s[threadIdx.x * R + r] = ((g >= 0) && (g < (int64_t) n))? acc[r] : never;
+		}
+	__syncthreads ();
+
+	for (int o = 2*threadIdx.x ; o < stride ; o += 2*FIR_THREADS)
+		{
+		const int64_t g = keepStart + o;
+		if (g >= (int64_t) n) break;
+		const double* w = s + o;                           // w[0..2h] = neighbourhood of output o
+		double e0 = w[0], e1 = w[2*h + 1], mid = w[1];
+		for (int k=2 ; k<=2*h ; k++) mid = MAX? fmax (mid, w[k]) : fmin (mid, w[k]);
+		if (h > 0) { e0 = MAX? fmax (e0, mid) : fmin (e0, mid);  e1 = MAX? fmax (mid, e1) : fmin (mid, e1); }
+		else       { e1 = w[1]; }
+		const double c0 = w[h], c1 = w[h+1];
+		const double r0 = (MAX? (e0 > c0) : (e0 < c0))? fill : c0;
+		const double r1 = (MAX? (e1 > c1) : (e1 < c1))? fill : c1;
+		if (g + 1 < (int64_t) n) *reinterpret_cast<double2*> (out + g) = make_double2 (r0, r1);
+		else                     out[g] = r0;
+		}
+	}
+
 // --------------------------------------------------------- run-time W kernel ----
 // Any odd W (up to the reference's 50001, sum.c:478).  Taps are walked in stages
 // of at most KC so the LDS image stays small; the accumulators live in registers
@@ -308,6 +386,22 @@ int gdsp_fir_apply (const gdsp_fir_plan* plan, const double* d_in, double* d_out
 	return GDSP_OK;
 	}
 
+} // extern "C"
+
+template <bool FMA, bool MAX>
+static void fir_extrema_launch (const double* d_in, double* d_out, uint32_t n, const double* h_taps,
+                                int h, double fill, hipStream_t s)
+	{
+	FirTaps<101> taps;
+	memcpy (taps.w, h_taps, sizeof(taps.w));
+	const int      stride = FIR_THREADS*FIR_R - 2*h;
+	const uint32_t ntiles = (uint32_t) (((uint64_t) n + stride - 1) / stride);
+	hipLaunchKernelGGL ((fir_fixed_extrema_kernel<101, FIR_R, FMA, MAX>), dim3(ntiles), dim3(FIR_THREADS), 0, s,
+	                    d_in, d_out, n, ntiles, taps, h, fill);
+	}
+
+extern "C" {
+
 // Hann plans cached per (device, W): `smooth` rebuilds its window for every
 // chromosome in the reference (sum.c:632-645); here it is built once.
 #define SMOOTH_CACHE 32
@@ -315,7 +409,46 @@ static struct { int device; uint32_t W; gdsp_fir_plan* plan; } smoothCache[SMOOT
 static int        smoothCacheLen = 0;
 static std::mutex smoothCacheLock;
 
+static int smooth_plan (uint32_t W, gdsp_fir_plan** out);
+
+// 1 when gdsp_smooth_local_extrema has a fused kernel for this pair of parameters
+int gdsp_smooth_local_extrema_fusable (uint32_t W, uint32_t N)
+	{ return (W == 101) && (N >= 1) && ((N - 1) / 2 <= FIR_FUSE_MAX_HALF); }
+
+// `= smooth W = localmax|localmin N` in one pass (sum.c:616-676 then minmax.c:981-1022 /
+// :1183-1227); bit-identical to gdsp_smooth followed by gdsp_local_extrema.
+int gdsp_smooth_local_extrema (const double* d_in, double* d_out, uint32_t n, uint32_t W, int mode,
+                               uint32_t N, int wantMax, double fill, void* stream)
+	{
+	GDSP_REQUIRE (gdsp_smooth_local_extrema_fusable (W, N), "no fused kernel for this window/neighborhood");
+	GDSP_REQUIRE ((mode == GDSP_FIR_EXACT) || (mode == GDSP_FIR_FMA), "unknown mode");
+	if (n == 0) return GDSP_OK;
+	GDSP_REQUIRE ((d_in != NULL) && (d_out != NULL) && (d_in != d_out), "vectors must be distinct and non-NULL");
+	GDSP_REQUIRE (gdsp_aligned16 (d_in) && gdsp_aligned16 (d_out), "vectors must be 16-byte aligned");
+	gdsp_fir_plan* plan = NULL;
+	int rc = smooth_plan (W, &plan);
+	if (rc != GDSP_OK) return rc;
+	const int   h = (int) ((N - 1) / 2);
+	hipStream_t s = gdsp_stream (stream);
+	if (mode == GDSP_FIR_FMA)
+		{ if (wantMax) fir_extrema_launch<true, true>  (d_in, d_out, n, plan->h_taps, h, fill, s);
+		  else         fir_extrema_launch<true, false> (d_in, d_out, n, plan->h_taps, h, fill, s); }
+	else
+		{ if (wantMax) fir_extrema_launch<false, true>  (d_in, d_out, n, plan->h_taps, h, fill, s);
+		  else         fir_extrema_launch<false, false> (d_in, d_out, n, plan->h_taps, h, fill, s); }
+	GDSP_LAUNCH_CHECK ();
+	return GDSP_OK;
+	}
+
 int gdsp_smooth (const double* d_in, double* d_out, uint32_t n, uint32_t W, int mode, void* stream)
+	{
+	gdsp_fir_plan* plan = NULL;
+	int rc = smooth_plan (W, &plan);
+	if (rc != GDSP_OK) return rc;
+	return gdsp_fir_apply (plan, d_in, d_out, n, mode, stream);
+	}
+
+static int smooth_plan (uint32_t W, gdsp_fir_plan** out)
 	{
 	GDSP_REQUIRE ((W >= 3) && (W & 1), "W must be odd and >= 3");
 	GDSP_REQUIRE (W <= 50001, "W exceeds 50001");          // sum.c:478, :557-558
@@ -323,27 +456,26 @@ int gdsp_smooth (const double* d_in, double* d_out, uint32_t n, uint32_t W, int 
 	GDSP_HIP_TRY (hipGetDevice (&device));
 
 	gdsp_fir_plan* plan = NULL;
+	std::lock_guard<std::mutex> hold (smoothCacheLock);
+	for (int i=0 ; i<smoothCacheLen ; i++)
+		{ if ((smoothCache[i].device == device) && (smoothCache[i].W == W)) { plan = smoothCache[i].plan;  break; } }
+	if (plan == NULL)
 		{
-		std::lock_guard<std::mutex> hold (smoothCacheLock);
-		for (int i=0 ; i<smoothCacheLen ; i++)
-			{ if ((smoothCache[i].device == device) && (smoothCache[i].W == W)) { plan = smoothCache[i].plan;  break; } }
-		if (plan == NULL)
-			{
-			double* taps = (double*) malloc ((size_t) W * sizeof(double));
-			if (taps == NULL) { gdsp_set_error ("out of host memory");  return GDSP_ENOMEM; }
-			gdsp_hann_taps (W, taps);
-			int rc = gdsp_fir_plan_create (&plan, taps, W);
-			free (taps);
-			if (rc != GDSP_OK) return rc;
-			if (smoothCacheLen == SMOOTH_CACHE)
-				{ gdsp_fir_plan_destroy (smoothCache[0].plan);  smoothCache[0] = smoothCache[--smoothCacheLen]; }
-			smoothCache[smoothCacheLen].device = device;
-			smoothCache[smoothCacheLen].W      = W;
-			smoothCache[smoothCacheLen].plan   = plan;
-			smoothCacheLen++;
-			}
+		double* taps = (double*) malloc ((size_t) W * sizeof(double));
+		if (taps == NULL) { gdsp_set_error ("out of host memory");  return GDSP_ENOMEM; }
+		gdsp_hann_taps (W, taps);
+		int rc = gdsp_fir_plan_create (&plan, taps, W);
+		free (taps);
+		if (rc != GDSP_OK) return rc;
+		if (smoothCacheLen == SMOOTH_CACHE)
+			{ gdsp_fir_plan_destroy (smoothCache[0].plan);  smoothCache[0] = smoothCache[--smoothCacheLen]; }
+		smoothCache[smoothCacheLen].device = device;
+		smoothCache[smoothCacheLen].W      = W;
+		smoothCache[smoothCacheLen].plan   = plan;
+		smoothCacheLen++;
 		}
-	return gdsp_fir_apply (plan, d_in, d_out, n, mode, stream);
+	*out = plan;
+	return GDSP_OK;
 	}
 
 } // extern "C"

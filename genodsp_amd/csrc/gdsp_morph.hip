@@ -71,30 +71,15 @@ __device__ __forceinline__ int mo_prev (const MoTables& t, int p)
 	return (w > 0)? t.prevTo[w-1] : MO_NONE_LO;
 	}
 
+// ---- stage: 128 bases per wave-step -> two mask words, MO_STAGE_UNROLL steps' loads in flight.
+// Tiles whose whole staged range lies inside the vector (all but the two ends) load
+// unconditionally: a predicated load gets its own branch and an s_waitcnt vmcnt(0), which
+// would leave one load in flight per wave.
 template <int OP>
-__global__ __launch_bounds__(MO_THREADS)
-void morph_kernel (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t ntiles,
-                   int tile, int haloL, int nwords,
-                   int left, int right, double length, double T, double one, double zero)
+__device__ __forceinline__ void mo_stage (uint64_t* mask, const double* __restrict__ in, uint32_t n,
+                                          int64_t g0, int nwords, double T, bool complement)
 	{
-	extern __shared__ __attribute__((aligned(16))) uint64_t moLds[];
-	uint64_t* mask     = moLds;                                    // nwords
-	int*      nextFrom = reinterpret_cast<int*> (mask + nwords);   // nwords+1
-	int*      prevTo   = nextFrom + nwords + 1;                    // nwords
-	__shared__ int scanA[MO_THREADS], scanB[MO_THREADS];
-
-	const uint32_t t         = gdsp_xcd_tile (blockIdx.x, ntiles);
-	const int64_t  tileStart = (int64_t) t * tile;
-	const int64_t  g0        = tileStart - haloL;                  // multiple of 128
-	const int      lane      = threadIdx.x & 63, wave = threadIdx.x >> 6;
-
-	// erode and open ask about the complement (positions NOT in S; outside the vector counts)
-	const bool complement = (OP == MO_ERODE) || (OP == MO_OPEN);
-
-	// ---- stage: 128 bases per wave-step -> two mask words, MO_STAGE_UNROLL steps' loads in flight.
-	// Tiles whose whole staged range lies inside the vector (all but the two ends) load
-	// unconditionally: a predicated load gets its own branch and an s_waitcnt vmcnt(0), which
-	// would leave one load in flight per wave.
+	const int  lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int  nchunks  = nwords / 2;
 	const bool interior = (g0 >= 0) && (g0 + 64*(int64_t) nwords <= (int64_t) n);
 	for (int c0 = wave*MO_STAGE_UNROLL ; c0 < nchunks ; c0 += (MO_THREADS/64)*MO_STAGE_UNROLL)
@@ -142,50 +127,75 @@ void morph_kernel (const double* __restrict__ in, double* __restrict__ out, uint
 			}
 		}
 	__syncthreads ();
+	}
 
-	// ---- per-word tables by one block-wide scan: each thread owns K consecutive words
+// ---- per-word tables by one block-wide scan: each thread owns K consecutive words.
+// nextFrom[w] = first set position at or after word w (nwords+1 entries), prevTo[w] = last
+// set position at or before the end of word w.  Ends with a barrier.
+__device__ __forceinline__ void mo_build_tables (const uint64_t* mask, int* nextFrom, int* prevTo, int nwords,
+                                                 int* scanA, int* scanB)
+	{
 	const int K  = (nwords + MO_THREADS - 1) / MO_THREADS;
 	const int w0 = threadIdx.x * K, w1 = (w0 + K < nwords)? w0 + K : nwords;
+	int firstSet = MO_NONE_HI, lastSet = MO_NONE_LO;
+	for (int w=w0 ; w<w1 ; w++)
 		{
-		int firstSet = MO_NONE_HI, lastSet = MO_NONE_LO;
-		for (int w=w0 ; w<w1 ; w++)
+		uint64_t m = mask[w];
+		if (m)
 			{
-			uint64_t m = mask[w];
-			if (m)
-				{
-				if (firstSet == MO_NONE_HI) firstSet = 64*w + __builtin_ctzll (m);
-				lastSet = 64*w + 63 - __builtin_clzll (m);
-				}
+			if (firstSet == MO_NONE_HI) firstSet = 64*w + __builtin_ctzll (m);
+			lastSet = 64*w + 63 - __builtin_clzll (m);
 			}
-		scanA[threadIdx.x] = firstSet;       // suffix-min over threads
-		scanB[threadIdx.x] = lastSet;        // prefix-max over threads
-		__syncthreads ();
-		for (int d=1 ; d<MO_THREADS ; d*=2)
-			{
-			int a = ((int) threadIdx.x + d < MO_THREADS)? scanA[threadIdx.x + d] : MO_NONE_HI;
-			int b = ((int) threadIdx.x - d >= 0)?         scanB[threadIdx.x - d] : MO_NONE_LO;
-			__syncthreads ();
-			if (a < scanA[threadIdx.x]) scanA[threadIdx.x] = a;
-			if (b > scanB[threadIdx.x]) scanB[threadIdx.x] = b;
-			__syncthreads ();
-			}
-		int carryHi = ((int) threadIdx.x + 1 < MO_THREADS)? scanA[threadIdx.x + 1] : MO_NONE_HI;
-		int carryLo = ((int) threadIdx.x - 1 >= 0)?         scanB[threadIdx.x - 1] : MO_NONE_LO;
-		for (int w=w1-1 ; w>=w0 ; w--)
-			{
-			uint64_t m = mask[w];
-			if (m) carryHi = 64*w + __builtin_ctzll (m);
-			nextFrom[w] = carryHi;
-			}
-		for (int w=w0 ; w<w1 ; w++)
-			{
-			uint64_t m = mask[w];
-			if (m) carryLo = 64*w + 63 - __builtin_clzll (m);
-			prevTo[w] = carryLo;
-			}
-		if (threadIdx.x == 0) nextFrom[nwords] = MO_NONE_HI;
 		}
+	scanA[threadIdx.x] = firstSet;       // suffix-min over threads
+	scanB[threadIdx.x] = lastSet;        // prefix-max over threads
 	__syncthreads ();
+	for (int d=1 ; d<MO_THREADS ; d*=2)
+		{
+		int a = ((int) threadIdx.x + d < MO_THREADS)? scanA[threadIdx.x + d] : MO_NONE_HI;
+		int b = ((int) threadIdx.x - d >= 0)?         scanB[threadIdx.x - d] : MO_NONE_LO;
+		__syncthreads ();
+		if (a < scanA[threadIdx.x]) scanA[threadIdx.x] = a;
+		if (b > scanB[threadIdx.x]) scanB[threadIdx.x] = b;
+		__syncthreads ();
+		}
+	int carryHi = ((int) threadIdx.x + 1 < MO_THREADS)? scanA[threadIdx.x + 1] : MO_NONE_HI;
+	int carryLo = ((int) threadIdx.x - 1 >= 0)?         scanB[threadIdx.x - 1] : MO_NONE_LO;
+	for (int w=w1-1 ; w>=w0 ; w--)
+		{
+		uint64_t m = mask[w];
+		if (m) carryHi = 64*w + __builtin_ctzll (m);
+		nextFrom[w] = carryHi;
+		}
+	for (int w=w0 ; w<w1 ; w++)
+		{
+		uint64_t m = mask[w];
+		if (m) carryLo = 64*w + 63 - __builtin_clzll (m);
+		prevTo[w] = carryLo;
+		}
+	if (threadIdx.x == 0) nextFrom[nwords] = MO_NONE_HI;
+	__syncthreads ();
+	}
+
+template <int OP>
+__global__ __launch_bounds__(MO_THREADS)
+void morph_kernel (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t ntiles,
+                   int tile, int haloL, int nwords,
+                   int left, int right, double length, double T, double one, double zero)
+	{
+	extern __shared__ __attribute__((aligned(16))) uint64_t moLds[];
+	uint64_t* mask     = moLds;                                    // nwords
+	int*      nextFrom = reinterpret_cast<int*> (mask + nwords);   // nwords+1
+	int*      prevTo   = nextFrom + nwords + 1;                    // nwords
+	__shared__ int scanA[MO_THREADS], scanB[MO_THREADS];
+
+	const uint32_t t         = gdsp_xcd_tile (blockIdx.x, ntiles);
+	const int64_t  tileStart = (int64_t) t * tile;
+	const int64_t  g0        = tileStart - haloL;                  // multiple of 128
+
+	// erode and open ask about the complement (positions NOT in S; outside the vector counts)
+	mo_stage<OP> (mask, in, n, g0, nwords, T, (OP == MO_ERODE) || (OP == MO_OPEN));
+	mo_build_tables (mask, nextFrom, prevTo, nwords, scanA, scanB);
 
 	// ---- answer: two adjacent bases per lane, one 16-byte store
 	const MoTables tb = { mask, nextFrom, prevTo };
@@ -227,6 +237,66 @@ void morph_kernel (const double* __restrict__ in, double* __restrict__ out, uint
 			}
 		if (g + 1 < (int64_t) n) *reinterpret_cast<double2*> (out + g) = make_double2 (r[0], r[1]);
 		else                     out[g] = r[0];
+		}
+	}
+
+// ---- `= dilate = erode [= binarize]` in one pass (BASELINE configs[3]): 16 B/base for the
+// chain instead of 16 B/base per operator.  The dilated set never leaves LDS: it is rebuilt
+// as a second bit mask (one ballot per 64 bases) from the first mask's tables, the tables
+// are rebuilt for its complement, and the erosion is answered from those.  Every decision is
+// the same integer predicate the separate kernels evaluate, so the output is bit-identical
+// to running them one after the other.
+//   dMemberOne / dMemberZero: whether dilate's `one` / `zero` output value counts as "in" for
+//   erode's own threshold; vOne / vZero: erode's outputs already passed through binarize.
+__global__ __launch_bounds__(MO_THREADS)
+void morph_dilate_erode_kernel (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t ntiles,
+                                int tile, int haloL, int nwords, int dLeft, int dRight, int eLeft, int eRight,
+                                double T, int dMemberOne, int dMemberZero, double vOne, double vZero)
+	{
+	extern __shared__ __attribute__((aligned(16))) uint64_t moLds[];
+	uint64_t* mask     = moLds;                                    // nwords: S, the input set
+	uint64_t* dmask    = mask + nwords;                            // nwords: complement of erode's input set
+	int*      nextFrom = reinterpret_cast<int*> (dmask + nwords);  // nwords+1
+	int*      prevTo   = nextFrom + nwords + 1;                    // nwords
+	__shared__ int scanA[MO_THREADS], scanB[MO_THREADS];
+
+	const uint32_t t         = gdsp_xcd_tile (blockIdx.x, ntiles);
+	const int64_t  tileStart = (int64_t) t * tile;
+	const int64_t  g0        = tileStart - haloL;
+	const int      lane      = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int      S         = 64 * nwords;
+
+	mo_stage<MO_DILATE> (mask, in, n, g0, nwords, T, false);
+	mo_build_tables (mask, nextFrom, prevTo, nwords, scanA, scanB);
+
+	// dilated set, one word per wave-step; positions outside the vector are not in any set
+		{
+		const MoTables tb = { mask, nextFrom, prevTo };
+		for (int w = wave ; w < nwords ; w += MO_THREADS/64)
+			{
+			const int     p = 64*w + lane;
+			const int64_t g = g0 + p;
+			bool dil = false;
+			if ((g >= 0) && (g < (int64_t) n) && (p - dRight >= 0) && (p + dLeft < S))
+				dil = (mo_next (tb, p - dRight) <= p + dLeft);
+			const bool member = (g >= 0) && (g < (int64_t) n) && (dil? (dMemberOne != 0) : (dMemberZero != 0));
+			const uint64_t word = __ballot (member);
+			if (lane == 0) dmask[w] = ~word;               // erode asks about the complement
+			}
+		}
+	__syncthreads ();
+	mo_build_tables (dmask, nextFrom, prevTo, nwords, scanA, scanB);
+
+	const MoTables tb = { dmask, nextFrom, prevTo };
+	for (int o = 2*threadIdx.x ; o < tile ; o += 2*MO_THREADS)
+		{
+		const int64_t g = tileStart + o;
+		if (g >= (int64_t) n) break;
+		const int  p  = haloL + o;
+		const bool k0 = (mo_next (tb, p     - eRight) > p     + eLeft);
+		const bool k1 = (mo_next (tb, p + 1 - eRight) > p + 1 + eLeft);
+		if (g + 1 < (int64_t) n) *reinterpret_cast<double2*> (out + g) = make_double2 (k0? vOne : vZero, k1? vOne : vZero);
+		else                     out[g] = k0? vOne : vZero;
 		}
 	}
 
@@ -286,6 +356,50 @@ int gdsp_dilate (const double* d_in, double* d_out, uint32_t n, uint32_t left, u
 int gdsp_erode (const double* d_in, double* d_out, uint32_t n, uint32_t left, uint32_t right,
                 double T, double one, double zero, void* stream)
 	{ return morph_launch<MO_ERODE> (d_in, d_out, n, left, right, 0.0, T, one, zero, stream); }
+
+/* `= dilate = erode [= binarize]` fused (see morph_dilate_erode_kernel).  Each stage keeps its
+ * own threshold and output values, exactly as the three operators would apply them. */
+int gdsp_dilate_erode (const double* d_in, double* d_out, uint32_t n,
+                       uint32_t dLeft, uint32_t dRight, double dT, double dOne, double dZero,
+                       uint32_t eLeft, uint32_t eRight, double eT, double eOne, double eZero,
+                       int binarize, double bT, int bTiesAbove, double bOne, double bZero, void* stream)
+	{
+	if (n == 0) return GDSP_OK;
+	GDSP_REQUIRE ((d_in != NULL) && (d_out != NULL) && (d_in != d_out), "vectors must be distinct and non-NULL");
+	GDSP_REQUIRE (gdsp_aligned16 (d_in) && gdsp_aligned16 (d_out), "vectors must be 16-byte aligned");
+	if (dLeft > n) dLeft = n;
+	if (dRight > n) dRight = n;
+	if (eLeft > n) eLeft = n;
+	if (eRight > n) eRight = n;
+	const uint64_t reachL = (uint64_t) dRight + eRight, reachR = (uint64_t) dLeft + eLeft + 1;
+	const uint64_t haloL = ((reachL + 127) / 128) * 128, haloR = ((reachR + 127) / 128) * 128;
+	if (haloL + haloR + 512 > MO_MAX_STAGE/2)
+		{
+		gdsp_set_error ("gdsp_dilate_erode: combined reach of %llu+%llu bases exceeds what one LDS tile holds",
+		                (unsigned long long) reachL, (unsigned long long) reachR);
+		return GDSP_EINVAL;
+		}
+	uint64_t tile = 4 * (haloL + haloR);
+	if (tile < MO_MIN_TILE) tile = MO_MIN_TILE;
+	if (tile + haloL + haloR > MO_MAX_STAGE/2) tile = MO_MAX_STAGE/2 - haloL - haloR;
+	tile = (tile / 512) * 512;
+	const int      nwords = (int) ((haloL + tile + haloR) / 64);
+	const uint32_t ntiles = (uint32_t) (((uint64_t) n + tile - 1) / tile);
+	const size_t   bytes  = (size_t) nwords * 16 + ((size_t) 2*nwords + 2) * 4;
+
+	double vOne = eOne, vZero = eZero;
+	if (binarize)
+		{
+		vOne  = (bTiesAbove? (eOne  >= bT) : (eOne  > bT))? bOne : bZero;     // logical.c:247-257
+		vZero = (bTiesAbove? (eZero >= bT) : (eZero > bT))? bOne : bZero;
+		}
+	hipLaunchKernelGGL (morph_dilate_erode_kernel, dim3(ntiles), dim3(MO_THREADS), bytes, gdsp_stream (stream),
+	                    d_in, d_out, n, ntiles, (int) tile, (int) haloL, nwords,
+	                    (int) dLeft, (int) dRight, (int) eLeft, (int) eRight,
+	                    dT, (int) (dOne > eT), (int) (dZero > eT), vOne, vZero);       // erode membership: v > T
+	GDSP_LAUNCH_CHECK ();
+	return GDSP_OK;
+	}
 
 int gdsp_close (const double* d_in, double* d_out, uint32_t n, double closingLength,
                 double T, double one, double zero, void* stream)

@@ -98,6 +98,7 @@ static int originOne      = false;
 static int inhibitOutput  = false;
 static int numDevices     = 1;
 int        firMode        = GDSP_FIR_EXACT;      /* --smooth=exact|fma (see ops_sum.c) */
+static int fuseChains     = true;                /* --nofuse: one kernel per operator          */
 
 /* a chromosome as the driver sees it: the public spec first, device state after */
 typedef struct xspec
@@ -146,6 +147,8 @@ static void usage (void)
 	"  --nooutput                do not write the resulting signal\n"
 	"  --window=<length>         (W=) default window size for windowed operators\n"
 	"  --gpus=<n>                shard whole chromosomes over n GPUs (default 1)\n"
+	"  --nofuse                  run every operator as its own kernel (default: the chains\n"
+	"                            smooth=localmax|localmin and dilate=erode[=binarize] are fused)\n"
 	"  --smooth=exact|fma        arithmetic of `smooth`: exact = bit-identical to genodsp\n"
 	"                            (default); fma = fused multiply-add, one rounding per tap\n"
 	"  --help[=<operator>]  ?  ?<operator>   operator help\n"
@@ -856,6 +859,7 @@ static void parse_options (int _argc, char** _argv)            /* genodsp.c:284-
 			if ((numDevices < 1) || (numDevices > 64)) chastise ("--gpus must be between 1 and 64 (\"%s\")\n", arg);
 			continue;
 			}
+		if (strcmp (arg, "--nofuse") == 0) { fuseChains = false;  continue; }
 		if (strcmp (arg, "--smooth=exact") == 0) { firMode = GDSP_FIR_EXACT;  continue; }
 		if (strcmp (arg, "--smooth=fma")   == 0) { firMode = GDSP_FIR_FMA;    continue; }
 		if (strcmp (arg, "?") == 0) usage_operations ();
@@ -950,7 +954,13 @@ int main (int argc, char** argv)
 				for (dspop* op=firstOp ; op!=stopOp ; op=op->next)
 					{
 					if (trackOperations) fprintf (stderr, "%s(%s)\n", op->name, s->chrom);
-					(*op->funcApply) (op, s->chrom, s->length, s->valVector);
+					int fused = fuseChains? try_fused_apply (op, stopOp, s) : 0;
+					if (fused == 0) { (*op->funcApply) (op, s->chrom, s->length, s->valVector);  continue; }
+					for ( ; fused > 1 ; fused--)           /* the chain ran as one kernel */
+						{
+						op = op->next;
+						if (trackOperations) fprintf (stderr, "%s(%s)\n", op->name, s->chrom);
+						}
 					}
 				}
 			}

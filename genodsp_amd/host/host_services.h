@@ -25,6 +25,14 @@ u32   window_arg       (char* name, char* arg, char* argVal, const char* what);
 void  value_or_variable (char* argVal, valtype* val, char** varName);
 void  resolve_variable  (dspop* op, char** varName, valtype* val, const char* role);
 
+/* ops_fused.c: run op (and the operators after it, up to stopOp) as one fused kernel when
+ * the chain is one the device library fuses; returns how many operators were consumed (0 = none) */
+int   try_fused_apply   (dspop* op, dspop* stopOp, spec* s);
+u32   op_smooth_window    (dspop* op);
+void  op_local_describe   (dspop* op, u32* neighborhood, int* wantMax, valtype* fill);
+void  op_morph_describe   (dspop* op, u32* left, u32* right, valtype* T, valtype* one, valtype* zero);
+void  op_binarize_describe (dspop* op, valtype* T, int* tiesAbove, valtype* one, valtype* zero);
+
 /* argument helpers used by every operator's parse function */
 #define OP_SHORT(fn, text)                                                            \
 void fn##_short (char* name, int nameWidth, FILE* f, char* indent)                    \

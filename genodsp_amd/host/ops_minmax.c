@@ -48,6 +48,12 @@ static void local_usage (char* name, FILE* f, char* indent, int wantMax)
 	else         fprintf (f, "%s  --infinity=<value>       value for non-minima (default: largest double)\n", indent);
 	}
 
+void op_local_describe (dspop* _op, u32* neighborhood, int* wantMax, valtype* fill)
+	{
+	dspop_local* op = (dspop_local*) _op;
+	*neighborhood = op->neighborhood;  *wantMax = op->wantMax;  *fill = op->fill;
+	}
+
 static void local_apply (dspop* _op, char* vName, u32 vLen, valtype* v)
 	{
 	dspop_local* op = (dspop_local*) _op;

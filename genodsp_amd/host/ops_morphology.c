@@ -80,6 +80,17 @@ static void morph_free (dspop* _op)
 	free (op);
 	}
 
+/* parameters as morph_apply would use them (resolves a threshold variable, with the usual note) */
+void op_morph_describe (dspop* _op, u32* left, u32* right, valtype* T, valtype* one, valtype* zero)
+	{
+	dspop_morph* op = (dspop_morph*) _op;
+	resolve_variable (_op, &op->thresholdVarName, &op->threshold, "threshold");
+	*left = op->left;  *right = op->right;
+	if ((*left == 0) && (*right == 0))
+		{ *left = (u32) (op->length / 2);  *right = (u32) (op->length - *left); }
+	*T = op->threshold;  *one = op->oneVal;  *zero = op->zeroVal;
+	}
+
 static void morph_apply (dspop* _op, char* vName, u32 vLen, valtype* v)
 	{
 	dspop_morph* op = (dspop_morph*) _op;

@@ -61,6 +61,13 @@ void op_binarize_free (dspop* _op)
 	free (op);
 	}
 
+void op_binarize_describe (dspop* _op, valtype* T, int* tiesAbove, valtype* one, valtype* zero)
+	{
+	dspop_binarize* op = (dspop_binarize*) _op;
+	resolve_variable (_op, &op->thresholdVarName, &op->threshold, "threshold");
+	*T = op->threshold;  *tiesAbove = op->tiesAbove;  *one = op->oneVal;  *zero = op->zeroVal;
+	}
+
 void op_binarize_apply (dspop* _op, arg_dont_complain(char* vName), u32 vLen, valtype* v)
 	{
 	dspop_binarize* op = (dspop_binarize*) _op;

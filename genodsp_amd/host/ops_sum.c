@@ -164,6 +164,8 @@ dspop* op_smooth_parse (char* name, int argc, char** argv)
 
 void op_smooth_free (dspop* op) { free (op); }
 
+u32 op_smooth_window (dspop* op) { return ((dspop_smooth*) op)->windowSize; }
+
 void op_smooth_apply (dspop* _op, char* vName, u32 vLen, valtype* v)
 	{
 	dspop_smooth* op = (dspop_smooth*) _op;

@@ -75,6 +75,13 @@ int gdsp_fir_apply        (const gdsp_fir_plan* plan, const double* d_in, double
 int gdsp_smooth           (const double* d_in, double* d_out, uint32_t n, uint32_t W,
                            int mode, void* stream);
 
+/* `= smooth W = localmax|localmin N` in one pass (sum.c:616-676 feeding minmax.c:1183-1227 /
+ * :981-1022): the smoothed tile is tested in LDS and only the peaks track is written.
+ * Bit-identical to gdsp_smooth followed by gdsp_local_extrema.  Fusable for W=101, N<=129. */
+int gdsp_smooth_local_extrema_fusable (uint32_t W, uint32_t N);
+int gdsp_smooth_local_extrema (const double* d_in, double* d_out, uint32_t n, uint32_t W, int mode,
+                               uint32_t N, int wantMax, double fill, void* stream);
+
 /* op_sliding_sum_apply (sum.c:420-463): centred window sum / denom, out-of-place.
  * Bit-identical to the reference whenever every partial sum is exact (integer
  * or dyadic signals); otherwise within the running-sum rounding bound. */
@@ -104,6 +111,13 @@ int gdsp_dilate (const double* d_in, double* d_out, uint32_t n, uint32_t left, u
                  double T, double one, double zero, void* stream);   /* :882-1072  */
 int gdsp_erode  (const double* d_in, double* d_out, uint32_t n, uint32_t left, uint32_t right,
                  double T, double one, double zero, void* stream);   /* :1331-1454 */
+/* `= dilate = erode [= binarize]` in one pass (morphology.c:882-1072 -> :1331-1454 ->
+ * logical.c:216-268): the dilated set stays in LDS as a bit mask.  Bit-identical to the
+ * three calls in sequence; each stage keeps its own threshold and output values. */
+int gdsp_dilate_erode (const double* d_in, double* d_out, uint32_t n,
+                       uint32_t dLeft, uint32_t dRight, double dT, double dOne, double dZero,
+                       uint32_t eLeft, uint32_t eRight, double eT, double eOne, double eZero,
+                       int binarize, double bT, int bTiesAbove, double bOne, double bZero, void* stream);
 int gdsp_close  (const double* d_in, double* d_out, uint32_t n, double closingLength,
                  double T, double one, double zero, void* stream);   /* :231-319   */
 int gdsp_open   (const double* d_in, double* d_out, uint32_t n, double openingLength,

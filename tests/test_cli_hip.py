@@ -108,3 +108,14 @@ def test_chromosome_specs_on_command_line_and_origin(tmp_path):
     rc, out, err = run(["chrZ:100:200", "--novalue"], "chrZ 90 110\nchrZ 150 160\nchrZ 195 300\n")
     assert rc == 0, err
     assert out == "chrZ\t100\t110\t1\nchrZ\t150\t160\t1\nchrZ\t195\t200\t1\n"
+
+
+@pytest.mark.parametrize("name", ["cli_smooth_localmax", "cli_dilate_erode_binarize"])
+def test_fused_chains_equal_separate_operators(name, tmp_path):
+    """The driver fuses these chains by default; --nofuse runs one kernel per operator.  Both must
+    print what the reference printed."""
+    case = golden().cases[name]
+    for extra in ([], ["--nofuse"]):
+        rc, out, err = run(extra + case["args"], case["stdin"], case["chroms_text"], tmp_path)
+        assert rc == 0, err
+        assert out == case["stdout"], extra

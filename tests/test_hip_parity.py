@@ -396,3 +396,47 @@ def test_synth_signal_matches_cpu_generator(mode, gd):
     for chrom, start, count in ((0, 0, 100000), (5, 123456789, 4097), (23, 4000000000 - 50, 50)):
         got = gd.synth_coverage(SEED, chrom, start, count, mode).numpy()
         assert bits_equal(got, cpu.synth_coverage(SEED, chrom, start, count, mode))
+
+
+# ------------------------------------------------------------ fused chains ----
+
+@pytest.mark.parametrize("n", [1, 2, 11, 2293, 2294, 2295, 2304, 4588, 100003])
+@pytest.mark.parametrize("N", [1, 3, 11, 41, 129])
+def test_fused_smooth_localmax_is_the_two_operators(n, N, gd):
+    rng = np.random.default_rng(n + N)
+    for kind in ("depth", "real"):
+        x = _signal(kind, n, rng)
+        d = gd.DeviceVector.from_numpy(x)
+        sm = cpu.smooth(x, 101)
+        for want_max, fill in ((True, 0.0), (False, cpu.DBL_MAX), (True, -7.0)):
+            got = gd.smooth_local_extrema(d, 101, N, want_max, fill).numpy()
+            want = cpu.local_extrema(sm, N, 1 if want_max else 0, fill)
+            assert bits_equal(got, want), (kind, want_max, first_diff(got, want))
+        # fma mode: identical to the two fma-mode kernels run one after the other
+        got = gd.smooth_local_extrema(d, 101, N, True, 0.0, mode=gd.FIR_FMA).numpy()
+        two = gd.localmax(gd.smooth(d, 101, mode=gd.FIR_FMA), N).numpy()
+        assert bits_equal(got, two)
+    assert gd.lib().gdsp_smooth_local_extrema_fusable(101, 11) == 1
+    assert gd.lib().gdsp_smooth_local_extrema_fusable(21, 11) == 0
+    assert gd.lib().gdsp_smooth_local_extrema_fusable(101, 131) == 0
+
+
+@pytest.mark.parametrize("n", [1, 2, 127, 129, 16384, 16385, 100000, 300007])
+@pytest.mark.parametrize("L", [1, 2, 7, 64, 65, 1001, 5000])
+def test_fused_dilate_erode_binarize_is_the_three_operators(n, L, gd):
+    rng = np.random.default_rng(n * 3 + L)
+    x = _islands(n, rng, max_gap=3 * L + 5, max_run=3 * L + 5)
+    d = gd.DeviceVector.from_numpy(x)
+    dl, dr = gd.split_length(L)
+    for (el, er) in ((dl, dr), (3, 0), (0, 2 * L)):
+        want = cpu.erode(cpu.dilate(x, dl, dr), el, er)
+        assert bits_equal(gd.dilate_erode(d, dl, dr, el, er).numpy(), want), ("plain", el, er)
+        wantb = cpu.binarize(want, 0.5, False, 9.0, -9.0)
+        assert bits_equal(gd.dilate_erode(d, dl, dr, el, er, binarize=(0.5, False, 9.0, -9.0)).numpy(), wantb)
+    # every stage with its own threshold and values, including ones that invert membership
+    want = cpu.erode(cpu.dilate(x, dl, dr, 2.0, 5.0, -1.0), dl, dr, 0.0, 3.0, 4.0)
+    got = gd.dilate_erode(d, dl, dr, dl, dr, d_T=2.0, d_one=5.0, d_zero=-1.0, e_T=0.0, e_one=3.0, e_zero=4.0).numpy()
+    assert bits_equal(got, want)
+    want = cpu.erode(cpu.dilate(x, dl, dr, 0.0, -5.0, 1.0), dl, dr)          # dilate's "one" is below erode's threshold
+    got = gd.dilate_erode(d, dl, dr, dl, dr, d_one=-5.0, d_zero=1.0).numpy()
+    assert bits_equal(got, want)
