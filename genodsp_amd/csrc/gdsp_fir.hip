@@ -23,9 +23,10 @@
 // Measured on MI355X (profiles/r01_*): the FP64 pipe is busy 86 % of the kernel's
 // cycles in FMA mode and the chip holds ~2.0 GHz under this load, i.e. the
 // kernel runs at the FP64 vector rate the part sustains, at half the HBM peak.
-// A persistent form with the taps in VGPRs and register prefetch of the next
-// tile was 15-20 % slower (3 waves/SIMD expose the LDS latency that 8 waves
-// hide); 7, 9 or 11 outputs per thread perform alike (profiles/r01_fir_variants_ab.txt).
+// Persistent forms (taps in VGPRs at 3 waves/SIMD, or taps in SGPRs with register
+// prefetch of the next tile at 5 waves/SIMD) were 7-20 % slower: the FMA stream
+// wants all 8 waves/SIMD; 7, 9 or 11 outputs per thread and 128-, 256- or
+// 512-thread workgroups perform alike (profiles/r01_fir_variants_ab.txt).
 // EXACT mode issues v_mul_f64 + v_add_f64 per tap (bit-identical to the
 // reference's unfused x86 loop); FMA mode issues one v_fma_f64 per tap.
 // This translation unit is compiled with -ffp-contract=off so that only the
