@@ -48,6 +48,9 @@ def main():
                     help="FIR arithmetic of the headline number (the other one is reported too)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink every chromosome (debugging only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="debugging: every rank uses GPU 0 and the gloo backend, to exercise the N>1 code path "
+                         "where only one GPU exists (numbers from such a run mean nothing)")
     ap.add_argument("--nofuse", action="store_true", help="peaks/morph workloads: one kernel per operator")
     ap.add_argument("--workload", choices=["smooth", "peaks", "morph", "percentile"], default="smooth",
                     help="smooth = BASELINE configs[1] (the metric); the others are configs[2..4], "
@@ -63,12 +66,18 @@ def main():
     import torch
     import genodsp_amd as gd
 
-    torch.cuda.set_device(local_rank)
-    gd.set_device(local_rank)
+    device_index = 0 if args.rehearse_on_one_gpu else local_rank
+    torch.cuda.set_device(device_index)
+    gd.set_device(device_index)
     dist = None
+    reduce_device = "cuda"
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group(backend="gloo")
+            reduce_device = "cpu"
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     def barrier():
         if dist is not None:
@@ -110,13 +119,14 @@ def main():
         wall_ms = (t1 - t0) * 1e3 / steps
         dev_ms = e0.elapsed_ms(e1) / steps          # HIP events on the launch stream
         if dist is not None:
-            t = torch.tensor([wall_ms, dev_ms], dtype=torch.float64, device="cuda")
+            t = torch.tensor([wall_ms, dev_ms], dtype=torch.float64, device=reduce_device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wall_ms, dev_ms = float(t[0]), float(t[1])
         return wall_ms, dev_ms
 
     if args.workload != "smooth":
-        other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_bases, vin, vout, stream, timed_fn=timed)
+        other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_bases, vin, vout, stream,
+                       timed_fn=timed, reduce_device=reduce_device)
         barrier()
         if dist is not None:
             dist.destroy_process_group()
@@ -149,7 +159,7 @@ def main():
                 "fp64_valu_frac": round(flops / FP64_VALU_PEAK_TFLOPS, 4)}
 
     result = {
-        "metric": "Gbases/sec on smooth W=101 over 3.1 Gbp",
+        "metric": "Gbases/sec on smooth W=101 over 3.1 Gbp; HBM GB/s vs peak at 1/2/4/8 GPU",
         "value": round(total_bases / (wall_ms * 1e-3) / 1e9, 2),
         "unit": "Gbases/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -178,7 +188,8 @@ def main():
         dist.destroy_process_group()
 
 
-def other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_bases, vin, vout, stream, timed_fn):
+def other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_bases, vin, vout, stream, timed_fn,
+                   reduce_device="cuda"):
     """BASELINE configs[2..4] in the bench harness: same signal, same timing discipline."""
     S = stream.handle
     tmp = {i: gd.DeviceVector(lengths[i]) for i in mine}
@@ -214,10 +225,10 @@ def other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_base
         if dist is not None:
             def allreduce(arr, op):       # RCCL: the path's only collective (<= 64 KiB per select pass)
                 if op == "sum":
-                    t = torch.from_numpy(arr.view(np.int64).copy()).cuda()
+                    t = torch.from_numpy(arr.view(np.int64).copy()).to(reduce_device)
                     dist.all_reduce(t)
                     return t.cpu().numpy().view(np.uint64)
-                t = torch.from_numpy((arr ^ np.uint64(1 << 63)).view(np.int64).copy()).cuda()
+                t = torch.from_numpy((arr ^ np.uint64(1 << 63)).view(np.int64).copy()).to(reduce_device)
                 dist.all_reduce(t, op=dist.ReduceOp.MIN if op == "min" else dist.ReduceOp.MAX)
                 return t.cpu().numpy().view(np.uint64) ^ np.uint64(1 << 63)
 
