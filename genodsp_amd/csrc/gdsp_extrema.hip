@@ -17,9 +17,10 @@
 //
 // HBM-bound (16 B/base).  A workgroup stages a tile plus its halo in LDS with
 // 16-byte loads; every lane then produces two adjacent outputs and stores them
-// as one 16-byte word.  Small windows are scanned directly from LDS; large
-// windows first build range extremes over power-of-two spans by doubling
-// (log2(window) LDS sweeps), after which every window is two lookups.
+// as one 16-byte word.  Windows up to 32 bases are scanned directly from LDS, up
+// to 256 by log2 doubling in LDS, longer ones with the van Herk / Gil-Werman
+// decomposition (prefix and suffix extremes over window-long segments, three
+// comparisons per base for any window).
 
 #include <float.h>
 #include "gdsp_common.h"
@@ -27,6 +28,7 @@
 #define EX_THREADS 256
 #define EX_TILE    4096              // outputs per workgroup
 #define EX_DIRECT_MAX_SPAN 32        // windows up to this many bases are scanned directly
+#define EX_DOUBLING_MAX_SPAN 256     // up to here: log2 doubling; beyond: segment prefix/suffix extremes
 #define EX_LDS_DOUBLES 18432         // 144 KiB of the 160 KiB LDS
 
 template <bool MAX> __device__ __forceinline__ bool ex_beats (double a, double b)
@@ -35,13 +37,46 @@ template <bool MAX> __device__ __forceinline__ bool ex_beats (double a, double b
 template <bool MAX> __device__ __forceinline__ double ex_pick (double a, double b)
 	{ return MAX? fmax (a, b) : fmin (a, b); }
 
+// Exclusive segmented scan of one (value, flag) pair per thread over the workgroup, with
+// `pick` as the operator: returns the extreme of the values of the threads before this one
+// (after it, when REVERSE) back to the nearest thread whose flag is set, that thread included;
+// `pad` when there is none.  Wave shuffles inside a wave, one LDS hop across the four waves.
+template <bool MAX, bool REVERSE>
+__device__ __forceinline__ double ex_seg_carry (double val, bool flag, double pad, double* scanV, int* scanF)
+	{
+	const int lane = REVERSE? 63 - (int) (threadIdx.x & 63) : (int) (threadIdx.x & 63);
+	const int wave = REVERSE? (EX_THREADS/64 - 1) - (int) (threadIdx.x >> 6) : (int) (threadIdx.x >> 6);
+	double v = val;
+	int    f = flag? 1 : 0;
+	for (int d=1 ; d<64 ; d*=2)
+		{
+		const double v2 = REVERSE? __shfl_down (v, d, 64) : __shfl_up (v, d, 64);
+		const int    f2 = REVERSE? __shfl_down (f, d, 64) : __shfl_up (f, d, 64);
+		if (lane >= d) { if (!f) v = ex_pick<MAX> (v2, v);  f |= f2; }
+		}
+	// exclusive within the wave
+	double cv = REVERSE? __shfl_down (v, 1, 64) : __shfl_up (v, 1, 64);
+	int    cf = REVERSE? __shfl_down (f, 1, 64) : __shfl_up (f, 1, 64);
+	if (lane == 0) { cv = pad;  cf = 0; }
+	__syncthreads ();                            // scanV/scanF may still be read by the previous scan
+	if (lane == 63) { scanV[wave] = v;  scanF[wave] = f; }
+	__syncthreads ();
+	double pv = pad;
+	for (int w=0 ; w<wave ; w++) pv = scanF[w]? scanV[w] : ex_pick<MAX> (pv, scanV[w]);
+	return cf? cv : ex_pick<MAX> (pv, cv);
+	}
+
 // LOCAL: localmin/localmax semantics; otherwise bestmin/bestmax
-template <bool MAX, bool LOCAL, bool DIRECT>
+enum { EX_DIRECT = 0, EX_DOUBLING = 1, EX_SEGMENTS = 2 };
+
+template <bool MAX, bool LOCAL, int METHOD>
 __global__ __launch_bounds__(EX_THREADS)
 void extrema_kernel (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t ntiles,
                      uint32_t lft, uint32_t rgt, double fill, int tile)
 	{
 	extern __shared__ __attribute__((aligned(16))) double lds[];
+	__shared__ double scanV[EX_THREADS/64];
+	__shared__ int    scanF[EX_THREADS/64];
 	const double   pad       = MAX? -INFINITY : INFINITY;   // never beats anything, like "outside the vector"
 	const uint32_t t         = gdsp_xcd_tile (blockIdx.x, ntiles);
 	const int64_t  tileStart = (int64_t) t * tile;
@@ -55,7 +90,7 @@ void extrema_kernel (const double* __restrict__ in, double* __restrict__ out, ui
 
 	const double* x = lds + sh;                  // x[o + k], k in [0,span): window of output o
 
-	if (DIRECT)
+	if (METHOD == EX_DIRECT)
 		{
 		for (int o = 2*threadIdx.x ; o < tile ; o += 2*EX_THREADS)
 			{
@@ -78,29 +113,100 @@ void extrema_kernel (const double* __restrict__ in, double* __restrict__ out, ui
 		return;
 		}
 
-	// doubling: after step s, cur[i] = extreme of x[i .. i+2^s); ping-pong between two LDS arrays
-	double* cur = lds;
-	double* nxt = lds + L;
-	int     lg  = 0;
-	while ((2 << lg) <= span) lg++;              // 2^lg <= span < 2^(lg+1)
-	for (int s=0 ; s<lg ; s++)
+	if (METHOD == EX_DOUBLING)
 		{
-		const int half = 1 << s;
-		for (int p=threadIdx.x ; p+2*half<=L ; p+=EX_THREADS) nxt[p] = ex_pick<MAX> (cur[p], cur[p+half]);
-		__syncthreads ();
-		double* swap = cur;  cur = nxt;  nxt = swap;
+		// medium windows: after step s, cur[i] = extreme of x[i .. i+2^s); ping-pong between two
+		// LDS arrays, log2(span) sweeps, then every window is two lookups
+		double* cur = lds;
+		double* nxt = lds + L;
+		int     lg  = 0;
+		while ((2 << lg) <= span) lg++;              // 2^lg <= span < 2^(lg+1)
+		for (int s=0 ; s<lg ; s++)
+			{
+			const int half = 1 << s;
+			for (int p=threadIdx.x ; p+2*half<=L ; p+=EX_THREADS) nxt[p] = ex_pick<MAX> (cur[p], cur[p+half]);
+			__syncthreads ();
+			double* swap = cur;  cur = nxt;  nxt = swap;
+			}
+		const int     w2 = 1 << lg;
+		const double* mm = cur + sh;
+		for (int o = 2*threadIdx.x ; o < tile ; o += 2*EX_THREADS)
+			{
+			int64_t g = tileStart + o;
+			if (g >= (int64_t) n) break;
+			double e0 = ex_pick<MAX> (mm[o],   mm[o   + span - w2]);
+			double e1 = ex_pick<MAX> (mm[o+1], mm[o+1 + span - w2]);
+			if (LOCAL)
+				{
+				double c0 = in[g], c1 = (g + 1 < (int64_t) n)? in[g+1] : 0.0;   // staged copy consumed: centres from L2
+				e0 = ex_beats<MAX> (e0, c0)? fill : c0;
+				e1 = ex_beats<MAX> (e1, c1)? fill : c1;
+				}
+			if (g + 1 < (int64_t) n) *reinterpret_cast<double2*> (out + g) = make_double2 (e0, e1);
+			else                     out[g] = e0;
+			}
+		return;
 		}
-	const int     w2 = 1 << lg;
-	const double* mm = cur + sh;
+
+	// Long windows, van Herk / Gil-Werman: cut the staged stretch into segments of `span`
+	// bases; G[q] = extreme from the start of q's segment to q, Hs[q] = extreme from q to the
+	// end of its segment.  A window of `span` bases starting at o covers the tail of one
+	// segment and the head of the next, so its extreme is pick(Hs[o], G[o+span-1]): three
+	// comparisons per base whatever the window length.  Each thread scans C consecutive
+	// bases; what crosses thread boundaries is a 256-element segmented scan.
+	double*   Hs = lds + L;                      // second array, x-space index
+	double*   G  = lds + sh;                     // first array, overwritten in place after Hs is built
+	const int Lx = L - sh;
+	int       C  = (Lx + EX_THREADS - 1) / EX_THREADS;
+	C |= 1;                                      // odd lane stride: conflict-free ds_read_b64
+	const int q0 = threadIdx.x * C;
+	const int q1 = (q0 + C < Lx)? q0 + C : Lx;
+
+	// ---- suffix extremes (right to left); a segment ends at q % span == span-1 or at Lx-1
+		{
+		double run = pad;
+		int    lastEnd = -1;                     // right-most segment end inside this chunk
+		int    r = (q1 > q0)? (q1 - 1) % span : 0;
+		for (int q=q1-1 ; q>=q0 ; q--)
+			{
+			if ((r == span-1) || (q == Lx-1)) { run = pad;  if (lastEnd < 0) lastEnd = q; }
+			run = ex_pick<MAX> (run, x[q]);
+			Hs[q] = run;
+			r = (r == 0)? span-1 : r-1;
+			}
+		const double carry = ex_seg_carry<MAX, true> (run, lastEnd >= 0, pad, scanV, scanF);
+		const int stop = (lastEnd >= 0)? lastEnd : q0 - 1;      // bases right of the last end see the carry
+		for (int q=q1-1 ; q>stop ; q--) Hs[q] = ex_pick<MAX> (Hs[q], carry);
+		}
+	__syncthreads ();
+
+	// ---- prefix extremes (left to right), in place over the staged values
+		{
+		double run = pad;
+		int    firstStart = -1;
+		int    r = q0 % span;
+		for (int q=q0 ; q<q1 ; q++)
+			{
+			if (r == 0) { run = pad;  if (firstStart < 0) firstStart = q; }
+			run = ex_pick<MAX> (run, G[q]);
+			G[q] = run;
+			r = (r == span-1)? 0 : r+1;
+			}
+		const double carry = ex_seg_carry<MAX, false> (run, firstStart >= 0, pad, scanV, scanF);
+		const int stop = (firstStart >= 0)? firstStart : q1;
+		for (int q=q0 ; q<stop ; q++) G[q] = ex_pick<MAX> (G[q], carry);
+		}
+	__syncthreads ();
+
 	for (int o = 2*threadIdx.x ; o < tile ; o += 2*EX_THREADS)
 		{
 		int64_t g = tileStart + o;
 		if (g >= (int64_t) n) break;
-		double e0 = ex_pick<MAX> (mm[o],   mm[o   + span - w2]);
-		double e1 = ex_pick<MAX> (mm[o+1], mm[o+1 + span - w2]);
+		double e0 = ex_pick<MAX> (Hs[o],   G[o   + span - 1]);
+		double e1 = ex_pick<MAX> (Hs[o+1], G[o+1 + span - 1]);
 		if (LOCAL)
 			{
-			// the staged copy was consumed by the ping-pong; centres come back from L2
+			// the staged copy was consumed by the prefix pass; centres come back from L2
 			double c0 = in[g], c1 = (g + 1 < (int64_t) n)? in[g+1] : 0.0;
 			e0 = ex_beats<MAX> (e0, c0)? fill : c0;
 			e1 = ex_beats<MAX> (e1, c1)? fill : c1;
@@ -124,6 +230,7 @@ static int extrema_launch (const double* d_in, double* d_out, uint32_t n, uint32
 	if (rgt > n) rgt = n;
 	const uint64_t span   = (uint64_t) lft + rgt + 1;
 	const bool     direct = (span <= EX_DIRECT_MAX_SPAN);
+	const bool     medium = (span <= EX_DOUBLING_MAX_SPAN);
 	int            tile   = EX_TILE;
 	size_t         ldsDoubles;
 	if (direct) ldsDoubles = (size_t) tile + span + 2;
@@ -145,15 +252,18 @@ static int extrema_launch (const double* d_in, double* d_out, uint32_t n, uint32
 	const size_t   bytes  = ldsDoubles * sizeof(double);
 	hipStream_t    s      = gdsp_stream (stream);
 	if (direct)
-		hipLaunchKernelGGL ((extrema_kernel<MAX, LOCAL, true>),  dim3(ntiles), dim3(EX_THREADS), bytes, s,
+		hipLaunchKernelGGL ((extrema_kernel<MAX, LOCAL, EX_DIRECT>),  dim3(ntiles), dim3(EX_THREADS), bytes, s,
+		                    d_in, d_out, n, ntiles, lft, rgt, fill, tile);
+	else if (medium)
+		hipLaunchKernelGGL ((extrema_kernel<MAX, LOCAL, EX_DOUBLING>), dim3(ntiles), dim3(EX_THREADS), bytes, s,
 		                    d_in, d_out, n, ntiles, lft, rgt, fill, tile);
 	else
 		{
 		if (bytes > 64*1024)          // more than 64 KiB of dynamic LDS has to be asked for
-			GDSP_HIP_TRY (hipFuncSetAttribute ((const void*) extrema_kernel<MAX, LOCAL, false>,
+			GDSP_HIP_TRY (hipFuncSetAttribute ((const void*) extrema_kernel<MAX, LOCAL, EX_SEGMENTS>,
 			                                   hipFuncAttributeMaxDynamicSharedMemorySize,
 			                                   (int) (EX_LDS_DOUBLES*sizeof(double))));
-		hipLaunchKernelGGL ((extrema_kernel<MAX, LOCAL, false>), dim3(ntiles), dim3(EX_THREADS), bytes, s,
+		hipLaunchKernelGGL ((extrema_kernel<MAX, LOCAL, EX_SEGMENTS>), dim3(ntiles), dim3(EX_THREADS), bytes, s,
 		                    d_in, d_out, n, ntiles, lft, rgt, fill, tile);
 		}
 	GDSP_LAUNCH_CHECK ();
