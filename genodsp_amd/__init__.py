@@ -442,6 +442,14 @@ def scale_intervals(v, start, end, val, divide=False, infinity=DBL_MAX, stream=N
     return v
 
 
+def mask_intervals(v, start, end, val, inside=True, outside_val=0.0, binarize_first=False, stream=None):
+    """mask / or (inside=True) and masknot / and (inside=False); see gdsp_mask_intervals."""
+    b = BinnedIntervals(v.n, start, end, val)
+    call("gdsp_mask_intervals", v.ptr, v.n, *b._args(), int(inside), float(outside_val), int(binarize_first), _sp(stream))
+    sync(stream)
+    return v
+
+
 def report_runs(v, collapse=True, uncovered=0, stream=None):
     """(start, end, value) arrays of the runs report_intervals would print."""
     work = DeviceBuffer(lib().gdsp_report_runs_work(v.n))

@@ -29,7 +29,7 @@
 #define IV_PER     4
 #define IV_TILE    (IV_THREADS * IV_PER)      // 1024 bases; the host bins with the same number
 
-enum { IV_SUM = 0, IV_MIN = 1, IV_MAX = 2, IV_MUL = 3, IV_DIV = 4 };
+enum { IV_SUM = 0, IV_MIN = 1, IV_MAX = 2, IV_MUL = 3, IV_DIV = 4, IV_SET = 5, IV_KEEP = 6 };
 
 template <int OP>
 __global__ __launch_bounds__(IV_THREADS)
@@ -41,10 +41,11 @@ void intervals_kernel (double* __restrict__ v, uint32_t n,
 	{
 	const uint32_t tile  = blockIdx.x;
 	const uint32_t lo    = tileOffsets[tile], hi = tileOffsets[tile+1];
-	const bool     scale = (OP == IV_MUL) || (OP == IV_DIV);
+	const bool     scale = (OP == IV_MUL) || (OP == IV_DIV) || (OP == IV_KEEP);   // ops with a rule for uncovered bases
+	const bool     nonzeroToOne = (OP == IV_SET || OP == IV_KEEP) && (clear & GDSP_MASK_BINARIZE_FIRST);
 	const bool     touch = (clear & GDSP_CLEAR_FIRST_TOUCH) != 0;   // "still missing -> assign"
 	const bool     fill  = (clear & GDSP_CLEAR_FILL) != 0;          // start from the missing value
-	if ((lo == hi) && !fill && !scale) return;           // untouched tile
+	if ((lo == hi) && !fill && !scale && !nonzeroToOne) return;   // untouched tile
 
 	const uint64_t base = (uint64_t) tile * IV_TILE;
 	uint32_t pos[IV_PER];
@@ -56,6 +57,7 @@ void intervals_kernel (double* __restrict__ v, uint32_t n,
 		pos[k]     = (uint32_t) (base + (uint64_t) k*IV_THREADS + threadIdx.x);   // coalesced per k
 		covered[k] = false;
 		x[k]       = fill? missingVal : ((pos[k] < n)? v[pos[k]] : 0.0);
+		if (nonzeroToOne && (x[k] != 0.0)) x[k] = 1.0;                  // logical.c:471-472, :766-767
 		}
 
 	for (uint32_t j=lo ; j<hi ; j++)
@@ -68,7 +70,9 @@ void intervals_kernel (double* __restrict__ v, uint32_t n,
 			{
 			if ((pos[k] >= s) && (pos[k] < e))
 				{
-				if (scale)                                                    // multiply.c:340-341, :735-736
+				if (OP == IV_KEEP) covered[k] = true;                          // mask.c:593-596, logical.c:862-865
+				else if (OP == IV_SET) x[k] = a;                               // mask.c:283-284, logical.c:535-536
+				else if (scale)                                                // multiply.c:340-341, :735-736
 					{ x[k] = (OP == IV_MUL)? x[k] * a : x[k] / a;  covered[k] = true; }
 				else if (touch && (x[k] == missingVal)) x[k] = a;             // genodsp.c:1311,1319,1327
 				else if (OP == IV_SUM) x[k] = x[k] + a;                        // genodsp.c:1328
@@ -83,8 +87,8 @@ void intervals_kernel (double* __restrict__ v, uint32_t n,
 		{
 		if (pos[k] >= n) continue;
 		double r = x[k];
-		if (scale && !covered[k])                         // multiply.c:330-331, divide :711
-			r = (OP == IV_MUL)? 0.0 : ((x[k] >= 0)? infinityVal : -infinityVal);
+		if (scale && !covered[k])                         // multiply.c:330-331, divide :711, masknot/and: the fill value
+			r = (OP == IV_MUL)? 0.0 : ((OP == IV_KEEP)? infinityVal : ((x[k] >= 0)? infinityVal : -infinityVal));
 		v[pos[k]] = r;
 		}
 	}
@@ -128,6 +132,19 @@ int gdsp_scale_intervals (double* d_v, uint32_t n, const uint32_t* d_start, cons
 	{
 	if (divide) return intervals_launch<IV_DIV> (d_v, n, d_start, d_end, d_val, d_tileOffsets, d_tileList, 0, 0.0, infinityVal, stream);
 	return             intervals_launch<IV_MUL> (d_v, n, d_start, d_end, d_val, d_tileOffsets, d_tileList, 0, 0.0, infinityVal, stream);
+	}
+
+/* mask.c:187-300 (mask), :483-640 (masknot), logical.c:439-560 (or), :737-880 (and):
+ *   inside  = 1: bases under an interval become d_val[i] (mask: the mask value; or: 1.0)
+ *   inside  = 0: bases under NO interval become outsideVal (masknot: the mask value; and: 0.0)
+ *   binarizeFirst: every nonzero base becomes 1.0 before anything else (or, and) */
+int gdsp_mask_intervals (double* d_v, uint32_t n, const uint32_t* d_start, const uint32_t* d_end,
+                         const double* d_val, const uint32_t* d_tileOffsets, const uint32_t* d_tileList,
+                         int inside, double outsideVal, int binarizeFirst, void* stream)
+	{
+	const int flags = binarizeFirst? GDSP_MASK_BINARIZE_FIRST : 0;
+	if (inside) return intervals_launch<IV_SET>  (d_v, n, d_start, d_end, d_val, d_tileOffsets, d_tileList, flags, 0.0, 0.0, stream);
+	return             intervals_launch<IV_KEEP> (d_v, n, d_start, d_end, d_val, d_tileOffsets, d_tileList, flags, 0.0, outsideVal, stream);
 	}
 
 // Host helper: bin `count` intervals [start,end) (already clipped to [0,n]) into

@@ -33,8 +33,8 @@
 
 /* ------------------------------------------------------------ operator table */
 /* same names, aliases and order as the reference's dspTable (genodsp.c:117-174);
- * operators outside the hot-path scope (clump, map, mask, or/and, minover...) are
- * not in this build and are reported as such */
+ * operators outside the hot-path scope (clump, map, minover, maxover) are not in
+ * this build and are reported as such */
 dspprototypes(op_window_sum)     dspprototypes(op_sliding_sum)   dspprototypes(op_smooth)
 dspprototypes(op_cumulative_sum) dspprototypes(op_percentile)    dspprototypes(op_add)
 dspprototypes(op_subtract)       dspprototypes(op_add_constant)  dspprototypes(op_invert)
@@ -44,6 +44,8 @@ dspprototypes(op_local_minima)   dspprototypes(op_local_maxima)  dspprototypes(o
 dspprototypes(op_best_local_max) dspprototypes(op_close)         dspprototypes(op_open)
 dspprototypes(op_dilate)         dspprototypes(op_erode)         dspprototypes(op_input)
 dspprototypes(op_output)         dspprototypes(op_show_variables)
+dspprototypes(op_mask)           dspprototypes(op_mask_not)      dspprototypes(op_or)
+dspprototypes(op_and)            dspprototypes(op_min_with)      dspprototypes(op_max_with)
 
 static dspinfo dspTable[] =
 	{dspinforecord("sum"           , op_window_sum)     , dspinfoalias ("window_sum")     ,
@@ -58,15 +60,21 @@ static dspinfo dspTable[] =
 	 dspinforecord("multiply"      , op_multiply)       ,
 	 dspinforecord("divide"        , op_divide)         ,
 	 dspinforecord("abs"           , op_absolute_value) ,
+	 dspinforecord("mask"          , op_mask)           ,
+	 dspinforecord("masknot"       , op_mask_not)       , dspinfoalias ("mask_not")       ,
 	 dspinforecord("clip"          , op_clip)           ,
 	 dspinforecord("erase"         , op_erase)          ,
 	 dspinforecord("binarize"      , op_binarize)       ,
+	 dspinforecord("or"            , op_or)             ,
+	 dspinforecord("and"           , op_and)            ,
 	 dspinforecord("localmin"      , op_local_minima)   , dspinfoalias ("local_min")      ,
 	 dspinforecord("localmax"      , op_local_maxima)   , dspinfoalias ("local_max")      ,
 	 dspinforecord("bestmin"       , op_best_local_min) , dspinfoalias ("best_min")       ,
 	 dspinfoalias ("bestlocalmin")                      , dspinfoalias ("best_local_min") ,
 	 dspinforecord("bestmax"       , op_best_local_max) , dspinfoalias ("best_max")       ,
 	 dspinfoalias ("bestlocalmax")                      , dspinfoalias ("best_local_max") ,
+	 dspinforecord("minwith"       , op_min_with)       , dspinfoalias ("min_with")       ,
+	 dspinforecord("maxwith"       , op_max_with)       , dspinfoalias ("max_with")       ,
 	 dspinforecord("close"         , op_close)          ,
 	 dspinforecord("open"          , op_open)           ,
 	 dspinforecord("dilate"        , op_dilate)         ,
@@ -77,8 +85,7 @@ static dspinfo dspTable[] =
 #define dspTableLen (sizeof(dspTable)/sizeof(dspinfo))
 
 static const char* notInThisBuild[] =
-	{ "clump", "anticlump", "anti_clump", "skimp", "mask", "masknot", "mask_not", "or", "and",
-	  "maxover", "max_over", "minover", "min_over", "minwith", "min_with", "maxwith", "max_with", "map", NULL };
+	{ "clump", "anticlump", "anti_clump", "skimp", "maxover", "max_over", "minover", "min_over", "map", NULL };
 
 /* ------------------------------------------------------------------- globals */
 spec*  chromsOfInterest = NULL;
@@ -619,6 +626,23 @@ void ib_flush_scale (int divide, valtype infinityVal)
 		spec* s = chromsSorted[ci];
 		check_gdsp (gdsp_scale_intervals (s->valVector, s->length, st->d_start, st->d_end, st->d_val, st->d_off, st->d_list,
 		                                  divide, infinityVal, op_stream ()), "scale by intervals");
+		pend[ci].count = 0;
+		}
+	pendTotal = 0;
+	}
+
+/* mask / masknot / or / and: every chromosome is visited (the binarise pass and the
+ * outside-value rule apply to chromosomes the file never mentions too) */
+void ib_flush_mask (int inside, valtype outsideVal, int binarizeFirst)
+	{
+	for (int ci=0 ; ci<numChroms ; ci++)
+		{
+		if ((pend[ci].count == 0) && inside && !binarizeFirst) continue;
+		staging* st;
+		stage_chromosome (ci, &st);
+		spec* s = chromsSorted[ci];
+		check_gdsp (gdsp_mask_intervals (s->valVector, s->length, st->d_start, st->d_end, st->d_val, st->d_off, st->d_list,
+		                                 inside, outsideVal, binarizeFirst, op_stream ()), "mask by intervals");
 		pend[ci].count = 0;
 		}
 	pendTotal = 0;

@@ -13,6 +13,7 @@ void ib_add         (spec* s, u32 start, u32 end, valtype val);
 u64  ib_pending     (void);
 void ib_flush_apply (int overlapOp, int clearFlags, valtype missingVal, int everyChromosome);
 void ib_flush_scale (int divide, valtype infinityVal);
+void ib_flush_mask  (int inside, valtype outsideVal, int binarizeFirst);
 
 void sync_all_devices    (void);
 int  device_count_in_use (void);

@@ -14,7 +14,7 @@
 #include "utilities.h"
 #include "host_services.h"
 
-enum { K_ADD, K_SUBTRACT, K_MULTIPLY, K_DIVIDE };
+enum { K_ADD, K_SUBTRACT, K_MULTIPLY, K_DIVIDE, K_MASK, K_MASKNOT, K_OR, K_AND, K_MINWITH, K_MAXWITH };
 
 typedef struct dspop_fileop
 	{
@@ -23,6 +23,9 @@ typedef struct dspop_fileop
 	char*   filename;
 	int     valColumn, originOne, destroyFile;
 	valtype infinityVal;
+	valtype maskVal;                /* mask, masknot */
+	char*   maskValVarName;
+	int     haveMaskVal;
 	} dspop_fileop;
 
 static dspop* fileop_parse (char* name, int argc, char** argv, int kind)
@@ -36,9 +39,12 @@ static dspop* fileop_parse (char* name, int argc, char** argv, int kind)
 		{
 		char* arg = argv[0];
 		char* argVal = strchr (arg, '=');  if (argVal != NULL) argVal++;
-		if ((strcmp (arg, "--novalue") == 0) || (strcmp (arg, "--novalues") == 0) || (strcmp (arg, "--value=none") == 0))
+		const int isMask = (kind == K_MASK) || (kind == K_MASKNOT);
+		const int isWith = (kind == K_MINWITH) || (kind == K_MAXWITH);
+		if (!isMask && !isWith
+		 && ((strcmp (arg, "--novalue") == 0) || (strcmp (arg, "--novalues") == 0) || (strcmp (arg, "--value=none") == 0)))
 			{ op->valColumn = -1;  continue; }
-		if (strcmp_prefix (arg, "--value=") == 0)
+		if (!isMask && (strcmp_prefix (arg, "--value=") == 0))
 			{
 			int col = string_to_int (argVal) - 1;
 			if (col == -1) chastise ("[%s] value column can't be 0 (\"%s\")\n", name, arg);
@@ -47,9 +53,18 @@ static dspop* fileop_parse (char* name, int argc, char** argv, int kind)
 			op->valColumn = col;
 			continue;
 			}
+		if (isMask && is_opt3 (arg, "mask", "M"))
+			{
+			if ((kind == K_MASK) && op->haveMaskVal)
+				{ fprintf (stderr, "[%s] mask value specified more than once (at \"%s\")\n", name, arg);  exit (EXIT_FAILURE); }
+			if (kind == K_MASK) value_or_variable (argVal, &op->maskVal, &op->maskValVarName);   /* mask.c:104-116 */
+			else                op->maskVal = string_to_valtype (argVal);                          /* mask.c:412-418 */
+			op->haveMaskVal = true;
+			continue;
+			}
 		if ((strcmp (arg, "--origin=one") == 0)  || (strcmp (arg, "--origin=1") == 0)) { op->originOne = true;   continue; }
 		if ((strcmp (arg, "--origin=zero") == 0) || (strcmp (arg, "--origin=0") == 0)) { op->originOne = false;  continue; }
-		if (((kind == K_ADD) || (kind == K_SUBTRACT)) && (strcmp (arg, "--destroy") == 0)) { op->destroyFile = true;  continue; }
+		if (((kind == K_ADD) || (kind == K_SUBTRACT) || isWith) && (strcmp (arg, "--destroy") == 0)) { op->destroyFile = true;  continue; }
 		if ((kind == K_DIVIDE) && (strcmp_prefix (arg, "--infinity=") == 0)) { op->infinityVal = string_to_valtype (argVal);  continue; }
 		if (strcmp (arg, "--debug") == 0) continue;
 		if (strcmp_prefix (arg, "--") == 0) chastise ("[%s] Can't understand \"%s\"\n", name, arg);
@@ -64,10 +79,12 @@ static void fileop_free (dspop* _op)
 	{
 	dspop_fileop* op = (dspop_fileop*) _op;
 	if (op->filename != NULL) free (op->filename);
+	if (op->maskValVarName != NULL) free (op->maskValVarName);
 	free (op);
 	}
 
-/* add.c:191-306, :484-599, multiply.c:193-393, :586-787 */
+/* add.c:191-306, :484-599, multiply.c:193-393, :586-787, mask.c:187-300, :483-640,
+ * logical.c:439-560, :737-880, minmax.c:1893-2010, :2179-2294 */
 static void fileop_apply (dspop* _op)
 	{
 	dspop_fileop* op = (dspop_fileop*) _op;
@@ -76,7 +93,12 @@ static void fileop_apply (dspop* _op)
 	spec*   s = NULL;
 	u32     start, end, o = op->originOne? 1 : 0, prevEnd = 0;
 	valtype val;
-	int     scaling = (op->kind == K_MULTIPLY) || (op->kind == K_DIVIDE);
+	/* "sorted" kinds say what happens to bases under NO interval, so their intervals must be
+	 * sorted, non-overlapping and grouped by chromosome, and every chromosome is visited */
+	int     scaling  = (op->kind == K_MULTIPLY) || (op->kind == K_DIVIDE) || (op->kind == K_MASKNOT) || (op->kind == K_AND);
+	int     skipZero = (op->kind != K_MASK) && (op->kind != K_MASKNOT) && (op->kind != K_MINWITH) && (op->kind != K_MAXWITH);
+	int     valCol   = ((op->kind == K_MASK) || (op->kind == K_MASKNOT))? -1 : op->valColumn;   /* mask.c:237 */
+	resolve_variable (_op, &op->maskValVarName, &op->maskVal, "mask value");
 
 	FILE* f = fopen (op->filename, "rt");
 	if (f == NULL) { fprintf (stderr, "[%s] can't open \"%s\" for reading\n", _op->name, op->filename);  exit (EXIT_FAILURE); }
@@ -84,9 +106,9 @@ static void fileop_apply (dspop* _op)
 
 	ib_begin ();
 	prevChrom[0] = 0;
-	while (read_interval (f, line, sizeof(line), op->valColumn, &chrom, &start, &end, &val))
+	while (read_interval (f, line, sizeof(line), valCol, &chrom, &start, &end, &val))
 		{
-		if (val == 0.0) continue;                          /* add.c:235, multiply.c:236 */
+		if (skipZero && (val == 0.0)) continue;            /* add.c:235, multiply.c:236, logical.c:489 */
 		if (strcmp (chrom, prevChrom) != 0)
 			{
 			s = find_chromosome_spec (chrom);
@@ -134,8 +156,11 @@ static void fileop_apply (dspop* _op)
 				}
 			prevEnd = adjEnd;
 			}
-		ib_add (s, adjStart, adjEnd, (op->kind == K_SUBTRACT)? -val : val);
-		if (!scaling && (ib_pending () >= 8*1024*1024)) ib_flush_apply (ri_overlapSum, 0, 0.0, false);
+		if      (op->kind == K_SUBTRACT) val = -val;
+		else if (op->kind == K_MASK)     val = op->maskVal;
+		else if (op->kind == K_OR)       val = 1.0;
+		ib_add (s, adjStart, adjEnd, val);
+		if ((op->kind <= K_SUBTRACT) && (ib_pending () >= 8*1024*1024)) ib_flush_apply (ri_overlapSum, 0, 0.0, false);
 		}
 	fclose (f);
 
@@ -144,11 +169,17 @@ static void fileop_apply (dspop* _op)
 		if (trackOperations)
 			for (int i=0 ; chromsSorted[i]!=NULL ; i++)
 				{ if (!chromsSorted[i]->flag) fprintf (stderr, "%s(%s,absent)\n", _op->name, chromsSorted[i]->chrom); }
-		ib_flush_scale (op->kind == K_DIVIDE, op->infinityVal);
+		if      (op->kind == K_MASKNOT) ib_flush_mask (false, op->maskVal, false);
+		else if (op->kind == K_AND)     ib_flush_mask (false, 0.0, true);
+		else                            ib_flush_scale (op->kind == K_DIVIDE, op->infinityVal);
 		}
 	else
 		{
-		ib_flush_apply (ri_overlapSum, 0, 0.0, false);
+		if      (op->kind == K_MASK)    ib_flush_mask (true, 0.0, false);
+		else if (op->kind == K_OR)      ib_flush_mask (true, 0.0, true);
+		else if (op->kind == K_MINWITH) ib_flush_apply (ri_overlapMin, 0, 0.0, false);
+		else if (op->kind == K_MAXWITH) ib_flush_apply (ri_overlapMax, 0, 0.0, false);
+		else                            ib_flush_apply (ri_overlapSum, 0, 0.0, false);
 		if (op->destroyFile) remove (op->filename);
 		}
 	}
@@ -159,16 +190,26 @@ static void fileop_usage (char* name, FILE* f, char* indent, int kind)
 		{ "Add the values of the intervals in a file to the signal.",
 		  "Subtract the values of the intervals in a file from the signal.",
 		  "Multiply the signal by the values of the (sorted, non-overlapping) intervals in a\nfile; bases under no interval become zero.",
-		  "Divide the signal by the values of the (sorted, non-overlapping) intervals in a\nfile; bases under no interval become +/- infinity." };
+		  "Divide the signal by the values of the (sorted, non-overlapping) intervals in a\nfile; bases under no interval become +/- infinity.",
+		  "Set the signal to the mask value under the intervals in a file.",
+		  "Set the signal to the mask value everywhere EXCEPT under the (sorted, non-overlapping)\nintervals in a file.",
+		  "Binarise the signal (non-zero -> 1), then OR it with the intervals in a file.",
+		  "Binarise the signal (non-zero -> 1), then AND it with the (sorted, non-overlapping)\nintervals in a file.",
+		  "Replace each base by the minimum of itself and the values of the intervals covering it.",
+		  "Replace each base by the maximum of itself and the values of the intervals covering it." };
 	if (indent == NULL) indent = "";
 	char* text = copy_string (what[kind]);
 	for (char* line = strtok (text, "\n") ; line != NULL ; line = strtok (NULL, "\n")) fprintf (f, "%s%s\n", indent, line);
 	free (text);
 	fprintf (f, "%s\n%susage: %s <filename> [options]\n", indent, indent, name);
-	fprintf (f, "%s  --value=<col>            column of the interval value (default: the global one)\n", indent);
-	fprintf (f, "%s  --novalue                intervals carry no value (each counts 1)\n", indent);
+	if ((kind == K_MASK) || (kind == K_MASKNOT))
+		fprintf (f, "%s  --mask=<value%s>     (M=) the mask value (default 0.0)\n", indent, (kind == K_MASK)? "|variable" : "");
+	else
+		fprintf (f, "%s  --value=<col>            column of the interval value (default: the global one)\n", indent);
+	if ((kind <= K_DIVIDE) || (kind == K_OR) || (kind == K_AND))
+		fprintf (f, "%s  --novalue                intervals carry no value (each counts 1)\n", indent);
 	fprintf (f, "%s  --origin=one|zero        coordinate convention of the file\n", indent);
-	if (kind <= K_SUBTRACT) fprintf (f, "%s  --destroy                delete the file afterwards\n", indent);
+	if ((kind <= K_SUBTRACT) || (kind >= K_MINWITH)) fprintf (f, "%s  --destroy                delete the file afterwards\n", indent);
 	if (kind == K_DIVIDE)   fprintf (f, "%s  --infinity=<value>       value standing for infinity (default: largest double)\n", indent);
 	}
 
@@ -184,6 +225,12 @@ FILEOP_GROUP (op_add,      K_ADD,      "add interval values (read from a file) t
 FILEOP_GROUP (op_subtract, K_SUBTRACT, "subtract interval values (read from a file) from the current set of interval values")
 FILEOP_GROUP (op_multiply, K_MULTIPLY, "multiply the current set of interval values by interval values read from a file")
 FILEOP_GROUP (op_divide,   K_DIVIDE,   "divide the current set of interval values by interval values read from a file")
+FILEOP_GROUP (op_mask,     K_MASK,     "mask the current set of interval values, over intervals read from a file")
+FILEOP_GROUP (op_mask_not, K_MASKNOT,  "mask the current set of interval values, outside of intervals read from a file")
+FILEOP_GROUP (op_or,       K_OR,       "logical-OR the current set of intervals with intervals read from a file")
+FILEOP_GROUP (op_and,      K_AND,      "logical-AND the current set of intervals with intervals read from a file")
+FILEOP_GROUP (op_min_with, K_MINWITH,  "take the minimum of the current values and interval values read from a file")
+FILEOP_GROUP (op_max_with, K_MAXWITH,  "take the maximum of the current values and interval values read from a file")
 
 /* ---------------------------------------------------------------- input ---- */
 typedef struct dspop_input

@@ -181,6 +181,7 @@ uint32_t gdsp_percentile_rank (uint32_t numValues, uint32_t pThousandths);
 #define GDSP_CLEAR_FIRST_TOUCH 1   /* a base still equal to missingVal is assigned (genodsp.c:1311) */
 #define GDSP_CLEAR_FILL        2   /* every base starts from missingVal (genodsp.c:1225-1240)       */
 #define GDSP_CLEAR_BOTH        3   /* what read_intervals(clear=true) does                          */
+#define GDSP_MASK_BINARIZE_FIRST 4 /* internal flag of gdsp_mask_intervals                            */
 uint32_t gdsp_interval_tile (void);
 int gdsp_bin_intervals   (uint32_t n, const uint32_t* h_start, const uint32_t* h_end, uint32_t count,
                           uint32_t* h_tileOffsets, uint32_t* h_tileList, uint64_t* listLen);
@@ -190,6 +191,16 @@ int gdsp_apply_intervals (double* d_v, uint32_t n, const uint32_t* d_start, cons
 int gdsp_scale_intervals (double* d_v, uint32_t n, const uint32_t* d_start, const uint32_t* d_end,
                           const double* d_val, const uint32_t* d_tileOffsets, const uint32_t* d_tileList,
                           int divide, double infinityVal, void* stream);
+
+/* mask / masknot (mask.c:187-300, :483-640) and or / and (logical.c:439-560, :737-880):
+ *   inside=1: bases under an interval become d_val[i]; inside=0: bases under NO interval become
+ *   outsideVal (intervals sorted and non-overlapping, as for multiply);
+ *   binarizeFirst: every nonzero base becomes 1.0 first (or, and).
+ * minwith / maxwith (minmax.c:1893-2010, :2179-2294) are gdsp_apply_intervals with
+ * GDSP_OVERLAP_MIN / GDSP_OVERLAP_MAX and clear=0. */
+int gdsp_mask_intervals (double* d_v, uint32_t n, const uint32_t* d_start, const uint32_t* d_end,
+                         const double* d_val, const uint32_t* d_tileOffsets, const uint32_t* d_tileList,
+                         int inside, double outsideVal, int binarizeFirst, void* stream);
 
 /* ---- genodsp.c report_intervals:1561-1691 --------------------------------------- */
 

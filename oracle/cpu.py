@@ -68,6 +68,7 @@ def _declare(L):
     sig("orc_fill", None, _pd, _u32, _f64)
     sig("orc_apply_intervals", None, _pd, _u32, _pu, _pu, _pd, _u32, _int, _int, _f64)
     sig("orc_scale_intervals", None, _pd, _u32, _pu, _pu, _pd, _u32, _int, _f64)
+    sig("orc_mask_intervals", None, _pd, _u32, _pu, _pu, _pd, _u32, _int, _f64, _int)
     sig("orc_report_runs", _u32, _pd, _u32, _int, _int, _pu, _pu, _pd, _u32)
     sig("orc_synth_coverage", None, _u64, _u32, _u32, _u32, _int, _pd)
 
@@ -242,6 +243,15 @@ def scale_intervals(v, start, end, val, divide=False, infinity=DBL_MAX):
     e, pe = _u(end)
     x, px = _in(val)
     lib().orc_scale_intervals(pv, v.size, ps, pe, px, s.size, int(divide), infinity)
+    return v
+
+
+def mask_intervals(v, start, end, val, inside=True, outside_val=0.0, binarize_first=False):
+    v, pv = _copy(v)
+    s, ps = _u(start)
+    e, pe = _u(end)
+    x, px = _in(val)
+    lib().orc_mask_intervals(pv, v.size, ps, pe, px, s.size, int(inside), outside_val, int(binarize_first))
     return v
 
 

@@ -456,6 +456,32 @@ void orc_scale_intervals (double* v, uint32_t n, const uint32_t* start, const ui
 		}
 	}
 
+/* mask.c:283-284 (mask) and logical.c:471-472,:535-536 (or): optional "nonzero -> 1.0" pass,
+ * then every base under an interval is assigned that interval's value, in file order.
+ * mask.c:593-611 (masknot) and logical.c:766-767,:862-880 (and): optional "nonzero -> 1.0"
+ * pass, then every base under NO interval (sorted, non-overlapping) gets outsideVal. */
+void orc_mask_intervals (double* v, uint32_t n, const uint32_t* start, const uint32_t* end,
+                         const double* val, uint32_t count, int inside, double outsideVal, int binarizeFirst)
+	{
+	uint32_t i, ix, prevEnd = 0, e;
+	if (binarizeFirst) for (ix=0 ; ix<n ; ix++) { if (v[ix] != 0.0) v[ix] = 1.0; }
+	if (inside)
+		{
+		for (i=0 ; i<count ; i++)
+			{
+			e = (end[i] > n)? n : end[i];
+			for (ix=start[i] ; ix<e ; ix++) v[ix] = val[i];
+			}
+		return;
+		}
+	for (i=0 ; i<count ; i++)
+		{
+		for (ix=prevEnd ; ix<start[i] ; ix++) v[ix] = outsideVal;
+		prevEnd = (end[i] > n)? n : end[i];
+		}
+	for (ix=prevEnd ; ix<n ; ix++) v[ix] = outsideVal;
+	}
+
 /* genodsp.c:1587-1678: run-length encoding of one
  * chromosome as report_intervals emits it.  Exact zeros end a run and are not
  * reported unless uncovered==show; equal neighbours collapse when asked to. */

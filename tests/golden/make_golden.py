@@ -160,12 +160,21 @@ vector_case("percentile_window", chroms3, "= percentile 75 --window=7 --max=30 -
 vector_case("percentile_0_100", chroms3, "= percentile 0,100 --quiet", sig3r, ["percentile0", "percentile100"])
 
 # ---- ingest + report through text (genodsp.c:1187-1350, :1561-1691), reference CLI
-def cli_case(name, chrom_text, args, stdin_text):
+def cli_case(name, chrom_text, args, stdin_text, files=None):
+    """files: {placeholder: text}; an argument "@placeholder@" stands for the path of that file."""
     chrom_path = "/tmp/golden_%s.chroms" % name
     with open(chrom_path, "w") as f:
         f.write(chrom_text)
-    rc, out, err = ref.run_cli(["--chromosomes=" + chrom_path] + args, stdin_text)
-    cases.append({"name": name, "kind": "cli", "chroms_text": chrom_text, "args": args,
+    real_args = []
+    for a in args:
+        for key, text in (files or {}).items():
+            path = "/tmp/golden_%s_%s" % (name, key)
+            with open(path, "w") as f:
+                f.write(text)
+            a = a.replace("@%s@" % key, path)
+        real_args.append(a)
+    rc, out, err = ref.run_cli(["--chromosomes=" + chrom_path] + real_args, stdin_text)
+    cases.append({"name": name, "kind": "cli", "chroms_text": chrom_text, "args": args, "files": files or {},
                   "stdin": stdin_text, "returncode": rc, "stdout": out, "stderr": err})
 
 
@@ -212,6 +221,27 @@ def valued_intervals(n, seed, count):
 
 
 cli_case("cli_valued_overlaps", "chrV 5000\n", ["--precision=12", "--nocollapse"], valued_intervals(5000, 2, 800))
+
+# interval-file operators (add.c, multiply.c, mask.c, logical.c, minmax.c, opio.c)
+GENOME3 = "chrA 300\nchrB 120\nchrC 40\n"
+SIGNAL3 = "".join("chrA %d %d %s\n" % (s, e, v) for s, e, v in
+                  [(5, 60, "2.5"), (40, 90, "1.25"), (100, 101, "7"), (150, 260, "0.5"), (255, 300, "3")]) + \
+          "chrB 0 50 4\nchrB 60 61 -2\nchrB 100 120 1.5\n"
+SORTED_IV = "chrA 10 50 2\nchrA 50 55 0\nchrA 80 120 0.5\nchrA 250 300 4\nchrB 30 70 3\n"
+LOOSE_IV = "chrB 10 30 1.5\nchrA 20 200 0.75\nchrA 0 30 6\nchrC 5 6 9\nchrA 190 290 0\n"
+for op, ivs, extra in (("add", LOOSE_IV, []), ("subtract", LOOSE_IV, []), ("multiply", SORTED_IV, []),
+                       ("divide", SORTED_IV, []), ("divide", SORTED_IV, ["--infinity=1000"]),
+                       ("mask", LOOSE_IV, ["--mask=-1"]), ("mask", LOOSE_IV, []), ("masknot", SORTED_IV, ["--mask=9"]),
+                       ("or", LOOSE_IV, []), ("and", SORTED_IV, []), ("minwith", LOOSE_IV, []),
+                       ("maxwith", LOOSE_IV, []), ("or", LOOSE_IV, ["--novalue"])):
+    tag = "cli_file_%s%s" % (op, "".join(e.strip("-").replace("=", "") for e in extra))
+    cli_case(tag, GENOME3, ["--precision=4", "--uncovered:show", "=", op, "@iv@"] + extra, SIGNAL3, {"iv": ivs})
+cli_case("cli_file_input_output", GENOME3,
+         ["--precision=3", "=", "output", "@mid@", "=", "addconst", "1", "=", "input", "@iv@", "--missing=2", "--overlap=max"],
+         SIGNAL3, {"iv": LOOSE_IV, "mid": ""})
+cli_case("cli_file_mask_variable", GENOME3,
+         ["--precision=3", "=", "percentile", "50", "--quiet", "=", "input", "@sig@", "=", "mask", "@iv@", "--mask=percentile50"],
+         SIGNAL3, {"iv": SORTED_IV, "sig": SIGNAL3})
 
 np.savez_compressed(os.path.join(HERE, "golden.npz"), **arrays)
 with open(os.path.join(HERE, "golden.json"), "w") as f:

@@ -17,7 +17,17 @@ BIN = os.path.join(ROOT, "genodsp_amd", "genodsp_hip")
 CLI_CASES = golden().cli_cases()
 
 
-def run(args, stdin_text="", chroms_text=None, tmp_path=None):
+def run(args, stdin_text="", chroms_text=None, tmp_path=None, files=None):
+    if files:
+        real = []
+        for a in args:
+            for key, text in files.items():
+                path = os.path.join(str(tmp_path), key + ".dat")
+                with open(path, "w") as f:
+                    f.write(text)
+                a = a.replace("@%s@" % key, path)
+            real.append(a)
+        args = real
     if chroms_text is not None:
         path = os.path.join(str(tmp_path), "genome.chroms")
         with open(path, "w") as f:
@@ -37,9 +47,9 @@ def built():
 def test_cli_stdout_matches_reference(case, tmp_path):
     if case["returncode"] != 0:
         pytest.skip("reference itself failed on this input")
-    rc, out, err = run(case["args"], case["stdin"], case["chroms_text"], tmp_path)
+    rc, out, err = run(case["args"], case["stdin"], case["chroms_text"], tmp_path, case.get("files"))
     assert rc == 0, err
-    if "percentile" in case["args"]:
+    if "percentile" in case["args"] and "input" not in case["args"]:
         # the reference prints its sort-scrambled signal after percentile (percentile.c:34-36);
         # here the signal is untouched, i.e. the output of the same pipeline without the operator
         assert out == golden().cases["cli_coverage"]["stdout"]

@@ -440,3 +440,29 @@ def test_fused_dilate_erode_binarize_is_the_three_operators(n, L, gd):
     want = cpu.erode(cpu.dilate(x, dl, dr, 0.0, -5.0, 1.0), dl, dr)          # dilate's "one" is below erode's threshold
     got = gd.dilate_erode(d, dl, dr, dl, dr, d_one=-5.0, d_zero=1.0).numpy()
     assert bits_equal(got, want)
+
+
+@pytest.mark.parametrize("n", [1, 1024, 3000, 100001])
+def test_mask_or_and_intervals_bit_exact(n, gd):
+    rng = np.random.default_rng(n + 5)
+    base = rng.standard_normal(n)
+    base[::3] = 0.0
+    if n > 4:
+        base[4] = -0.0
+    # loose (overlapping, unsorted) intervals: mask / or
+    s, e, val = _random_intervals(n, 20 + n // 50, rng, max_len=90, integer=False)
+    for binarize_first in (False, True):
+        got = gd.mask_intervals(gd.DeviceVector.from_numpy(base), s, e, val, True, 0.0, binarize_first).numpy()
+        assert bits_equal(got, cpu.mask_intervals(base, s, e, val, True, 0.0, binarize_first)), binarize_first
+    # sorted, non-overlapping intervals: masknot / and
+    cuts = np.unique(rng.integers(0, n + 1, 40))
+    s2, e2 = cuts[:-1:2].astype(np.uint32), cuts[1::2].astype(np.uint32)
+    k = min(s2.size, e2.size)
+    s2, e2 = s2[:k], e2[:k]
+    for outside, binarize_first in ((9.5, False), (0.0, True)):
+        got = gd.mask_intervals(gd.DeviceVector.from_numpy(base), s2, e2, np.ones(k), False, outside, binarize_first).numpy()
+        assert bits_equal(got, cpu.mask_intervals(base, s2, e2, np.ones(k), False, outside, binarize_first))
+    # minwith / maxwith are the ingest kernel without clearing
+    for op in (cpu.OVERLAP_MIN, cpu.OVERLAP_MAX):
+        got = gd.apply_intervals(gd.DeviceVector.from_numpy(base), s, e, val, op).numpy()
+        assert bits_equal(got, cpu.apply_intervals(base, s, e, val, op))
