@@ -303,6 +303,15 @@ def invert(v, mid, stream=None):
     return v
 
 
+def map_values(v, knots_in, knots_out, stream=None):
+    """op_map_apply: piecewise-linear mapping through knots sorted by knots_in."""
+    a = _dev_array(knots_in, np.float64)
+    b = _dev_array(knots_out, np.float64)
+    call("gdsp_map", v.ptr, v.n, C.c_void_p(a.ptr), C.c_void_p(b.ptr), len(knots_in), _sp(stream))
+    sync(stream)
+    return v
+
+
 def fill(v, val, stream=None):
     call("gdsp_fill", v.ptr, v.n, float(val), _sp(stream))
     return v

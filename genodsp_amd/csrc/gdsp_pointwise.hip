@@ -147,7 +147,89 @@ void minmax_kernel (const double* __restrict__ v, uint32_t n, uint32_t window, d
 		}
 	}
 
+// ------------------------------------------------------------------- map ----
+// op_map_apply, map.c:194-381: piecewise-linear mapping through a table of (in, out) knots
+// sorted by `in`.  Values at or below the first knot / at or above the last take that knot's
+// output; in between, the piece is found by the reference's binary search (map.c:300-315,
+// including its skip over repeated knots) and the value is out_lo + (v - in_lo) * out_diff /
+// in_diff with the reference's operation order, each operation rounded on its own.  The
+// reference also remembers the last piece between bases; for strictly increasing knots that
+// shortcut picks the same piece as the search, so the result is bit-identical.  The table
+// sits in LDS (up to MAP_LDS_KNOTS knots) or is searched in global memory.
+#define MAP_LDS_KNOTS 2048
+template <bool IN_LDS>
+__global__ __launch_bounds__(PW_THREADS)
+void map_kernel (double* __restrict__ v, uint32_t n, uint32_t ntiles,
+                 const double* __restrict__ knotIn, const double* __restrict__ knotOut, uint32_t nknots)
+	{
+	__shared__ double ldsIn[IN_LDS? MAP_LDS_KNOTS : 1], ldsOut[IN_LDS? MAP_LDS_KNOTS : 1];
+	const double* tin  = knotIn;
+	const double* tout = knotOut;
+	if (IN_LDS)
+		{
+		for (uint32_t k=threadIdx.x ; k<nknots ; k+=PW_THREADS) { ldsIn[k] = knotIn[k];  ldsOut[k] = knotOut[k]; }
+		__syncthreads ();
+		tin = ldsIn;  tout = ldsOut;
+		}
+	const uint32_t maxIx = nknots - 1;
+	const double   minIn = tin[0], maxIn = tin[maxIx], outForMin = tout[0], outForMax = tout[maxIx];
+
+	auto mapOne = [&] (double x) -> double
+		{
+		if (x <= minIn) return outForMin;
+		if (x >= maxIn) return outForMax;
+		if (x != x)     return x;                       // NaN: the reference's search would not terminate meaningfully
+		uint32_t lo = 0, hi = maxIx;
+		while (lo + 1 < hi)
+			{
+			const uint32_t mid = (lo + hi) / 2;
+			const double   m   = tin[mid];
+			if      (x < m) hi = mid;
+			else if (x > m) lo = mid;
+			else          { lo = mid;  break; }
+			}
+		while ((lo < maxIx) && (tin[lo] == tin[lo+1])) lo++;
+		const double pieceLo = tin[lo], pieceHi = tin[lo+1], outLo = tout[lo], outHi = tout[lo+1];
+		if (x == pieceLo) return outLo;
+		if (x == pieceHi) return outHi;
+		return outLo + (x - pieceLo) * (outHi - outLo) / (pieceHi - pieceLo);
+		};
+
+	const uint32_t tile = gdsp_xcd_tile (blockIdx.x, ntiles);
+	const size_t   base = (size_t) tile * PW_TILE;
+	if (base + PW_TILE <= (size_t) n)
+		{
+		double2* p = reinterpret_cast<double2*> (v + base) + threadIdx.x;
+		double2  d[PW_UNROLL];
+#pragma unroll
+		for (int u=0 ; u<PW_UNROLL ; u++) d[u] = p[u*PW_THREADS];
+#pragma unroll
+		for (int u=0 ; u<PW_UNROLL ; u++) { d[u].x = mapOne (d[u].x);  d[u].y = mapOne (d[u].y); }
+#pragma unroll
+		for (int u=0 ; u<PW_UNROLL ; u++) p[u*PW_THREADS] = d[u];
+		}
+	else
+		{
+		for (size_t i = base + threadIdx.x ; i < (size_t) n ; i += PW_THREADS) v[i] = mapOne (v[i]);
+		}
+	}
+
 extern "C" {
+
+int gdsp_map (double* d_v, uint32_t n, const double* d_knotIn, const double* d_knotOut, uint32_t nknots, void* stream)
+	{
+	GDSP_REQUIRE (nknots >= 1, "the mapping needs at least one knot");
+	if (n == 0) return GDSP_OK;
+	GDSP_REQUIRE ((d_v != NULL) && (d_knotIn != NULL) && (d_knotOut != NULL), "NULL pointer");
+	GDSP_REQUIRE (gdsp_aligned16 (d_v), "vector must be 16-byte aligned");
+	const uint32_t ntiles = (uint32_t) (((uint64_t) n + PW_TILE - 1) / PW_TILE);
+	if (nknots <= MAP_LDS_KNOTS)
+		hipLaunchKernelGGL ((map_kernel<true>),  dim3(ntiles), dim3(PW_THREADS), 0, gdsp_stream (stream), d_v, n, ntiles, d_knotIn, d_knotOut, nknots);
+	else
+		hipLaunchKernelGGL ((map_kernel<false>), dim3(ntiles), dim3(PW_THREADS), 0, gdsp_stream (stream), d_v, n, ntiles, d_knotIn, d_knotOut, nknots);
+	GDSP_LAUNCH_CHECK ();
+	return GDSP_OK;
+	}
 
 int gdsp_binarize (double* d_v, uint32_t n, double T, int tiesAbove, double one, double zero, void* stream)
 	{

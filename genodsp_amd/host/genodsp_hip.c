@@ -33,7 +33,7 @@
 
 /* ------------------------------------------------------------ operator table */
 /* same names, aliases and order as the reference's dspTable (genodsp.c:117-174);
- * operators outside the hot-path scope (clump, map, minover, maxover) are not in
+ * operators outside the hot-path scope (clump, minover, maxover) are not in
  * this build and are reported as such */
 dspprototypes(op_window_sum)     dspprototypes(op_sliding_sum)   dspprototypes(op_smooth)
 dspprototypes(op_cumulative_sum) dspprototypes(op_percentile)    dspprototypes(op_add)
@@ -46,6 +46,7 @@ dspprototypes(op_dilate)         dspprototypes(op_erode)         dspprototypes(o
 dspprototypes(op_output)         dspprototypes(op_show_variables)
 dspprototypes(op_mask)           dspprototypes(op_mask_not)      dspprototypes(op_or)
 dspprototypes(op_and)            dspprototypes(op_min_with)      dspprototypes(op_max_with)
+dspprototypes(op_map)
 
 static dspinfo dspTable[] =
 	{dspinforecord("sum"           , op_window_sum)     , dspinfoalias ("window_sum")     ,
@@ -79,13 +80,14 @@ static dspinfo dspTable[] =
 	 dspinforecord("open"          , op_open)           ,
 	 dspinforecord("dilate"        , op_dilate)         ,
 	 dspinforecord("erode"         , op_erode)          ,
+	 dspinforecord("map"           , op_map)            ,
 	 dspinforecord("input"         , op_input)          ,
 	 dspinforecord("output"        , op_output)         ,
 	 dspinforecord("variables"     , op_show_variables) };
 #define dspTableLen (sizeof(dspTable)/sizeof(dspinfo))
 
 static const char* notInThisBuild[] =
-	{ "clump", "anticlump", "anti_clump", "skimp", "maxover", "max_over", "minover", "min_over", "map", NULL };
+	{ "clump", "anticlump", "anti_clump", "skimp", "maxover", "max_over", "minover", "min_over", NULL };
 
 /* ------------------------------------------------------------------- globals */
 spec*  chromsOfInterest = NULL;

@@ -133,6 +133,10 @@ int gdsp_erase        (double* d_v, uint32_t n, int haveMin, double minVal, int 
 int gdsp_add_constant (double* d_v, uint32_t n, double c, void* stream);   /* add.c:726-741   */
 int gdsp_abs          (double* d_v, uint32_t n, void* stream);             /* add.c:1038-1049 */
 int gdsp_invert       (double* d_v, uint32_t n, double mid, void* stream); /* add.c:927-937   */
+/* op_map_apply (map.c:194-381): piecewise-linear mapping through nknots (in,out) knots sorted by
+ * `in` (device arrays).  Bit-identical to the reference for strictly increasing knots. */
+int gdsp_map          (double* d_v, uint32_t n, const double* d_knotIn, const double* d_knotOut,
+                       uint32_t nknots, void* stream);
 /* add.c:909-923 / percentile.c:434-530: d_minmax[0]=min(d_minmax[0], min over sample),
  * d_minmax[1]=max(...), d_minmax[2]+=count (as double); sample = every window-th value
  * with lo <= v <= hi.  Initialise with gdsp_minmax_init. */

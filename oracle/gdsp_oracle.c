@@ -332,6 +332,34 @@ void orc_abs (double* v, uint32_t n)
 	for (ix=0 ; ix<n ; ix++) { if (v[ix] < 0) v[ix] = -v[ix]; }
 	}
 
+/* map.c:194-381, with the piece found by the reference's binary search (:300-315) for every
+ * base; the reference's "same piece as last time" shortcut picks the same piece when the
+ * knots are strictly increasing.  knots sorted by `in` (the reference qsorts them, :452). */
+void orc_map (double* v, uint32_t n, const double* kin, const double* kout, uint32_t nknots)
+	{
+	uint32_t maxIx = nknots - 1, ix, lo, hi, mid;
+	double   x;
+	for (ix=0 ; ix<n ; ix++)
+		{
+		x = v[ix];
+		if (x <= kin[0])     { v[ix] = kout[0];      continue; }
+		if (x >= kin[maxIx]) { v[ix] = kout[maxIx];  continue; }
+		if (x != x) continue;
+		lo = 0;  hi = maxIx;
+		while (lo + 1 < hi)
+			{
+			mid = (lo + hi) / 2;
+			if      (x < kin[mid]) hi = mid;
+			else if (x > kin[mid]) lo = mid;
+			else                 { lo = mid;  break; }
+			}
+		while ((lo < maxIx) && (kin[lo] == kin[lo+1])) lo++;
+		if      (x == kin[lo])   v[ix] = kout[lo];
+		else if (x == kin[lo+1]) v[ix] = kout[lo+1];
+		else v[ix] = kout[lo] + (x - kin[lo]) * (kout[lo+1] - kout[lo]) / (kin[lo+1] - kin[lo]);
+		}
+	}
+
 /* add.c:909-923: genome-wide min and max, seeded with the first element of
  * the first (longest) chromosome */
 void orc_genome_minmax (const double* const* vecs, const uint32_t* lens, int nchrom, double* minOut, double* maxOut)

@@ -34,6 +34,7 @@ class OracleBackend:
     abs_ = staticmethod(cpu.abs_)
     invert = staticmethod(cpu.invert)
     genome_minmax = staticmethod(cpu.genome_minmax)
+    map_values = staticmethod(cpu.map_values)
 
     def percentile(self, vecs, pts, window, lo, hi):
         return cpu.percentile(vecs, pts, window, lo, hi)
@@ -104,6 +105,9 @@ class GpuBackend:
 
     def invert(self, x, mid):
         return self.gd.invert(x, mid)
+
+    def map_values(self, x, kin, kout):
+        return self.gd.map_values(x, kin, kout)
 
     def genome_minmax(self, vecs):
         lo, hi, _ = self.gd.genome_minmax(vecs)

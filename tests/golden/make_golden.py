@@ -46,13 +46,20 @@ def signal(kind, n, chrom_index=0):
     raise ValueError(kind)
 
 
-def vector_case(name, chroms, pipeline, inputs, want_globals=()):
-    """chroms: [(name, length)], inputs: {chrom: vector}."""
+def vector_case(name, chroms, pipeline, inputs, want_globals=(), files=None):
+    """chroms: [(name, length)], inputs: {chrom: vector}; files: {placeholder: text}, "@placeholder@"
+    in the pipeline stands for that file's path."""
     g = ref.Genome(chroms)
     for c, v in inputs.items():
         g.set(c, v)
-    g.run(pipeline)
-    rec = {"name": name, "kind": "vector", "chroms": chroms, "pipeline": pipeline, "globals": {}}
+    real = pipeline
+    for key, text in (files or {}).items():
+        path = "/tmp/golden_%s_%s" % (name, key)
+        with open(path, "w") as f:
+            f.write(text)
+        real = real.replace("@%s@" % key, path)
+    g.run(real)
+    rec = {"name": name, "kind": "vector", "chroms": chroms, "pipeline": pipeline, "globals": {}, "files": files or {}}
     for c, _ in chroms:
         arrays["%s/in/%s" % (name, c)] = np.asarray(inputs[c], np.float64)
         arrays["%s/out/%s" % (name, c)] = g.get(c)
@@ -144,6 +151,12 @@ one("abs", "noise", 999, "= abs")
 vector_case("invert_genome", [("c1", 500), ("c2", 800), ("c3", 300)], "= invert",
             {"c1": signal("noise", 500), "c2": signal("noise", 800), "c3": signal("noise", 300)})
 vector_case("invert_mid", [("c1", 500)], "= invert 2.5", {"c1": signal("noise", 500)})
+
+# ---- map (map.c): strictly increasing knots, given out of order (the reference sorts them)
+MAPFILE = "# in out\n10 100\n0 0\n2.5 -4\n\n40 41.5\n25 3e2\n61 7\n"
+for kind in ("depth", "real", "noise"):
+    vector_case("map_" + kind, [("chrA", 1500)], "= map @m@", {"chrA": signal(kind, 1500)}, files={"m": MAPFILE})
+vector_case("map_single_knot", [("chrA", 300)], "= map @m@", {"chrA": signal("noise", 300)}, files={"m": "3 9\n"})
 
 # ---- percentile: named globals; --preserve is not needed because outputs are not compared
 chroms3 = [("c1", 2000), ("c2", 3500), ("c3", 1200)]

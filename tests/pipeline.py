@@ -70,7 +70,8 @@ def _window_arg(args, default, odd=False, name="--window"):
 class Runner:
     """Runs ops on `backend` over a genome {name: vector}; processing order as the reference."""
 
-    def __init__(self, backend, chroms, vectors):
+    def __init__(self, backend, chroms, vectors, files=None):
+        self.files = files or {}
         self.b = backend
         self.chroms = list(chroms)                      # [(name, length)] in file order
         self.v = {c: backend.load(vectors[c]) for c, _ in chroms}
@@ -255,6 +256,20 @@ class Runner:
             lo, hi = self.b.genome_minmax([self.v[c] for c in self.sorted])
             mid = (lo + hi) / 2.0                       # add.c:925
         self._each(lambda x: self.b.invert(x, mid))
+
+    # ---- map.c
+    def op_map(self, args):
+        text = self.files[args[0].strip("@")]
+        pairs = []
+        for line in text.splitlines():
+            line = line.strip()
+            if line and not line.startswith("#"):
+                a, b = line.split()[:2]
+                pairs.append((to_value(a), to_value(b)))
+        pairs.sort(key=lambda p: p[0])                  # the reference qsorts by the input value (map.c:452)
+        kin = np.array([p[0] for p in pairs])
+        kout = np.array([p[1] for p in pairs])
+        self._each(lambda x: self.b.map_values(x, kin, kout))
 
     # ---- percentile.c
     def op_percentile(self, args):

@@ -36,7 +36,7 @@ def _tolerant(name):
 @pytest.mark.parametrize("case", VECTOR_CASES, ids=[c["name"] for c in VECTOR_CASES])
 def test_hip_matches_reference_golden_vectors(case, gold, gd):
     chroms = [tuple(c) for c in case["chroms"]]
-    r = Runner(GpuBackend(), chroms, gold.inputs(case)).run(case["pipeline"])
+    r = Runner(GpuBackend(), chroms, gold.inputs(case), case.get("files")).run(case["pipeline"])
     if "percentile" in case["pipeline"]:
         # non-destructive here (the reference scrambles the signal): inputs must be intact
         for c, _ in chroms:
@@ -466,3 +466,17 @@ def test_mask_or_and_intervals_bit_exact(n, gd):
     for op in (cpu.OVERLAP_MIN, cpu.OVERLAP_MAX):
         got = gd.apply_intervals(gd.DeviceVector.from_numpy(base), s, e, val, op).numpy()
         assert bits_equal(got, cpu.apply_intervals(base, s, e, val, op))
+
+
+@pytest.mark.parametrize("n", [1, 4095, 4096, 4097, 200003])
+@pytest.mark.parametrize("nknots", [1, 2, 7, 2048, 2049, 10000])
+def test_map_values_bit_exact(n, nknots, gd):
+    rng = np.random.default_rng(n + nknots)
+    x = rng.standard_normal(n) * 30
+    kin = np.sort(rng.standard_normal(nknots) * 25)
+    kin = np.unique(kin)
+    kout = rng.standard_normal(kin.size) * 10
+    if n > 3 and kin.size > 1:
+        x[0], x[1], x[2] = kin[0], kin[-1], kin[kin.size // 2]        # exactly on knots
+    got = gd.map_values(gd.DeviceVector.from_numpy(x), kin, kout).numpy()
+    assert bits_equal(got, cpu.map_values(x, kin, kout))

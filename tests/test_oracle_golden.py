@@ -14,7 +14,7 @@ CASES = golden().vector_cases()
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
 def test_oracle_matches_reference_vectors(case, gold):
     chroms = [tuple(c) for c in case["chroms"]]
-    r = Runner(OracleBackend(), chroms, gold.inputs(case)).run(case["pipeline"])
+    r = Runner(OracleBackend(), chroms, gold.inputs(case), case.get("files")).run(case["pipeline"])
     if "percentile" not in case["pipeline"]:           # the reference leaves the signal scrambled
         want = gold.outputs(case)
         for c, _ in chroms:
