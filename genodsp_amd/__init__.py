@@ -459,6 +459,17 @@ def mask_intervals(v, start, end, val, inside=True, outside_val=0.0, binarize_fi
     return v
 
 
+def extreme_in_intervals(v, start, end, want_max, fill, stream=None):
+    """minover / maxover over sorted, non-overlapping intervals."""
+    b = BinnedIntervals(v.n, start, end, np.ones(len(start)))
+    count = len(start)
+    work = DeviceBuffer(lib().gdsp_extreme_in_intervals_work(count))
+    call("gdsp_extreme_in_intervals", v.ptr, v.n, C.c_void_p(b.d_start.ptr), C.c_void_p(b.d_end.ptr), count,
+         C.c_void_p(b.d_offsets.ptr), C.c_void_p(b.d_list.ptr), int(want_max), float(fill), C.c_void_p(work.ptr), _sp(stream))
+    sync(stream)
+    return v
+
+
 def report_runs(v, collapse=True, uncovered=0, stream=None):
     """(start, end, value) arrays of the runs report_intervals would print."""
     work = DeviceBuffer(lib().gdsp_report_runs_work(v.n))

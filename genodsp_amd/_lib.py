@@ -88,6 +88,8 @@ SIGNATURES = {
     "gdsp_apply_intervals": (_int, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _int, _int, _f64, _vp]),
     "gdsp_scale_intervals": (_int, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _int, _f64, _vp]),
     "gdsp_mask_intervals": (_int, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _int, _f64, _int, _vp]),
+    "gdsp_extreme_in_intervals_work": (_sz, [_u32]),
+    "gdsp_extreme_in_intervals": (_int, [_vp, _u32, _vp, _vp, _u32, _vp, _vp, _int, _f64, _vp, _vp]),
     "gdsp_report_runs_work": (_sz, [_u32]),
     "gdsp_report_runs": (_int, [_vp, _u32, _int, _int, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
     "gdsp_synth_coverage": (_int, [_vp, _u64, _u32, _u32, _u32, _int, _vp]),

@@ -134,6 +134,141 @@ int gdsp_scale_intervals (double* d_v, uint32_t n, const uint32_t* d_start, cons
 	return             intervals_launch<IV_MUL> (d_v, n, d_start, d_end, d_val, d_tileOffsets, d_tileList, 0, 0.0, infinityVal, stream);
 	}
 
+} // extern "C"
+
+// ------------------------------------------------------- minover / maxover ----
+// op_min_in_interval_apply minmax.c:193-390, op_max_in_interval_apply :596-793: inside every
+// (sorted, non-overlapping) interval only the extreme value survives, at the position nearest
+// the interval's centre among the tied ones (largest inset = min(ix-start, end-ix), then the
+// lowest ix); everything else, inside or outside intervals, becomes the fill value.
+// Three tile passes sharing the ingest kernel's tile lists:
+//   phase 0: per interval, atomic min/max of the order-preserving key of the values;
+//   phase 1: among bases equal to that extreme, atomic max of (inset << 32 | ~ix);
+//   phase 2: rewrite the tile: the winner keeps its value, the rest is filled.
+template <bool MAX, int PHASE>
+__global__ __launch_bounds__(IV_THREADS)
+void over_kernel (double* __restrict__ v, uint32_t n,
+                  const uint32_t* __restrict__ start, const uint32_t* __restrict__ end,
+                  const uint32_t* __restrict__ tileOffsets, const uint32_t* __restrict__ tileList,
+                  unsigned long long* __restrict__ bestKey, unsigned long long* __restrict__ bestPos, double fill)
+	{
+	const uint32_t tile = blockIdx.x;
+	const uint32_t lo   = tileOffsets[tile], hi = tileOffsets[tile+1];
+	if ((PHASE < 2) && (lo == hi)) return;
+
+	const uint64_t base = (uint64_t) tile * IV_TILE;
+	uint32_t pos[IV_PER];
+	double   x[IV_PER];
+	bool     keep[IV_PER];
+#pragma unroll
+	for (int k=0 ; k<IV_PER ; k++)
+		{
+		pos[k]  = (uint32_t) (base + (uint64_t) k*IV_THREADS + threadIdx.x);
+		x[k]    = (pos[k] < n)? v[pos[k]] : 0.0;
+		keep[k] = false;
+		}
+
+	for (uint32_t j=lo ; j<hi ; j++)
+		{
+		const uint32_t i = tileList[j];
+		const uint32_t s = start[i], e = (end[i] < n)? end[i] : n;
+		if (PHASE == 0)
+			{
+			unsigned long long best = MAX? 0ULL : ~0ULL;
+			bool any = false;
+#pragma unroll
+			for (int k=0 ; k<IV_PER ; k++)
+				{
+				if ((pos[k] >= s) && (pos[k] < e))
+					{
+					const unsigned long long key = gdsp_key_of (x[k]);
+					if (MAX? (key > best) : (key < best)) best = key;
+					any = true;
+					}
+				}
+			for (int off=32 ; off>0 ; off>>=1)
+				{
+				const unsigned long long o = __shfl_down (best, off, 64);
+				if (MAX? (o > best) : (o < best)) best = o;
+				}
+			if (__any (any) && ((threadIdx.x & 63) == 0))
+				{ if (MAX) atomicMax (&bestKey[i], best);  else atomicMin (&bestKey[i], best); }
+			}
+		else if (PHASE == 1)
+			{
+			const unsigned long long target = bestKey[i];
+			unsigned long long best = 0;
+#pragma unroll
+			for (int k=0 ; k<IV_PER ; k++)
+				{
+				if ((pos[k] >= s) && (pos[k] < e) && (gdsp_key_of (x[k]) == target))
+					{
+					const uint32_t a = pos[k] - s, b = e - pos[k];
+					const unsigned long long packed = ((unsigned long long) ((a < b)? a : b) << 32) | (0xFFFFFFFFu - pos[k]);
+					if (packed > best) best = packed;
+					}
+				}
+			for (int off=32 ; off>0 ; off>>=1)
+				{
+				const unsigned long long o = __shfl_down (best, off, 64);
+				if (o > best) best = o;
+				}
+			if ((best != 0) && ((threadIdx.x & 63) == 0)) atomicMax (&bestPos[i], best);
+			}
+		else
+			{
+			const uint32_t winner = 0xFFFFFFFFu - (uint32_t) (bestPos[i] & 0xFFFFFFFFu);
+#pragma unroll
+			for (int k=0 ; k<IV_PER ; k++) { if ((pos[k] >= s) && (pos[k] < e) && (pos[k] == winner)) keep[k] = true; }
+			}
+		}
+	if (PHASE == 2)
+		{
+#pragma unroll
+		for (int k=0 ; k<IV_PER ; k++) { if (pos[k] < n) v[pos[k]] = keep[k]? x[k] : fill; }
+		}
+	}
+
+__global__ void over_init_kernel (unsigned long long* bestKey, unsigned long long* bestPos, uint32_t count, int wantMax)
+	{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < count) { bestKey[i] = wantMax? 0ULL : ~0ULL;  bestPos[i] = 0ULL; }
+	}
+
+template <bool MAX>
+static int over_launch (double* d_v, uint32_t n, const uint32_t* d_start, const uint32_t* d_end, uint32_t count,
+                        const uint32_t* d_tileOffsets, const uint32_t* d_tileList, double fill,
+                        unsigned long long* key, unsigned long long* pos, hipStream_t s)
+	{
+	const uint32_t ntiles = (uint32_t) (((uint64_t) n + IV_TILE - 1) / IV_TILE);
+	if (count != 0)
+		{
+		hipLaunchKernelGGL (over_init_kernel, dim3((count + 255) / 256), dim3(256), 0, s, key, pos, count, MAX? 1 : 0);
+		hipLaunchKernelGGL ((over_kernel<MAX, 0>), dim3(ntiles), dim3(IV_THREADS), 0, s, d_v, n, d_start, d_end, d_tileOffsets, d_tileList, key, pos, fill);
+		hipLaunchKernelGGL ((over_kernel<MAX, 1>), dim3(ntiles), dim3(IV_THREADS), 0, s, d_v, n, d_start, d_end, d_tileOffsets, d_tileList, key, pos, fill);
+		}
+	hipLaunchKernelGGL ((over_kernel<MAX, 2>), dim3(ntiles), dim3(IV_THREADS), 0, s, d_v, n, d_start, d_end, d_tileOffsets, d_tileList, key, pos, fill);
+	GDSP_LAUNCH_CHECK ();
+	return GDSP_OK;
+	}
+
+extern "C" {
+
+size_t gdsp_extreme_in_intervals_work (uint32_t count) { return ((size_t) count + 1) * 2 * sizeof(uint64_t); }
+
+/* minover (wantMax=0, fill = the infinity value) / maxover (wantMax=1, fill = the zero value) */
+int gdsp_extreme_in_intervals (double* d_v, uint32_t n, const uint32_t* d_start, const uint32_t* d_end, uint32_t count,
+                               const uint32_t* d_tileOffsets, const uint32_t* d_tileList,
+                               int wantMax, double fill, void* d_work, void* stream)
+	{
+	if (n == 0) return GDSP_OK;
+	GDSP_REQUIRE ((d_v != NULL) && (d_tileOffsets != NULL) && (d_work != NULL), "NULL pointer");
+	unsigned long long* key = (unsigned long long*) d_work;
+	unsigned long long* pos = key + count + 1;
+	if (wantMax) return over_launch<true>  (d_v, n, d_start, d_end, count, d_tileOffsets, d_tileList, fill, key, pos, gdsp_stream (stream));
+	return             over_launch<false> (d_v, n, d_start, d_end, count, d_tileOffsets, d_tileList, fill, key, pos, gdsp_stream (stream));
+	}
+
 /* mask.c:187-300 (mask), :483-640 (masknot), logical.c:439-560 (or), :737-880 (and):
  *   inside  = 1: bases under an interval become d_val[i] (mask: the mask value; or: 1.0)
  *   inside  = 0: bases under NO interval become outsideVal (masknot: the mask value; and: 0.0)

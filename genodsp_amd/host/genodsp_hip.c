@@ -33,7 +33,7 @@
 
 /* ------------------------------------------------------------ operator table */
 /* same names, aliases and order as the reference's dspTable (genodsp.c:117-174);
- * operators outside the hot-path scope (clump, minover, maxover) are not in
+ * operators outside the hot-path scope (clump, anticlump) are not in
  * this build and are reported as such */
 dspprototypes(op_window_sum)     dspprototypes(op_sliding_sum)   dspprototypes(op_smooth)
 dspprototypes(op_cumulative_sum) dspprototypes(op_percentile)    dspprototypes(op_add)
@@ -46,7 +46,7 @@ dspprototypes(op_dilate)         dspprototypes(op_erode)         dspprototypes(o
 dspprototypes(op_output)         dspprototypes(op_show_variables)
 dspprototypes(op_mask)           dspprototypes(op_mask_not)      dspprototypes(op_or)
 dspprototypes(op_and)            dspprototypes(op_min_with)      dspprototypes(op_max_with)
-dspprototypes(op_map)
+dspprototypes(op_map)            dspprototypes(op_min_in_interval) dspprototypes(op_max_in_interval)
 
 static dspinfo dspTable[] =
 	{dspinforecord("sum"           , op_window_sum)     , dspinfoalias ("window_sum")     ,
@@ -68,6 +68,8 @@ static dspinfo dspTable[] =
 	 dspinforecord("binarize"      , op_binarize)       ,
 	 dspinforecord("or"            , op_or)             ,
 	 dspinforecord("and"           , op_and)            ,
+	 dspinforecord("maxover"       , op_max_in_interval), dspinfoalias ("max_over")       ,
+	 dspinforecord("minover"       , op_min_in_interval), dspinfoalias ("min_over")       ,
 	 dspinforecord("localmin"      , op_local_minima)   , dspinfoalias ("local_min")      ,
 	 dspinforecord("localmax"      , op_local_maxima)   , dspinfoalias ("local_max")      ,
 	 dspinforecord("bestmin"       , op_best_local_min) , dspinfoalias ("best_min")       ,
@@ -87,7 +89,7 @@ static dspinfo dspTable[] =
 #define dspTableLen (sizeof(dspTable)/sizeof(dspinfo))
 
 static const char* notInThisBuild[] =
-	{ "clump", "anticlump", "anti_clump", "skimp", "maxover", "max_over", "minover", "min_over", NULL };
+	{ "clump", "anticlump", "anti_clump", "skimp", NULL };
 
 /* ------------------------------------------------------------------- globals */
 spec*  chromsOfInterest = NULL;
@@ -512,6 +514,7 @@ typedef struct staging
 	size_t   ivCap, offCap, listCap;
 	u32     *h_start, *h_end, *h_off, *h_list;   valtype* h_val;
 	u32     *d_start, *d_end, *d_off, *d_list;   valtype* d_val;
+	void*    d_over;   size_t overCap;            /* per-interval records of minover / maxover */
 	} staging;
 static staging stage[64];
 
@@ -645,6 +648,28 @@ void ib_flush_mask (int inside, valtype outsideVal, int binarizeFirst)
 		spec* s = chromsSorted[ci];
 		check_gdsp (gdsp_mask_intervals (s->valVector, s->length, st->d_start, st->d_end, st->d_val, st->d_off, st->d_list,
 		                                 inside, outsideVal, binarizeFirst, op_stream ()), "mask by intervals");
+		pend[ci].count = 0;
+		}
+	pendTotal = 0;
+	}
+
+/* minover / maxover: every chromosome is visited (bases under no interval are filled too) */
+void ib_flush_over (int wantMax, valtype fillVal)
+	{
+	for (int ci=0 ; ci<numChroms ; ci++)
+		{
+		staging* st;
+		stage_chromosome (ci, &st);
+		spec* s = chromsSorted[ci];
+		size_t need = gdsp_extreme_in_intervals_work (pend[ci].count);
+		if (need > st->overCap)
+			{
+			if (st->d_over != NULL) check_gdsp (gdsp_free (st->d_over), "free workspace");
+			check_gdsp (gdsp_malloc (&st->d_over, 2*need), "allocate workspace");
+			st->overCap = 2*need;
+			}
+		check_gdsp (gdsp_extreme_in_intervals (s->valVector, s->length, st->d_start, st->d_end, pend[ci].count,
+		                                       st->d_off, st->d_list, wantMax, fillVal, st->d_over, op_stream ()), "extreme in intervals");
 		pend[ci].count = 0;
 		}
 	pendTotal = 0;

@@ -14,6 +14,7 @@ u64  ib_pending     (void);
 void ib_flush_apply (int overlapOp, int clearFlags, valtype missingVal, int everyChromosome);
 void ib_flush_scale (int divide, valtype infinityVal);
 void ib_flush_mask  (int inside, valtype outsideVal, int binarizeFirst);
+void ib_flush_over  (int wantMax, valtype fillVal);
 
 void sync_all_devices    (void);
 int  device_count_in_use (void);

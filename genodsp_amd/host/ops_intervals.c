@@ -14,7 +14,7 @@
 #include "utilities.h"
 #include "host_services.h"
 
-enum { K_ADD, K_SUBTRACT, K_MULTIPLY, K_DIVIDE, K_MASK, K_MASKNOT, K_OR, K_AND, K_MINWITH, K_MAXWITH };
+enum { K_ADD, K_SUBTRACT, K_MULTIPLY, K_DIVIDE, K_MASK, K_MASKNOT, K_OR, K_AND, K_MINWITH, K_MAXWITH, K_MINOVER, K_MAXOVER };
 
 typedef struct dspop_fileop
 	{
@@ -35,11 +35,13 @@ static dspop* fileop_parse (char* name, int argc, char** argv, int kind)
 	op->valColumn   = (int) get_named_global ("valColumn", 4-1);
 	op->originOne   = (int) get_named_global ("originOne", false);
 	op->infinityVal = valtypeMax;
+	if (kind == K_MINOVER) op->maskVal = valtypeMax;     /* minmax.c:103; maxover's zero value is 0.0 (:504) */
 	for ( ; argc > 0 ; argv++, argc--)
 		{
 		char* arg = argv[0];
 		char* argVal = strchr (arg, '=');  if (argVal != NULL) argVal++;
-		const int isMask = (kind == K_MASK) || (kind == K_MASKNOT);
+		const int isOver = (kind == K_MINOVER) || (kind == K_MAXOVER);
+		const int isMask = (kind == K_MASK) || (kind == K_MASKNOT) || isOver;     /* no value column either */
 		const int isWith = (kind == K_MINWITH) || (kind == K_MAXWITH);
 		if (!isMask && !isWith
 		 && ((strcmp (arg, "--novalue") == 0) || (strcmp (arg, "--novalues") == 0) || (strcmp (arg, "--value=none") == 0)))
@@ -53,7 +55,9 @@ static dspop* fileop_parse (char* name, int argc, char** argv, int kind)
 			op->valColumn = col;
 			continue;
 			}
-		if (isMask && is_opt3 (arg, "mask", "M"))
+		if ((kind == K_MINOVER) && (strcmp_prefix (arg, "--infinity=") == 0)) { op->maskVal = string_to_valtype (argVal);  continue; }
+		if ((kind == K_MAXOVER) && is_opt3 (arg, "zero", "Z"))                { op->maskVal = string_to_valtype (argVal);  continue; }
+		if (isMask && !isOver && is_opt3 (arg, "mask", "M"))
 			{
 			if ((kind == K_MASK) && op->haveMaskVal)
 				{ fprintf (stderr, "[%s] mask value specified more than once (at \"%s\")\n", name, arg);  exit (EXIT_FAILURE); }
@@ -95,9 +99,11 @@ static void fileop_apply (dspop* _op)
 	valtype val;
 	/* "sorted" kinds say what happens to bases under NO interval, so their intervals must be
 	 * sorted, non-overlapping and grouped by chromosome, and every chromosome is visited */
-	int     scaling  = (op->kind == K_MULTIPLY) || (op->kind == K_DIVIDE) || (op->kind == K_MASKNOT) || (op->kind == K_AND);
+	int     scaling  = (op->kind == K_MULTIPLY) || (op->kind == K_DIVIDE) || (op->kind == K_MASKNOT) || (op->kind == K_AND)
+	                || (op->kind == K_MINOVER) || (op->kind == K_MAXOVER);
 	int     skipZero = (op->kind != K_MASK) && (op->kind != K_MASKNOT) && (op->kind != K_MINWITH) && (op->kind != K_MAXWITH);
-	int     valCol   = ((op->kind == K_MASK) || (op->kind == K_MASKNOT))? -1 : op->valColumn;   /* mask.c:237 */
+	int     valCol   = ((op->kind == K_MASK) || (op->kind == K_MASKNOT) || (op->kind == K_MINOVER) || (op->kind == K_MAXOVER))
+	                   ? -1 : op->valColumn;                                             /* mask.c:237, minmax.c:227 */
 	resolve_variable (_op, &op->maskValVarName, &op->maskVal, "mask value");
 
 	FILE* f = fopen (op->filename, "rt");
@@ -169,7 +175,9 @@ static void fileop_apply (dspop* _op)
 		if (trackOperations)
 			for (int i=0 ; chromsSorted[i]!=NULL ; i++)
 				{ if (!chromsSorted[i]->flag) fprintf (stderr, "%s(%s,absent)\n", _op->name, chromsSorted[i]->chrom); }
-		if      (op->kind == K_MASKNOT) ib_flush_mask (false, op->maskVal, false);
+		if      (op->kind == K_MINOVER) ib_flush_over (false, op->maskVal);
+		else if (op->kind == K_MAXOVER) ib_flush_over (true,  op->maskVal);
+		else if (op->kind == K_MASKNOT) ib_flush_mask (false, op->maskVal, false);
 		else if (op->kind == K_AND)     ib_flush_mask (false, 0.0, true);
 		else                            ib_flush_scale (op->kind == K_DIVIDE, op->infinityVal);
 		}
@@ -196,13 +204,17 @@ static void fileop_usage (char* name, FILE* f, char* indent, int kind)
 		  "Binarise the signal (non-zero -> 1), then OR it with the intervals in a file.",
 		  "Binarise the signal (non-zero -> 1), then AND it with the (sorted, non-overlapping)\nintervals in a file.",
 		  "Replace each base by the minimum of itself and the values of the intervals covering it.",
-		  "Replace each base by the maximum of itself and the values of the intervals covering it." };
+		  "Replace each base by the maximum of itself and the values of the intervals covering it.",
+		  "Keep, inside each (sorted, non-overlapping) interval of a file, only the minimum (the most\ncentral one on ties); everything else becomes the infinity value.",
+		  "Keep, inside each (sorted, non-overlapping) interval of a file, only the maximum (the most\ncentral one on ties); everything else becomes the zero value." };
 	if (indent == NULL) indent = "";
 	char* text = copy_string (what[kind]);
 	for (char* line = strtok (text, "\n") ; line != NULL ; line = strtok (NULL, "\n")) fprintf (f, "%s%s\n", indent, line);
 	free (text);
 	fprintf (f, "%s\n%susage: %s <filename> [options]\n", indent, indent, name);
-	if ((kind == K_MASK) || (kind == K_MASKNOT))
+	if (kind == K_MINOVER)      fprintf (f, "%s  --infinity=<value>       value for non-minima (default: largest double)\n", indent);
+	else if (kind == K_MAXOVER) fprintf (f, "%s  --zero=<value>           (Z=) value for non-maxima (default 0.0)\n", indent);
+	else if ((kind == K_MASK) || (kind == K_MASKNOT))
 		fprintf (f, "%s  --mask=<value%s>     (M=) the mask value (default 0.0)\n", indent, (kind == K_MASK)? "|variable" : "");
 	else
 		fprintf (f, "%s  --value=<col>            column of the interval value (default: the global one)\n", indent);
@@ -231,6 +243,8 @@ FILEOP_GROUP (op_or,       K_OR,       "logical-OR the current set of intervals 
 FILEOP_GROUP (op_and,      K_AND,      "logical-AND the current set of intervals with intervals read from a file")
 FILEOP_GROUP (op_min_with, K_MINWITH,  "take the minimum of the current values and interval values read from a file")
 FILEOP_GROUP (op_max_with, K_MAXWITH,  "take the maximum of the current values and interval values read from a file")
+FILEOP_GROUP (op_min_in_interval, K_MINOVER, "find the minimum value in each of a set of intervals read from a file")
+FILEOP_GROUP (op_max_in_interval, K_MAXOVER, "find the maximum value in each of a set of intervals read from a file")
 
 /* ---------------------------------------------------------------- input ---- */
 typedef struct dspop_input

@@ -206,6 +206,14 @@ int gdsp_mask_intervals (double* d_v, uint32_t n, const uint32_t* d_start, const
                          const double* d_val, const uint32_t* d_tileOffsets, const uint32_t* d_tileList,
                          int inside, double outsideVal, int binarizeFirst, void* stream);
 
+/* minover / maxover (minmax.c:193-390, :596-793): inside each sorted, non-overlapping interval only
+ * the extreme survives, at the tied position nearest the interval's centre; everything else becomes
+ * `fill`.  d_work >= gdsp_extreme_in_intervals_work(count) bytes. */
+size_t gdsp_extreme_in_intervals_work (uint32_t count);
+int gdsp_extreme_in_intervals (double* d_v, uint32_t n, const uint32_t* d_start, const uint32_t* d_end, uint32_t count,
+                               const uint32_t* d_tileOffsets, const uint32_t* d_tileList,
+                               int wantMax, double fill, void* d_work, void* stream);
+
 /* ---- genodsp.c report_intervals:1561-1691 --------------------------------------- */
 
 /* Run-length encode one chromosome on the device.  d_runs receives up to cap

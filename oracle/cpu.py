@@ -70,6 +70,7 @@ def _declare(L):
     sig("orc_apply_intervals", None, _pd, _u32, _pu, _pu, _pd, _u32, _int, _int, _f64)
     sig("orc_scale_intervals", None, _pd, _u32, _pu, _pu, _pd, _u32, _int, _f64)
     sig("orc_mask_intervals", None, _pd, _u32, _pu, _pu, _pd, _u32, _int, _f64, _int)
+    sig("orc_extreme_in_intervals", None, _pd, _u32, _pu, _pu, _u32, _int, _f64)
     sig("orc_report_runs", _u32, _pd, _u32, _int, _int, _pu, _pu, _pd, _u32)
     sig("orc_synth_coverage", None, _u64, _u32, _u32, _u32, _int, _pd)
 
@@ -261,6 +262,14 @@ def mask_intervals(v, start, end, val, inside=True, outside_val=0.0, binarize_fi
     e, pe = _u(end)
     x, px = _in(val)
     lib().orc_mask_intervals(pv, v.size, ps, pe, px, s.size, int(inside), outside_val, int(binarize_first))
+    return v
+
+
+def extreme_in_intervals(v, start, end, want_max, fill):
+    v, pv = _copy(v)
+    s, ps = _u(start)
+    e, pe = _u(end)
+    lib().orc_extreme_in_intervals(pv, v.size, ps, pe, s.size, int(want_max), fill)
     return v
 
 

@@ -510,6 +510,37 @@ void orc_mask_intervals (double* v, uint32_t n, const uint32_t* start, const uin
 	for (ix=prevEnd ; ix<n ; ix++) v[ix] = outsideVal;
 	}
 
+/* minmax.c:270-352 (minover) and :673-755 (maxover): per sorted, non-overlapping interval the
+ * extreme value and, among ties, the position with the largest inset min(ix-start, end-ix)
+ * (the earliest on equal insets) survive; every other base becomes `fill`. */
+void orc_extreme_in_intervals (double* v, uint32_t n, const uint32_t* start, const uint32_t* end,
+                               uint32_t count, int wantMax, double fill)
+	{
+	uint32_t i, ix, prevEnd = 0, s, e, bestIx, inset, maxInset;
+	double   best;
+	for (i=0 ; i<count ; i++)
+		{
+		s = start[i];  e = (end[i] > n)? n : end[i];
+		for (ix=prevEnd ; ix<s ; ix++) v[ix] = fill;
+		best = v[s];  bestIx = s;  maxInset = 0;
+		for (ix=s+1 ; ix<e ; ix++)
+			{
+			if (wantMax? (v[ix] < best) : (v[ix] > best)) continue;
+			if (wantMax? (v[ix] > best) : (v[ix] < best))
+				{
+				best = v[ix];  bestIx = ix;
+				maxInset = (ix-s < e-ix)? ix-s : e-ix;
+				continue;
+				}
+			inset = (ix-s < e-ix)? ix-s : e-ix;
+			if (inset > maxInset) { bestIx = ix;  maxInset = inset; }
+			}
+		for (ix=s ; ix<e ; ix++) { if (ix != bestIx) v[ix] = fill; }
+		prevEnd = e;
+		}
+	for (ix=prevEnd ; ix<n ; ix++) v[ix] = fill;
+	}
+
 /* genodsp.c:1587-1678: run-length encoding of one
  * chromosome as report_intervals emits it.  Exact zeros end a run and are not
  * reported unless uncovered==show; equal neighbours collapse when asked to. */

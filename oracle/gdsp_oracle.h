@@ -72,6 +72,9 @@ void orc_scale_intervals (double* v, uint32_t n, const uint32_t* start, const ui
 void orc_mask_intervals  (double* v, uint32_t n, const uint32_t* start, const uint32_t* end,
                           const double* val, uint32_t count, int inside, double outsideVal, int binarizeFirst);
 
+void orc_extreme_in_intervals (double* v, uint32_t n, const uint32_t* start, const uint32_t* end,
+                               uint32_t count, int wantMax, double fill);          /* minmax.c minover/maxover */
+
 /* genodsp.c report_intervals: run-length encode one chromosome; returns the
  * number of runs written (at most cap).  uncovered: 0 hide, 1 show, -1 NA */
 uint32_t orc_report_runs (const double* v, uint32_t n, int collapse, int uncovered,

@@ -246,7 +246,9 @@ for op, ivs, extra in (("add", LOOSE_IV, []), ("subtract", LOOSE_IV, []), ("mult
                        ("divide", SORTED_IV, []), ("divide", SORTED_IV, ["--infinity=1000"]),
                        ("mask", LOOSE_IV, ["--mask=-1"]), ("mask", LOOSE_IV, []), ("masknot", SORTED_IV, ["--mask=9"]),
                        ("or", LOOSE_IV, []), ("and", SORTED_IV, []), ("minwith", LOOSE_IV, []),
-                       ("maxwith", LOOSE_IV, []), ("or", LOOSE_IV, ["--novalue"])):
+                       ("maxwith", LOOSE_IV, []), ("or", LOOSE_IV, ["--novalue"]),
+                       ("minover", SORTED_IV, ["--infinity=99"]), ("maxover", SORTED_IV, []),
+                       ("maxover", SORTED_IV, ["--zero=-1"])):
     tag = "cli_file_%s%s" % (op, "".join(e.strip("-").replace("=", "") for e in extra))
     cli_case(tag, GENOME3, ["--precision=4", "--uncovered:show", "=", op, "@iv@"] + extra, SIGNAL3, {"iv": ivs})
 cli_case("cli_file_input_output", GENOME3,

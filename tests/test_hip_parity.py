@@ -480,3 +480,23 @@ def test_map_values_bit_exact(n, nknots, gd):
         x[0], x[1], x[2] = kin[0], kin[-1], kin[kin.size // 2]        # exactly on knots
     got = gd.map_values(gd.DeviceVector.from_numpy(x), kin, kout).numpy()
     assert bits_equal(got, cpu.map_values(x, kin, kout))
+
+
+@pytest.mark.parametrize("n", [1, 1024, 5000, 100001])
+def test_minover_maxover_bit_exact(n, gd):
+    rng = np.random.default_rng(n + 9)
+    for kind in ("blocky", "real"):
+        base = np.repeat(rng.integers(0, 4, n // 3 + 1), 3)[:n].astype(np.float64) if kind == "blocky" \
+            else rng.standard_normal(n)
+        cuts = np.unique(rng.integers(0, n + 1, 60))
+        s, e = cuts[:-1:2].astype(np.uint32), cuts[1::2].astype(np.uint32)
+        k = min(s.size, e.size)
+        s, e = s[:k], e[:k]
+        for want_max, fill in ((False, 99.0), (True, 0.0)):
+            got = gd.extreme_in_intervals(gd.DeviceVector.from_numpy(base), s, e, want_max, fill).numpy()
+            want = cpu.extreme_in_intervals(base, s, e, want_max, fill)
+            assert bits_equal(got, want), (kind, want_max, first_diff(got, want))
+    # one interval spanning many tiles, ties everywhere: the most central base wins
+    flat = np.full(n, 2.0)
+    got = gd.extreme_in_intervals(gd.DeviceVector.from_numpy(flat), [0], [n], True, 0.0).numpy()
+    assert bits_equal(got, cpu.extreme_in_intervals(flat, [0], [n], True, 0.0))
