@@ -129,6 +129,10 @@ typedef struct devstate
 
 static devstate devs[64];
 static int      currentDevice = 0;
+static int      physicalDevices = 1;   /* logical device d runs on GPU d % physicalDevices (see --gpus) */
+
+static int use_device (int logical)
+	{ return gdsp_set_device (logical % physicalDevices); }
 
 void check_gdsp (int status, const char* what)
 	{
@@ -342,7 +346,7 @@ static void sort_chromosomes_by_length (void)             /* genodsp.c:1113-1145
 void select_device_of (spec* s)
 	{
 	int d = ((xspec*) s)->device;
-	if (d != currentDevice) { check_gdsp (gdsp_set_device (d), "select device");  currentDevice = d; }
+	if (d != currentDevice) { check_gdsp (use_device (d), "select device");  currentDevice = d; }
 	}
 
 void* op_stream (void) { return devs[currentDevice].stream; }
@@ -389,10 +393,10 @@ void sync_all_devices (void)
 	{
 	for (int d=0 ; d<numDevices ; d++)
 		{
-		check_gdsp (gdsp_set_device (d), "select device");
+		check_gdsp (use_device (d), "select device");
 		check_gdsp (gdsp_stream_sync (devs[d].stream), "synchronise");
 		}
-	check_gdsp (gdsp_set_device (currentDevice), "select device");
+	check_gdsp (use_device (currentDevice), "select device");
 	}
 
 int device_count_in_use (void) { return numDevices; }
@@ -412,7 +416,7 @@ static void allocate_vectors (void)
 		}
 	for (int d=0 ; d<numDevices ; d++)
 		{
-		check_gdsp (gdsp_set_device (d), "select device");
+		check_gdsp (use_device (d), "select device");
 		check_gdsp (gdsp_stream_create (&devs[d].stream), "create stream");
 		}
 	for (int i=0 ; chromsSorted[i]!=NULL ; i++)
@@ -421,7 +425,7 @@ static void allocate_vectors (void)
 		xspec* x = (xspec*) s;
 		if (trackOperations)
 			tracking_report ("allocate(%s / %s bytes)\n", s->chrom, ucommatize (s->length));
-		check_gdsp (gdsp_set_device (x->device), "select device");
+		check_gdsp (use_device (x->device), "select device");
 		currentDevice = x->device;
 		size_t bytes = ((size_t) s->length + 2) * sizeof(valtype);
 		check_gdsp (gdsp_malloc ((void**) &s->valVector, bytes), "allocate chromosome vector");
@@ -977,8 +981,14 @@ int main (int argc, char** argv)
 
 	int available = 0;
 	check_gdsp (gdsp_device_count (&available), "count GPUs");
-	if (available < numDevices)
-		{ fprintf (stderr, "[%s] %d GPU(s) requested, %d visible\n", programName, numDevices, available);  return EXIT_FAILURE; }
+	if (available < 1) { fprintf (stderr, "[%s] no GPU visible\n", programName);  return EXIT_FAILURE; }
+	physicalDevices = available;
+	if ((available < numDevices) && (getenv ("GDSP_OVERSUBSCRIBE_GPUS") == NULL))
+		{
+		fprintf (stderr, "[%s] %d GPU(s) requested, %d visible (set GDSP_OVERSUBSCRIBE_GPUS=1 to run the\n"
+		                 "%d shards on the visible GPUs anyway)\n", programName, numDevices, available, numDevices);
+		return EXIT_FAILURE;
+		}
 
 	sort_chromosomes_by_length ();
 	allocate_vectors ();
