@@ -186,9 +186,19 @@ def smooth_local_extrema(v, W, N, want_max, fill, out=None, mode=FIR_EXACT, stre
     return out
 
 
+def _long_work(v):
+    nbytes = lib().gdsp_long_window_work(v.n)
+    return DeviceBuffer(nbytes), nbytes
+
+
 def sliding_sum(v, W, denom=1.0, out=None, stream=None):
     out = out if out is not None else v.like()
-    call("gdsp_sliding_sum", v.ptr, out.ptr, v.n, W, float(denom), _sp(stream))
+    if W <= 8192:
+        call("gdsp_sliding_sum", v.ptr, out.ptr, v.n, W, float(denom), _sp(stream))
+        return out
+    work, nbytes = _long_work(v)
+    call("gdsp_sliding_sum_any", v.ptr, out.ptr, v.n, W, float(denom), C.c_void_p(work.ptr), nbytes, _sp(stream))
+    sync(stream)
     return out
 
 
@@ -208,7 +218,12 @@ def cumulative_sum(v, stream=None):
 
 def local_extrema(v, N, want_max, fill, out=None, stream=None):
     out = out if out is not None else v.like()
-    call("gdsp_local_extrema", v.ptr, out.ptr, v.n, N, int(want_max), float(fill), _sp(stream))
+    if N <= 4096:
+        call("gdsp_local_extrema", v.ptr, out.ptr, v.n, N, int(want_max), float(fill), _sp(stream))
+        return out
+    work, nbytes = _long_work(v)
+    call("gdsp_local_extrema_any", v.ptr, out.ptr, v.n, N, int(want_max), float(fill), C.c_void_p(work.ptr), nbytes, _sp(stream))
+    sync(stream)
     return out
 
 
@@ -222,7 +237,12 @@ def localmin(v, N=3, infinity=DBL_MAX, **kw):
 
 def best_extrema(v, W, want_max, out=None, stream=None):
     out = out if out is not None else v.like()
-    call("gdsp_best_extrema", v.ptr, out.ptr, v.n, W, int(want_max), _sp(stream))
+    if W <= 4096:
+        call("gdsp_best_extrema", v.ptr, out.ptr, v.n, W, int(want_max), _sp(stream))
+        return out
+    work, nbytes = _long_work(v)
+    call("gdsp_best_extrema_any", v.ptr, out.ptr, v.n, W, int(want_max), C.c_void_p(work.ptr), nbytes, _sp(stream))
+    sync(stream)
     return out
 
 

@@ -62,6 +62,10 @@ SIGNATURES = {
     "gdsp_cumulative_sum": (_int, [_vp, _u32, _vp, _vp]),
     "gdsp_local_extrema": (_int, [_vp, _vp, _u32, _u32, _int, _f64, _vp]),
     "gdsp_best_extrema": (_int, [_vp, _vp, _u32, _u32, _int, _vp]),
+    "gdsp_long_window_work": (_sz, [_u32]),
+    "gdsp_best_extrema_any": (_int, [_vp, _vp, _u32, _u32, _int, _vp, _sz, _vp]),
+    "gdsp_local_extrema_any": (_int, [_vp, _vp, _u32, _u32, _int, _f64, _vp, _sz, _vp]),
+    "gdsp_sliding_sum_any": (_int, [_vp, _vp, _u32, _u32, _f64, _vp, _sz, _vp]),
     "gdsp_dilate": (_int, [_vp, _vp, _u32, _u32, _u32, _f64, _f64, _f64, _vp]),
     "gdsp_erode": (_int, [_vp, _vp, _u32, _u32, _u32, _f64, _f64, _f64, _vp]),
     "gdsp_dilate_erode": (_int, [_vp, _vp, _u32, _u32, _u32, _f64, _f64, _f64, _u32, _u32, _f64, _f64, _f64,

@@ -374,13 +374,23 @@ valtype* get_scratch_vector (void)                        /* genodsp.c:1904-1940
 			{
 			/* longest local chromosome, but never less than what the select histograms need */
 			size_t n = (d->maxLength > 16384)? d->maxLength : 16384;
-			check_gdsp (gdsp_malloc ((void**) &d->scratch[i], n * sizeof(valtype)), "allocate scratch vector");
+			check_gdsp (gdsp_malloc ((void**) &d->scratch[i], (n + 2) * sizeof(valtype)), "allocate scratch vector");
 			}
 		d->scratchInUse[i] = true;
 		return d->scratch[i];
 		}
 	fprintf (stderr, "[%s] internal error: out of scratch vectors\n", programName);
 	exit (EXIT_FAILURE);
+	}
+
+/* workspace for the long-window forms: gdsp_long_window_work(maxLength) bytes, once per device */
+void* long_window_workspace (size_t* bytes)
+	{
+	static void* work[64];
+	devstate* d = &devs[currentDevice];
+	*bytes = gdsp_long_window_work (d->maxLength);
+	if (work[currentDevice] == NULL) check_gdsp (gdsp_malloc (&work[currentDevice], *bytes), "allocate long-window workspace");
+	return work[currentDevice];
 	}
 
 void release_scratch_vector (valtype* v)

@@ -57,7 +57,13 @@ void op_local_describe (dspop* _op, u32* neighborhood, int* wantMax, valtype* fi
 static void local_apply (dspop* _op, char* vName, u32 vLen, valtype* v)
 	{
 	dspop_local* op = (dspop_local*) _op;
-	check_gdsp (gdsp_local_extrema (v, partner_vector (vName), vLen, op->neighborhood, op->wantMax, op->fill, op_stream ()), _op->name);
+	int rc = gdsp_local_extrema (v, partner_vector (vName), vLen, op->neighborhood, op->wantMax, op->fill, op_stream ());
+	if (rc == GDSP_EINVAL)                       /* neighbourhood beyond one LDS tile: whole-vector form */
+		{
+		size_t bytes;  void* work = long_window_workspace (&bytes);
+		rc = gdsp_local_extrema_any (v, partner_vector (vName), vLen, op->neighborhood, op->wantMax, op->fill, work, bytes, op_stream ());
+		}
+	check_gdsp (rc, _op->name);
 	flip_vector (vName);
 	}
 
@@ -100,7 +106,13 @@ static void best_usage (char* name, FILE* f, char* indent, int wantMax)
 static void best_apply (dspop* _op, char* vName, u32 vLen, valtype* v)
 	{
 	dspop_best* op = (dspop_best*) _op;
-	check_gdsp (gdsp_best_extrema (v, partner_vector (vName), vLen, op->windowSize, op->wantMax, op_stream ()), _op->name);
+	int rc = gdsp_best_extrema (v, partner_vector (vName), vLen, op->windowSize, op->wantMax, op_stream ());
+	if (rc == GDSP_EINVAL)
+		{
+		size_t bytes;  void* work = long_window_workspace (&bytes);
+		rc = gdsp_best_extrema_any (v, partner_vector (vName), vLen, op->windowSize, op->wantMax, work, bytes, op_stream ());
+		}
+	check_gdsp (rc, _op->name);
 	flip_vector (vName);
 	}
 

@@ -116,7 +116,13 @@ void op_sliding_sum_free (dspop* op) { free (op); }
 void op_sliding_sum_apply (dspop* _op, char* vName, u32 vLen, valtype* v)
 	{
 	dspop_sum* op = (dspop_sum*) _op;
-	check_gdsp (gdsp_sliding_sum (v, partner_vector (vName), vLen, op->windowSize, op->denominator, op_stream ()), _op->name);
+	int rc = gdsp_sliding_sum (v, partner_vector (vName), vLen, op->windowSize, op->denominator, op_stream ());
+	if (rc == GDSP_EINVAL)                       /* window beyond one LDS tile: prefix-difference form */
+		{
+		size_t bytes;  void* work = long_window_workspace (&bytes);
+		rc = gdsp_sliding_sum_any (v, partner_vector (vName), vLen, op->windowSize, op->denominator, work, bytes, op_stream ());
+		}
+	check_gdsp (rc, _op->name);
 	flip_vector (vName);
 	}
 

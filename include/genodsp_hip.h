@@ -103,6 +103,17 @@ int gdsp_local_extrema (const double* d_in, double* d_out, uint32_t n, uint32_t 
 int gdsp_best_extrema  (const double* d_in, double* d_out, uint32_t n, uint32_t W,
                         int wantMax, void* stream);
 
+/* Any window length (the tiled kernels above stop at what one LDS tile holds and return
+ * GDSP_EINVAL beyond): the *_any forms use the tiled kernel when it applies and otherwise
+ * whole-vector passes through d_work (>= gdsp_long_window_work(n) bytes of device memory). */
+size_t gdsp_long_window_work (uint32_t n);
+int gdsp_best_extrema_any  (const double* d_in, double* d_out, uint32_t n, uint32_t W, int wantMax,
+                            void* d_work, size_t workBytes, void* stream);
+int gdsp_local_extrema_any (const double* d_in, double* d_out, uint32_t n, uint32_t N, int wantMax, double fill,
+                            void* d_work, size_t workBytes, void* stream);
+int gdsp_sliding_sum_any   (const double* d_in, double* d_out, uint32_t n, uint32_t W, double denom,
+                            void* d_work, size_t workBytes, void* stream);
+
 /* ---- morphology.c --------------------------------------------------------------- */
 
 /* All four binarise with v > T and write only one/zero.  Out-of-place

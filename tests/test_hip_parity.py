@@ -500,3 +500,21 @@ def test_minover_maxover_bit_exact(n, gd):
     flat = np.full(n, 2.0)
     got = gd.extreme_in_intervals(gd.DeviceVector.from_numpy(flat), [0], [n], True, 0.0).numpy()
     assert bits_equal(got, cpu.extreme_in_intervals(flat, [0], [n], True, 0.0))
+
+
+@pytest.mark.parametrize("n", [1, 100, 20011, 300007])
+@pytest.mark.parametrize("W", [9001, 20000, 65536, 1000001])
+def test_windows_beyond_one_lds_tile(n, W, gd):
+    """Windows longer than the tiled kernels hold fall back to whole-vector passes; same answers."""
+    rng = np.random.default_rng(n + W)
+    x = _signal("depth", n, rng)
+    d = gd.DeviceVector.from_numpy(x)
+    assert bits_equal(gd.best_extrema(d, W, True).numpy(), cpu.best_extrema(x, W, 1))
+    assert bits_equal(gd.best_extrema(d, W, False).numpy(), cpu.best_extrema(x, W, 0))
+    assert bits_equal(gd.sliding_sum(d, W).numpy(), cpu.sliding_sum(x, W))
+    N = W | 1
+    if n <= 20011:            # the oracle's localmax is O(n N)
+        y = _signal("noise", n, rng)
+        dy = gd.DeviceVector.from_numpy(y)
+        assert bits_equal(gd.localmax(dy, N).numpy(), cpu.local_extrema(y, N, 1, 0.0))
+        assert bits_equal(gd.localmin(dy, N).numpy(), cpu.local_extrema(y, N, 0, cpu.DBL_MAX))
