@@ -104,14 +104,24 @@ void window_sum_tile_kernel (double* __restrict__ v, uint32_t n, uint32_t W, uin
 	const uint64_t base  = (uint64_t) tile * K * W;
 	const uint32_t span  = (uint32_t) ((base + (uint64_t) K*W <= n)? K*W : n - base);   // bases in this tile
 
-	// stage: thread handles bases p, p+256, ...; (row, col) advance without divisions
+	// stage: thread handles bases p, p+256, ...; (row, col) advance without divisions.  Four
+	// loads are issued (index clamped, never predicated) before the four LDS stores.
 	uint32_t row = threadIdx.x / W, col = threadIdx.x % W;
 	const uint32_t dRow = SU_THREADS / W, dCol = SU_THREADS % W;
-	for (uint32_t p=threadIdx.x ; p<span ; p+=SU_THREADS)
+	for (uint32_t p0=threadIdx.x ; p0<span ; p0+=4*SU_THREADS)
 		{
-		suLds[(size_t) row * pitch + col] = v[base + p];
-		row += dRow;  col += dCol;
-		if (col >= W) { col -= W;  row++; }
+		double x[4];
+#pragma unroll
+		for (int u=0 ; u<4 ; u++)
+			{ const uint32_t p = p0 + u*SU_THREADS;  x[u] = v[base + ((p < span)? p : span-1)]; }
+#pragma unroll
+		for (int u=0 ; u<4 ; u++)
+			{
+			const uint32_t p = p0 + u*SU_THREADS;
+			if (p < span) suLds[(size_t) row * pitch + col] = x[u];
+			row += dRow;  col += dCol;
+			if (col >= W) { col -= W;  row++; }
+			}
 		}
 	__syncthreads ();
 
