@@ -332,6 +332,15 @@ def map_values(v, knots_in, knots_out, stream=None):
     return v
 
 
+def clump(v, average, min_length, above=True, one=1.0, zero=0.0, stream=None):
+    """op_clump_apply (above) / op_skimp_apply: in place."""
+    work = DeviceBuffer(lib().gdsp_clump_work(v.n))
+    call("gdsp_clump", v.ptr, v.n, float(average), int(min_length), int(bool(above)), float(one), float(zero),
+         C.c_void_p(work.ptr), _sp(stream))
+    sync(stream)
+    return v
+
+
 def fill(v, val, stream=None):
     call("gdsp_fill", v.ptr, v.n, float(val), _sp(stream))
     return v

@@ -79,6 +79,8 @@ SIGNATURES = {
     "gdsp_abs": (_int, [_vp, _u32, _vp]),
     "gdsp_invert": (_int, [_vp, _u32, _f64, _vp]),
     "gdsp_map": (_int, [_vp, _u32, _vp, _vp, _u32, _vp]),
+    "gdsp_clump_work": (_sz, [_u32]),
+    "gdsp_clump": (_int, [_vp, _u32, _f64, _u32, _int, _f64, _f64, _vp, _vp]),
     "gdsp_minmax_init": (_int, [_vp, _vp]),
     "gdsp_minmax_update": (_int, [_vp, _u32, _u32, _f64, _f64, _vp, _vp]),
     "gdsp_select_hist_init": (_int, [_vp, _int, _vp]),

@@ -47,12 +47,15 @@ dspprototypes(op_output)         dspprototypes(op_show_variables)
 dspprototypes(op_mask)           dspprototypes(op_mask_not)      dspprototypes(op_or)
 dspprototypes(op_and)            dspprototypes(op_min_with)      dspprototypes(op_max_with)
 dspprototypes(op_map)            dspprototypes(op_min_in_interval) dspprototypes(op_max_in_interval)
+dspprototypes(op_clump)          dspprototypes(op_skimp)
 
 static dspinfo dspTable[] =
 	{dspinforecord("sum"           , op_window_sum)     , dspinfoalias ("window_sum")     ,
 	 dspinforecord("slidingsum"    , op_sliding_sum)    , dspinfoalias ("sliding_sum")    ,
 	 dspinforecord("smooth"        , op_smooth)         ,
 	 dspinforecord("cumulativesum" , op_cumulative_sum) , dspinfoalias ("cumulative")     , dspinfoalias ("integrate"),
+	 dspinforecord("clump"         , op_clump)          ,
+	 dspinforecord("anticlump"     , op_skimp)          , dspinfoalias ("anti_clump")     , dspinfoalias ("skimp"),
 	 dspinforecord("percentile"    , op_percentile)     ,
 	 dspinforecord("add"           , op_add)            ,
 	 dspinforecord("subtract"      , op_subtract)       ,
@@ -88,8 +91,7 @@ static dspinfo dspTable[] =
 	 dspinforecord("variables"     , op_show_variables) };
 #define dspTableLen (sizeof(dspTable)/sizeof(dspinfo))
 
-static const char* notInThisBuild[] =
-	{ "clump", "anticlump", "anti_clump", "skimp", NULL };
+static const char* notInThisBuild[] = { NULL };    /* every operator of the reference's table is built */
 
 /* ------------------------------------------------------------------- globals */
 spec*  chromsOfInterest = NULL;
@@ -390,6 +392,24 @@ void* long_window_workspace (size_t* bytes)
 	devstate* d = &devs[currentDevice];
 	*bytes = gdsp_long_window_work (d->maxLength);
 	if (work[currentDevice] == NULL) check_gdsp (gdsp_malloc (&work[currentDevice], *bytes), "allocate long-window workspace");
+	return work[currentDevice];
+	}
+
+/* general per-device workspace that only ever grows (clump's scans) */
+void* device_workspace (size_t bytes)
+	{
+	static void*  work[64];
+	static size_t have[64];
+	if (have[currentDevice] < bytes)
+		{
+		if (work[currentDevice] != NULL)
+			{
+			check_gdsp (gdsp_stream_sync (devs[currentDevice].stream), "synchronise");
+			gdsp_free (work[currentDevice]);
+			}
+		check_gdsp (gdsp_malloc (&work[currentDevice], bytes), "allocate operator workspace");
+		have[currentDevice] = bytes;
+		}
 	return work[currentDevice];
 	}
 

@@ -148,6 +148,14 @@ int gdsp_invert       (double* d_v, uint32_t n, double mid, void* stream); /* ad
  * `in` (device arrays).  Bit-identical to the reference for strictly increasing knots. */
 int gdsp_map          (double* d_v, uint32_t n, const double* d_knotIn, const double* d_knotOut,
                        uint32_t nknots, void* stream);
+/* clump_search (clump.c:494-736), op_clump_apply (above != 0) / op_skimp_apply: bases in stretches
+ * of at least minLength whose average is >= (<=) `average` become `one`, the rest `zero`; each
+ * merged run is trimmed to its first and last base on the right side of the threshold.  In place;
+ * d_work >= gdsp_clump_work(n) bytes.  Whole-vector scans; bit-identical to the reference whenever
+ * the running sum of (v - average) is exactly representable (depth against a dyadic threshold). */
+size_t gdsp_clump_work (uint32_t n);
+int gdsp_clump        (double* d_v, uint32_t n, double average, uint32_t minLength, int above,
+                       double one, double zero, void* d_work, void* stream);
 /* add.c:909-923 / percentile.c:434-530: d_minmax[0]=min(d_minmax[0], min over sample),
  * d_minmax[1]=max(...), d_minmax[2]+=count (as double); sample = every window-th value
  * with lo <= v <= hi.  Initialise with gdsp_minmax_init. */

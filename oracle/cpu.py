@@ -65,6 +65,7 @@ def _declare(L):
     sig("orc_genome_minmax", None, C.POINTER(_pd), _pu, _int, _pd, _pd)
     sig("orc_invert", None, _pd, _u32, _f64)
     sig("orc_map", None, _pd, _u32, _pd, _pd, _u32)
+    sig("orc_clump", None, _pd, _u32, _f64, _u32, _int, _f64, _f64)
     sig("orc_percentile", _u32, C.POINTER(_pd), _pu, _int, _u32, _f64, _f64, _pu, _int, _pd)
     sig("orc_fill", None, _pd, _u32, _f64)
     sig("orc_apply_intervals", None, _pd, _u32, _pu, _pu, _pd, _u32, _int, _int, _f64)
@@ -225,6 +226,12 @@ def map_values(v, knots_in, knots_out):
     a, pa = _in(knots_in)
     b, pb = _in(knots_out)
     lib().orc_map(pv, v.size, pa, pb, a.size)
+    return v
+
+
+def clump(v, average, min_length, above=True, one=1.0, zero=0.0):
+    v, pv = _copy(v)
+    lib().orc_clump(pv, v.size, average, min_length, 1 if above else 0, one, zero)
     return v
 
 

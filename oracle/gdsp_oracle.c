@@ -360,6 +360,83 @@ void orc_map (double* v, uint32_t n, const double* kin, const double* kout, uint
 		}
 	}
 
+/* clump.c:494-736 (clump_search): mark every stretch of at least minLength bases whose average is
+ * >= average (above) or <= average (!above), merge them, trim each merged run to its first and
+ * last base on the right side of the threshold.  Same walk as the reference: one running sum of
+ * (v - average), the list of its strict record minima (value, position) starting with (0, -1), a
+ * cursor on the earliest record not above the running sum (moved only in the direction the sum
+ * just moved, :591-607), and the longest qualifying stretch ending at each base (:613-646).
+ * relative lengths (:512-518) are resolved by the caller. */
+void orc_clump (double* v, uint32_t n, double average, uint32_t minLength, int above, double one, double zero)
+	{
+	double*   mark  = (double*)  malloc (((size_t) n + 1) * sizeof(double));
+	double*   recV  = (double*)  malloc (((size_t) n + 1) * sizeof(double));
+	uint32_t* recAt = (uint32_t*) malloc (((size_t) n + 1) * sizeof(uint32_t));
+	uint32_t  nrec, cursor, ix, iy, from, to, runFrom = (uint32_t) -1, runTo = (uint32_t) -1, scan;
+	double    sum = 0.0, lowest = 0.0, d;
+	int       hopeless = 1;
+
+	for (ix=0 ; ix<n ; ix++)                                       /* :548-569 */
+		{
+		d = above? v[ix] - average : average - v[ix];
+		if (d >= 0.0) { hopeless = 0;  break; }
+		}
+	if (hopeless)
+		{
+		for (ix=0 ; ix<n ; ix++) v[ix] = zero;
+		goto done;
+		}
+
+	recV[0] = 0.0;  recAt[0] = (uint32_t) -1;  nrec = 1;  cursor = 0;
+	for (ix=0 ; ix<n ; ix++)
+		{
+		d = above? v[ix] - average : average - v[ix];
+		mark[ix] = zero;
+		sum += d;
+		if (sum < lowest) { lowest = sum;  recV[nrec] = sum;  recAt[nrec] = ix;  nrec++; }
+		if      (d < 0) { while (recV[cursor] > sum) cursor++; }
+		else if (d > 0) { while ((cursor > 0) && (recV[cursor-1] <= sum)) cursor--; }
+
+		if (ix - recAt[cursor] < minLength) continue;              /* u32 arithmetic, as :614 */
+		from = recAt[cursor] + 1;  to = ix;
+		if ((runFrom == (uint32_t) -1) || (from > runTo + 1))
+			{ for (iy=from ; iy<=to ; iy++) mark[iy] = one;  runFrom = from;  runTo = to; }
+		else if (from >= runFrom)
+			{ for (iy=runTo+1 ; iy<=to ; iy++) mark[iy] = one;  runTo = to; }
+		else
+			{
+			for (iy=from ; iy<runFrom ; iy++) mark[iy] = one;
+			for (iy=runTo+1 ; iy<=to ; iy++) mark[iy] = one;
+			runFrom = from;  runTo = to;
+			}
+		}
+
+	scan = 0;                                                      /* :651-716 */
+	for (;;)
+		{
+		for (from=scan ; from<n ; from++) { if (mark[from] != zero) break;  v[from] = zero; }
+		if (from >= n) break;
+		for (ix=from ; ix<n ; ix++)
+			{
+			if (mark[ix] == zero) break;
+			if (above? (v[ix] >= average) : (v[ix] <= average)) break;
+			v[ix] = zero;
+			}
+		if ((ix >= n) || (mark[ix] == zero)) { scan = ix;  continue; }
+		from = ix;  to = ix++;
+		for ( ; ix<n ; ix++)
+			{
+			if (mark[ix] == zero) break;
+			if (above? (v[ix] >= average) : (v[ix] <= average)) to = ix;
+			}
+		for (iy=from ; iy<=to ; iy++) v[iy] = one;
+		for (iy=to+1 ; iy<ix ; iy++) v[iy] = zero;
+		scan = ix;
+		}
+done:
+	free (mark);  free (recV);  free (recAt);
+	}
+
 /* add.c:909-923: genome-wide min and max, seeded with the first element of
  * the first (longest) chromosome */
 void orc_genome_minmax (const double* const* vecs, const uint32_t* lens, int nchrom, double* minOut, double* maxOut)

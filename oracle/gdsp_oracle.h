@@ -53,6 +53,8 @@ void orc_abs          (double* v, uint32_t n);
 void orc_genome_minmax(const double* const* vecs, const uint32_t* lens, int nchrom, double* minOut, double* maxOut);
 void orc_invert       (double* v, uint32_t n, double mid);
 void orc_map          (double* v, uint32_t n, const double* kin, const double* kout, uint32_t nknots);   /* map.c */
+void orc_clump        (double* v, uint32_t n, double average, uint32_t minLength, int above,
+                       double one, double zero);                                                   /* clump.c */
 
 /* percentile.c -- vecs/lens in the reference's processing order (longest first);
  * pThousandths[i] is the percentile in units of 0.001 %.  Returns the number of

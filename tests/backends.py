@@ -35,6 +35,7 @@ class OracleBackend:
     invert = staticmethod(cpu.invert)
     genome_minmax = staticmethod(cpu.genome_minmax)
     map_values = staticmethod(cpu.map_values)
+    clump = staticmethod(cpu.clump)
 
     def percentile(self, vecs, pts, window, lo, hi):
         return cpu.percentile(vecs, pts, window, lo, hi)
@@ -108,6 +109,9 @@ class GpuBackend:
 
     def map_values(self, x, kin, kout):
         return self.gd.map_values(x, kin, kout)
+
+    def clump(self, x, avg, L, above, one, zero):
+        return self.gd.clump(x, avg, L, above, one, zero)
 
     def genome_minmax(self, vecs):
         lo, hi, _ = self.gd.genome_minmax(vecs)

@@ -258,6 +258,32 @@ cli_case("cli_file_mask_variable", GENOME3,
          ["--precision=3", "=", "percentile", "50", "--quiet", "=", "input", "@sig@", "=", "mask", "@iv@", "--mask=percentile50"],
          SIGNAL3, {"iv": SORTED_IV, "sig": SIGNAL3})
 
+# ---- clump / anticlump (clump.c); appended last so the seeded generator leaves earlier cases unchanged.
+#      Depth against dyadic thresholds keeps the running sums exact (see gdsp_clump.hip).
+for kind in ("depth", "blocky", "islands"):
+    v = signal(kind, 3000)
+    for op in ("clump", "anticlump"):
+        for T, L in (("2", 20), ("1.5", 100), ("10", 7), ("0.25", 1)):
+            vector_case("%s_%s_T%s_L%d" % (op, kind, T.replace(".", "p"), L), [("chrA", 3000)],
+                        "= %s %s --length=%d" % (op, T, L), {"chrA": v})
+vector_case("clump_default_length", [("chrA", 2000)], "= clump 12", {"chrA": signal("depth", 2000)})
+vector_case("clump_one_zero", [("chrA", 2000)], "= clump 12 L=50 --one=7 --zero=-1", {"chrA": signal("depth", 2000)})
+vector_case("skimp_alias", [("chrA", 2000)], "= skimp 12 L=50", {"chrA": signal("depth", 2000)})
+vector_case("clump_all_below", [("chrA", 500)], "= clump 1000 L=5", {"chrA": signal("depth", 500)})
+vector_case("clump_all_above", [("chrA", 500)], "= clump -1 L=5", {"chrA": signal("depth", 500)})
+vector_case("clump_relative", [("c1", 2000), ("c2", 900)], "= clump 12 --length=CL/40",
+            {"c1": signal("depth", 2000, 0), "c2": signal("depth", 900, 1)})
+vector_case("clump_relative_max", [("c1", 2000), ("c2", 900)], "= anticlump 12 --length=max(0.02*CL,30)",
+            {"c1": signal("depth", 2000, 0), "c2": signal("depth", 900, 1)})
+vector_case("clump_longer_than_vector", [("chrA", 300)], "= clump 1 L=1K", {"chrA": signal("depth", 300)})
+vector_case("clump_whole_vector", [("chrA", 300)], "= clump 1 L=CL", {"chrA": signal("depth", 300) + 1})
+vector_case("clump_percentile_variable", [("c1", 2000), ("c2", 900)],       # --preserve: the signal survives percentile
+            "= percentile 75 --quiet --preserve=@keep@ = clump --average=percentile75 L=40",
+            {"c1": signal("depth", 2000, 0), "c2": signal("depth", 900, 1)}, ["percentile75"], files={"keep": ""})
+cli_case("cli_clump", APPENDIX_C_CH, ["--novalue", "=", "clump", "1.5", "L=8"], APPENDIX_C_IV)
+cli_case("cli_anticlump_show", APPENDIX_C_CH, ["--novalue", "--uncovered:show", "=", "anticlump", "0.5", "L=12", "--one=2"],
+         APPENDIX_C_IV)
+
 np.savez_compressed(os.path.join(HERE, "golden.npz"), **arrays)
 with open(os.path.join(HERE, "golden.json"), "w") as f:
     json.dump({"seed": SEED, "cases": cases}, f, indent=1)

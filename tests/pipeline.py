@@ -257,6 +257,37 @@ class Runner:
             mid = (lo + hi) / 2.0                       # add.c:925
         self._each(lambda x: self.b.invert(x, mid))
 
+    # ---- clump.c
+    def _clump(self, args, above):
+        avg, length, rel, one, zero = 0.0, 100, 0.0, 1.0, 0.0
+        for a in args:
+            k, v = _kv(a)
+            if k in ("--average", "T", "--T"):
+                avg = self.globals[v]
+            elif k in ("--length", "L", "--L"):
+                length, rel = parse_clump_length(v)
+            elif k in ("--one", "O", "--O"):
+                one = to_value(v)
+            elif k in ("--zero", "Z", "--Z"):
+                zero = to_value(v)
+            elif not a.startswith("--"):
+                avg = to_value(a)
+
+        def run(x):
+            n = self.b.length(x)
+            L = max(length, int(np.uint32(rel * n))) if rel > 0 else length      # clump.c:512-518
+            return self.b.clump(x, avg, L, above, one, zero)
+        self._each(run)
+
+    def op_clump(self, args):
+        self._clump(args, True)
+
+    def op_anticlump(self, args):
+        self._clump(args, False)
+
+    op_anti_clump = op_anticlump
+    op_skimp = op_anticlump
+
     # ---- map.c
     def op_map(self, args):
         text = self.files[args[0].strip("@")]
@@ -283,7 +314,7 @@ class Runner:
                 lo = to_value(v)
             elif k == "--max":
                 hi = to_value(v)
-            elif a in ("--quiet",):
+            elif a in ("--quiet",) or k == "--preserve":
                 pass
             elif not a.startswith("--"):
                 spec = a
@@ -292,6 +323,25 @@ class Runner:
         if count:
             for pt, val in zip(pts, vals):
                 self.globals[percentile_name(pt)] = val
+
+
+def parse_clump_length(text, max_ok=True):
+    """clump.c:353-485: <n> | CL | CL*f | f*CL | CL/k | max(relative, n) -> (minLength, relativeLength)."""
+    if max_ok and text.startswith("max(") and text.endswith(")"):
+        a, b = text[4:-1].split(",", 1)
+        la, ra = parse_clump_length(a, False)
+        lb, rb = parse_clump_length(b, False)
+        assert (ra > 0) != (rb > 0)
+        return (lb, ra) if ra > 0 else (la, rb)
+    if text == "CL":
+        return 0, 1.0
+    if text.startswith("CL*"):
+        return 0, float(text[3:])
+    if text.endswith("*CL"):
+        return 0, float(text[:-3])
+    if text.startswith("CL/"):
+        return 0, 1.0 / float(text[3:])
+    return to_int(text), 0.0
 
 
 def parse_percentile_spec(spec):

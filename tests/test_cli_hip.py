@@ -99,8 +99,10 @@ def test_errors_are_loud(tmp_path):
     chroms = "chr1 100\n"
     rc, out, err = run(["=", "nosuchop"], "", chroms, tmp_path)
     assert rc != 0 and "not a known operation" in err
-    rc, out, err = run(["=", "clump", "3"], "", chroms, tmp_path)
-    assert rc != 0 and "outside this build" in err
+    rc, out, err = run(["=", "clump", "3", "--length=0"], "", chroms, tmp_path)
+    assert rc != 0 and "minimum length can't be zero" in err
+    rc, out, err = run(["=", "clump", "--average=nothere"], "chr1 1 2 3\n", chroms, tmp_path)
+    assert rc != 0 and "no such variable" in err
     rc, out, err = run(["--novalue"], "chr1 90 120\n", chroms, tmp_path)
     assert rc != 0 and "beyond the end of the chromosome" in err
     rc, out, err = run(["--novalue", "--cliptochromosome"], "chr1 90 120\n", chroms, tmp_path)

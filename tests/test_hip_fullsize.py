@@ -147,3 +147,17 @@ def test_running_sums_full_chromosome(gd, depth):
     last = fetch(total, N - 1, 1)[0]
     s, e, v = gd.report_runs(depth)
     assert last == float(np.sum((e - s).astype(np.float64) * v))              # exact in f64: < 2^53
+
+
+def test_clump_full_chromosome(gd, depth):
+    """clump has unbounded reach (a qualifying stretch can be any length), so the whole chromosome goes
+    through the oracle: one sequential O(n) walk, a few seconds."""
+    x = depth.numpy()
+    T = float(np.floor(x.mean())) + 0.5
+    got = gd.clump(depth.copy(), T, 1000, True, 1.0, 0.0).numpy()
+    want = cpu.clump(x, T, 1000, True)
+    assert bits_equal(got, want), int(np.flatnonzero(got != want)[0])
+    assert 0 < int(got.sum()) < N
+    del want
+    got = gd.clump(depth.copy(), T, N // 50, False, 1.0, 0.0).numpy()            # --length=CL/50
+    assert bits_equal(got, cpu.clump(x, T, N // 50, False))

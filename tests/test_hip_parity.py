@@ -37,7 +37,7 @@ def _tolerant(name):
 def test_hip_matches_reference_golden_vectors(case, gold, gd):
     chroms = [tuple(c) for c in case["chroms"]]
     r = Runner(GpuBackend(), chroms, gold.inputs(case), case.get("files")).run(case["pipeline"])
-    if "percentile" in case["pipeline"]:
+    if "percentile" in case["pipeline"] and "--preserve" not in case["pipeline"]:
         # non-destructive here (the reference scrambles the signal): inputs must be intact
         for c, _ in chroms:
             assert bits_equal(r.result(c), gold.inputs(case)[c])
@@ -518,3 +518,29 @@ def test_windows_beyond_one_lds_tile(n, W, gd):
         dy = gd.DeviceVector.from_numpy(y)
         assert bits_equal(gd.localmax(dy, N).numpy(), cpu.local_extrema(y, N, 1, 0.0))
         assert bits_equal(gd.localmin(dy, N).numpy(), cpu.local_extrema(y, N, 0, cpu.DBL_MAX))
+
+
+# ------------------------------------------------------------------- clump ----
+@pytest.mark.parametrize("n", [1, 2, 100, 4095, 4096, 4097, 100003, 5000011])
+@pytest.mark.parametrize("L", [1, 7, 100, 5000])
+def test_clump_anticlump_bit_exact(n, L, gd):
+    """clump.c:494-736 by whole-vector scans; depth against a dyadic threshold keeps every running sum exact.
+    n = 5000011 needs more than 1024 scan chunks (two totals per thread in the offsets pass)."""
+    rng = np.random.default_rng(n + L)
+    x = _signal("depth", n, rng)
+    for T in (float(np.floor(np.median(x))) + 0.5, float(np.floor(x.mean())) - 0.25):
+        for above in (True, False):
+            got = gd.clump(gd.DeviceVector.from_numpy(x), T, L, above, 1.0, 0.0).numpy()
+            want = cpu.clump(x, T, L, above)
+            assert bits_equal(got, want), (T, above, first_diff(got, want))
+
+
+def test_clump_degenerate_inputs(gd):
+    x = np.full(5000, 3.0)
+    for T, above, want in ((4.0, True, 0.0), (3.0, True, 1.0), (2.0, False, 0.0), (3.0, False, 1.0)):
+        got = gd.clump(gd.DeviceVector.from_numpy(x), T, 100, above, 1.0, 0.0).numpy()
+        assert np.all(got == want) and bits_equal(got, cpu.clump(x, T, 100, above))
+    got = gd.clump(gd.DeviceVector.from_numpy(x), 3.0, 5001, True, 1.0, 0.0).numpy()     # longer than the vector
+    assert np.all(got == 0.0)
+    got = gd.clump(gd.DeviceVector.from_numpy(x), 3.0, 5000, True, 9.0, -9.0).numpy()    # exactly the vector
+    assert np.all(got == 9.0)

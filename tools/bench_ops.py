@@ -68,6 +68,10 @@ timeit("sum W=100", lambda: gd.window_sum(a, 100, stream=S), prep=lambda: copy_i
 work = gd.DeviceBuffer(gd.lib().gdsp_cumulative_sum_work(n))
 timeit("cumulativesum", lambda: gd.call("gdsp_cumulative_sum", a.ptr, n, gd.C.c_void_p(work.ptr), gd._sp(S)),
        prep=lambda: copy_into(a, src))
+cwork = gd.DeviceBuffer(gd.lib().gdsp_clump_work(n))
+timeit("clump T=30.5 L=1000", lambda: gd.call("gdsp_clump", a.ptr, n, 30.5, 1000, 1, 1.0, 0.0, gd.C.c_void_p(cwork.ptr), gd._sp(S)),
+       prep=lambda: copy_into(a, src))
+del cwork
 hist = gd.DeviceBuffer((8192 + 2) * 8)
 import ctypes as C  # noqa: E402
 timeit("select histogram pass (depth)", lambda: gd.call("gdsp_select_histogram", src.ptr, n, 1, -gd.DBL_MAX, gd.DBL_MAX, 52, 12,
