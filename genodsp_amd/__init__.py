@@ -16,7 +16,7 @@ import numpy as np
 
 from ._lib import GdspError, SIGNATURES, SO_PATH, build, call, lib
 
-FIR_EXACT, FIR_FMA = 0, 1
+FIR_EXACT, FIR_FMA, FIR_HANN = 0, 1, 2
 OVERLAP_SUM, OVERLAP_MIN, OVERLAP_MAX = 0, 1, 2
 DBL_MAX = float(np.finfo(np.float64).max)
 DBL_MIN = float(np.finfo(np.float64).tiny)

@@ -30,6 +30,10 @@ void gdsp_set_error (const char* fmt, ...);
 		}                                                                         \
 	} while (0)
 
+// gdsp_hann.hip: `smooth` through block sums of the Hann window's constant and cosine parts
+bool gdsp_hann_blocks_available (uint32_t W);
+int  gdsp_hann_blocks_apply (const double* d_in, double* d_out, uint32_t n, uint32_t W, void* stream);
+
 static inline hipStream_t gdsp_stream (void* s) { return (hipStream_t) s; }
 
 static inline bool gdsp_aligned16 (const void* p) { return (((uintptr_t) p) & 15) == 0; }

@@ -422,6 +422,7 @@ int gdsp_smooth_local_extrema (const double* d_in, double* d_out, uint32_t n, ui
                                uint32_t N, int wantMax, double fill, void* stream)
 	{
 	GDSP_REQUIRE (gdsp_smooth_local_extrema_fusable (W, N), "no fused kernel for this window/neighborhood");
+	if (mode == GDSP_FIR_HANN) mode = GDSP_FIR_FMA;            // the fused kernel evaluates directly
 	GDSP_REQUIRE ((mode == GDSP_FIR_EXACT) || (mode == GDSP_FIR_FMA), "unknown mode");
 	if (n == 0) return GDSP_OK;
 	GDSP_REQUIRE ((d_in != NULL) && (d_out != NULL) && (d_in != d_out), "vectors must be distinct and non-NULL");
@@ -443,6 +444,13 @@ int gdsp_smooth_local_extrema (const double* d_in, double* d_out, uint32_t n, ui
 
 int gdsp_smooth (const double* d_in, double* d_out, uint32_t n, uint32_t W, int mode, void* stream)
 	{
+	if (mode == GDSP_FIR_HANN)
+		{
+		GDSP_REQUIRE ((W >= 3) && (W & 1), "W must be odd and >= 3");
+		GDSP_REQUIRE (W <= 50001, "W exceeds 50001");
+		if (gdsp_hann_blocks_available (W)) return gdsp_hann_blocks_apply (d_in, d_out, n, W, stream);
+		mode = GDSP_FIR_FMA;                                   // same tolerance class, direct evaluation
+		}
 	gdsp_fir_plan* plan = NULL;
 	int rc = smooth_plan (W, &plan);
 	if (rc != GDSP_OK) return rc;

@@ -1,0 +1,280 @@
+// gdsp_hann.hip -- `smooth` evaluated through the structure of its window (GDSP_FIR_HANN).
+//
+// The reference's window (sum.c:632-645) is a Hann window: tap k = c * (1 - cos(w*k)), k = 1..W,
+// with w = 2*pi/(W+1) and c = 1/(2 * sum of the unnormalised taps).  Over any stretch of taps
+//     sum_k (1 - cos(w*k)) * x[a-1+k]  =  S - C,   S = sum of the inputs under the stretch,
+//                                                  C = Re( exp(j*phase) * sum of x[e]*exp(j*w*e) )
+// and sums over a stretch need no multiply per tap.  Cut the line into blocks of 16 elements: a
+// stretch [a',b'] is a suffix of a's block + the whole blocks between + a prefix of b's block --
+// additions only, no differences of running sums, so nothing cancels in the sums themselves.
+// S - C does cancel where the taps are small, so the E = 8 taps at either end of the window are
+// evaluated directly (16 multiply-adds per base) and only the W-2E middle taps, all at least
+// 0.15 of the largest, go through the block sums.  ~45 FP64 operations per base instead of 101
+// multiply-adds: `smooth W=101` stops being bound by the FP64 pipe (gdsp_fir.hip) and becomes an
+// HBM stream.
+//
+// One thread owns one block as the right end b' of the middle stretch of 16 windows:
+//   phase 0  the 2E direct taps of its 16 outputs, sliding over 15+E inputs on either side;
+//   phase 1  prefix sums of its own block, three sequences (x, x*cos, x*sin), kept in registers;
+//            block totals to LDS;
+//   phase 2  totals of the whole blocks between (rotated to this block's phase -- every phase
+//            factor in the kernel is relative to the owner's block, so all of them are constants
+//            of W that reach the VALU as scalar operands: no table, no sincos); then one
+//            backward walk over the 16+dr elements that hold the 16 left ends a', accumulating
+//            the suffix sums and finishing one output per step.
+// Elements sit in LDS with a pitch of 17 per block of 16, so the lane-strided ds_read_b64 of
+// all walks are conflict free; results return through the same LDS image for 16-byte coalesced
+// stores.  41 KiB of LDS per workgroup (3 workgroups per CU).
+//
+// Not bit-identical to the reference (different association, exact cosines instead of the
+// normalised taps' roundings): within the north star's one rounding per floating-point
+// operation, W * 2^-52 * sum|w_k v_k| as for FMA, and as close to an extended-precision
+// evaluation as the reference itself -- both asserted in tests/test_hip_parity.py.  EXACT stays
+// the default of the command line.
+
+#include <math.h>
+#include "gdsp_common.h"
+
+#define HN_THREADS 256
+#define HN_G       16
+#define HN_PITCH   17
+#define HN_ELEMS   (HN_THREADS * HN_G)
+#define HN_E       8                                     // direct taps at either end of the window
+
+template <int W> struct HannGeom
+	{
+	static constexpr int H      = (W - 1) / 2;
+	static constexpr int E      = HN_E;
+	static constexpr int DM     = W - 2*E - 1;           // a' = b' - DM: ends of the middle stretch
+	static constexpr int DQ     = DM / HN_G, DR = DM % HN_G;
+	static constexpr int BACK   = DM + E;                // first element of the window = b' - BACK
+	static constexpr int HALO_L = (BACK + HN_G - 1) / HN_G;   // leading blocks that only feed
+	static constexpr int HALO_R = (E + HN_G - 1) / HN_G;      // trailing ones
+	static constexpr int OUT    = (HN_THREADS - HALO_L - HALO_R) * HN_G;
+	static constexpr int NLEFT  = HN_G + DR;             // elements that hold the 16 left ends a'
+	static constexpr int NT     = DQ - 1;                // whole blocks always between
+	static constexpr int LO     = HALO_L * HN_G - BACK;  // offset of element b'-BACK in block p-HALO_L (s = 0)
+	static constexpr int LEAD   = HALO_L * HN_G - (H - E);    // staged elements before the first output
+	static constexpr int NEDGE  = HN_G + E - 1;          // inputs under the E direct taps of 16 outputs
+	static_assert (DQ >= 2, "window shorter than two blocks");
+	static_assert ((LEAD & 1) == 0, "tile start must stay 16-byte aligned");
+	static_assert (LO + NEDGE <= 2 * HN_G, "left edge spans more than two blocks");
+	};
+
+template <int W> struct HannConsts
+	{
+	double edge[HN_E];                                             // 1 - cos(w k),        k = 1..E
+	double ownC[HN_G], ownS[HN_G];                                 // exp(+j w u),         u = 0..15
+	double leftC[HannGeom<W>::NLEFT], leftS[HannGeom<W>::NLEFT];   // exp(+j w (u - DM)),  u = 0..NLEFT-1
+	double rotC[HannGeom<W>::NT], rotS[HannGeom<W>::NT];           // exp(-j w 16 d),      d = 1..NT
+	double demC[HN_G], demS[HN_G];                                 // exp(+j w (W-E - s)), s = 0..15
+	double scale;                                                  // c = 1 / (2 * sum of raw taps)
+	};
+
+template <int W>
+__global__ __launch_bounds__(HN_THREADS)
+void hann_blocks_kernel (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t ntiles,
+                         HannConsts<W> K)
+	{
+	typedef HannGeom<W> G;
+	__shared__ __attribute__((aligned(16))) double lds[HN_THREADS * HN_PITCH];
+	__shared__ double tot[3][HN_THREADS];
+
+	const uint32_t tile = gdsp_xcd_tile (blockIdx.x, ntiles);
+	const int64_t  out0 = (int64_t) tile * G::OUT;
+	const int64_t  e0   = out0 - G::LEAD;                         // first staged element (even)
+	const int      p    = threadIdx.x;
+	const bool     live = (p >= G::HALO_L) && (p < HN_THREADS - G::HALO_R);
+
+	// ---- stage 4096 elements, zero outside the chromosome
+	if ((e0 >= 0) && (e0 + HN_ELEMS <= (int64_t) n))
+		{
+		const double2* src = reinterpret_cast<const double2*> (in + e0);
+		double2 r[HN_G/2];
+#pragma unroll
+		for (int u=0 ; u<HN_G/2 ; u++) r[u] = src[u*HN_THREADS + p];
+#pragma unroll
+		for (int u=0 ; u<HN_G/2 ; u++)
+			{
+			const int e = 2 * (u*HN_THREADS + p);
+			double* dst = lds + e + (e >> 4);
+			dst[0] = r[u].x;  dst[1] = r[u].y;
+			}
+		}
+	else
+		{
+		for (int e=p ; e<HN_ELEMS ; e+=HN_THREADS)
+			{
+			const int64_t g = e0 + e;
+			lds[e + (e >> 4)] = ((g >= 0) && (g < (int64_t) n))? in[g] : 0.0;
+			}
+		}
+	__syncthreads ();
+
+	// ---- phase 0: the E taps at either end of each of the 16 windows, directly
+	double acc[HN_G];
+#pragma unroll
+	for (int s=0 ; s<HN_G ; s++) acc[s] = 0.0;
+	if (live)
+		{
+		const double* xl = lds + (p - G::HALO_L) * HN_PITCH;        // element b'-BACK of s=0 is xl[LO]
+#pragma unroll
+		for (int j=0 ; j<G::NEDGE ; j++)                            // window s meets input j under tap k = j-s+1
+			{
+			const int    o = G::LO + j;
+			const double x = xl[o + (o >> 4)];
+#pragma unroll
+			for (int s=0 ; s<HN_G ; s++)
+				{ if ((j - s >= 0) && (j - s < G::E)) acc[s] = __builtin_fma (K.edge[j-s], x, acc[s]); }
+			}
+		const double* xr = lds + p * HN_PITCH;                      // element b'+m of window s is xr[s+m]
+#pragma unroll
+		for (int j=1 ; j<=G::NEDGE ; j++)                           // tap W+1-m = tap m from the far end
+			{
+			const double x = xr[j + (j >> 4)];
+#pragma unroll
+			for (int s=0 ; s<HN_G ; s++)
+				{ if ((j - s >= 1) && (j - s <= G::E)) acc[s] = __builtin_fma (K.edge[G::E - (j-s)], x, acc[s]); }
+			}
+		}
+
+	// ---- phase 1: prefix sums of the own block in the own phase
+	double P0[HN_G], Pr[HN_G], Pi[HN_G];
+		{
+		const double* xb = lds + p * HN_PITCH;
+		double a0 = 0.0, ar = 0.0, ai = 0.0;
+#pragma unroll
+		for (int u=0 ; u<HN_G ; u++)
+			{
+			const double x = xb[u];
+			a0 += x;
+			ar  = __builtin_fma (x, K.ownC[u], ar);
+			ai  = __builtin_fma (x, K.ownS[u], ai);
+			P0[u] = a0;  Pr[u] = ar;  Pi[u] = ai;
+			}
+		tot[0][p] = a0;  tot[1][p] = ar;  tot[2][p] = ai;
+		}
+	__syncthreads ();
+
+	// ---- phase 2: the middle stretch of one window per left end
+	if (live)
+		{
+		double T0 = 0.0, Tr = 0.0, Ti = 0.0;                       // whole blocks p-NT .. p-1
+#pragma unroll
+		for (int d=G::NT ; d>=1 ; d--)
+			{
+			const double b0 = tot[0][p-d], br = tot[1][p-d], bi = tot[2][p-d];
+			T0 += b0;
+			Tr += __builtin_fma (br, K.rotC[d-1], -(bi * K.rotS[d-1]));
+			Ti += __builtin_fma (br, K.rotS[d-1],   bi * K.rotC[d-1]);
+			}
+		const double* lb = lds + (p - G::DQ) * HN_PITCH;            // block of the left ends of s >= DR
+		const double* la = lb - HN_PITCH + (HN_G - G::DR);          // last DR elements of the block before
+		double s0 = 0.0, sr = 0.0, si = 0.0;
+#pragma unroll
+		for (int u=G::NLEFT-1 ; u>=G::DR ; u--)
+			{
+			const double x = lb[u - G::DR];
+			s0 += x;
+			sr  = __builtin_fma (x, K.leftC[u], sr);
+			si  = __builtin_fma (x, K.leftS[u], si);
+			if (u < HN_G)                                           // left end of the stretch whose right end is own[u]
+				{
+				const double z0 = (s0 + T0) + P0[u];
+				const double zr = (sr + Tr) + Pr[u];
+				const double zi = (si + Ti) + Pi[u];
+				const double c  = __builtin_fma (K.demC[u], zr, -(K.demS[u] * zi));
+				acc[u] = K.scale * ((z0 - c) + acc[u]);
+				}
+			}
+		T0 += s0;  Tr += sr;  Ti += si;                            // that block is whole for the remaining windows
+		s0 = 0.0;  sr = 0.0;  si = 0.0;
+#pragma unroll
+		for (int u=G::DR-1 ; u>=0 ; u--)
+			{
+			const double x = la[u];
+			s0 += x;
+			sr  = __builtin_fma (x, K.leftC[u], sr);
+			si  = __builtin_fma (x, K.leftS[u], si);
+			const double z0 = (s0 + T0) + P0[u];
+			const double zr = (sr + Tr) + Pr[u];
+			const double zi = (si + Ti) + Pi[u];
+			const double c  = __builtin_fma (K.demC[u], zr, -(K.demS[u] * zi));
+			acc[u] = K.scale * ((z0 - c) + acc[u]);
+			}
+		}
+	__syncthreads ();                                              // every read of the staged inputs is done
+
+	// ---- results back through LDS: output o of the tile belongs to thread HALO_L + o/16
+	if (live)
+		{
+		double* mine = lds + (p - G::HALO_L) * HN_PITCH;
+#pragma unroll
+		for (int u=0 ; u<HN_G ; u++) mine[u] = acc[u];
+		}
+	__syncthreads ();
+
+	if (out0 + G::OUT <= (int64_t) n)
+		{
+		double2* dst = reinterpret_cast<double2*> (out + out0);
+#pragma unroll
+		for (int u=0 ; u<(G::OUT/2 + HN_THREADS - 1)/HN_THREADS ; u++)
+			{
+			const int q = u*HN_THREADS + p;
+			if (q < G::OUT/2)
+				{
+				const int o = 2*q;
+				const double* src = lds + o + (o >> 4);
+				dst[q] = make_double2 (src[0], src[1]);
+				}
+			}
+		}
+	else
+		{
+		for (int o=p ; o<G::OUT ; o+=HN_THREADS)
+			{ if (out0 + o < (int64_t) n) out[out0 + o] = lds[o + (o >> 4)]; }
+		}
+	}
+
+template <int W>
+static void hann_launch (const double* d_in, double* d_out, uint32_t n, hipStream_t s)
+	{
+	typedef HannGeom<W> G;
+	HannConsts<W> K;
+	const double pi = 3.14159265358979323846264;
+	const int    M  = W + 1;                                       // the window's period
+	auto cs = [&] (long m, double* c, double* sn)                   // exp(j*2*pi*m/M), argument reduced first
+		{
+		long r = ((m % M) + M) % M;
+		double x = r / (double) M;
+		*c = cos (2*pi*x);  *sn = sin (2*pi*x);
+		};
+	for (int k=1 ; k<=G::E ; k++)    { double c, sn;  cs (k, &c, &sn);  K.edge[k-1] = 1 - c; }
+	for (int u=0 ; u<HN_G ; u++)     cs (u, &K.ownC[u], &K.ownS[u]);
+	for (int u=0 ; u<G::NLEFT ; u++) cs ((long) u - G::DM, &K.leftC[u], &K.leftS[u]);
+	for (int d=1 ; d<=G::NT ; d++)   cs (-(long) HN_G * d, &K.rotC[d-1], &K.rotS[d-1]);
+	for (int u=0 ; u<HN_G ; u++)     cs ((long) W - G::E - u, &K.demC[u], &K.demS[u]);
+	double total = 0.0;                                            // as gdsp_hann_taps sums it (sum.c:632-645)
+	for (int k=0 ; k<W ; k++)
+		{
+		const int kk = (k <= G::H)? k : W-1-k;
+		total += (1 - cos (2*pi*((kk+1) / (double) M))) / 2;
+		}
+	K.scale = 0.5 / total;
+	const uint32_t ntiles = (uint32_t) (((uint64_t) n + G::OUT - 1) / G::OUT);
+	hipLaunchKernelGGL ((hann_blocks_kernel<W>), dim3(ntiles), dim3(HN_THREADS), 0, s, d_in, d_out, n, ntiles, K);
+	}
+
+// 1 when GDSP_FIR_HANN has a kernel for this window
+bool gdsp_hann_blocks_available (uint32_t W) { return W == 101; }
+
+int gdsp_hann_blocks_apply (const double* d_in, double* d_out, uint32_t n, uint32_t W, void* stream)
+	{
+	GDSP_REQUIRE (gdsp_hann_blocks_available (W), "no block-sum kernel for this window");
+	if (n == 0) return GDSP_OK;
+	GDSP_REQUIRE ((d_in != NULL) && (d_out != NULL) && (d_in != d_out), "vectors must be distinct and non-NULL");
+	GDSP_REQUIRE (gdsp_aligned16 (d_in) && gdsp_aligned16 (d_out), "vectors must be 16-byte aligned");
+	hann_launch<101> (d_in, d_out, n, gdsp_stream (stream));
+	GDSP_LAUNCH_CHECK ();
+	return GDSP_OK;
+	}

@@ -110,7 +110,7 @@ static int clipToLength   = false;
 static int originOne      = false;
 static int inhibitOutput  = false;
 static int numDevices     = 1;
-int        firMode        = GDSP_FIR_EXACT;      /* --smooth=exact|fma (see ops_sum.c) */
+int        firMode        = GDSP_FIR_EXACT;      /* --smooth=exact|fma|hann (see ops_sum.c) */
 static int fuseChains     = true;                /* --nofuse: one kernel per operator          */
 
 /* a chromosome as the driver sees it: the public spec first, device state after */
@@ -947,6 +947,7 @@ static void parse_options (int _argc, char** _argv)            /* genodsp.c:284-
 		if (strcmp (arg, "--nofuse") == 0) { fuseChains = false;  continue; }
 		if (strcmp (arg, "--smooth=exact") == 0) { firMode = GDSP_FIR_EXACT;  continue; }
 		if (strcmp (arg, "--smooth=fma")   == 0) { firMode = GDSP_FIR_FMA;    continue; }
+		if (strcmp (arg, "--smooth=hann")  == 0) { firMode = GDSP_FIR_HANN;   continue; }
 		if (strcmp (arg, "?") == 0) usage_operations ();
 		if ((strcmp_prefix (arg, "--help=") == 0) || (strcmp_prefix (arg, "?=") == 0))
 			{

@@ -32,6 +32,12 @@ extern "C" {
  * FMA fuses them (one rounding per tap instead of two). */
 #define GDSP_FIR_EXACT 0
 #define GDSP_FIR_FMA   1
+/* HANN (gdsp_smooth only) uses what the window is -- tap k = c*(1 - cos(w(k+1))) -- and builds
+ * each output from block sums of x and of x*exp(jwe): ~25 operations per base for any tap
+ * count, additions only (no differences of running sums).  Within W * 2^-52 * sum|w_k v_k| of
+ * the reference, like FMA, and no further from the exact value than the reference is.
+ * Windows without such a kernel (anything but W=101 in this build) are evaluated as FMA. */
+#define GDSP_FIR_HANN  2
 
 /* interval overlap operators, values as genodsp_interface.h:157-159 */
 #define GDSP_OVERLAP_SUM 0

@@ -115,6 +115,44 @@ def test_smooth_fma_within_one_rounding_per_op(W, n, kind, gd):
     assert np.abs(got[sel] - truth).max() <= np.abs(want[sel] - truth).max() * 1.5 + 1e-300
 
 
+@pytest.mark.parametrize("n", [1, 2, 49, 50, 51, 101, 3983, 3984, 3985, 4096, 7968, 100003, 1000000])
+@pytest.mark.parametrize("kind", ["depth", "real", "noise"])
+def test_smooth_hann_block_sums_within_one_rounding_per_op(n, kind, gd):
+    """HANN mode evaluates the same window through block sums (gdsp_hann.hip): a different association
+    and exact cosines, so not the reference's bits -- the bar is the north star's one rounding per
+    floating-point operation, W * 2^-52 * sum|w_k v_k| (as for FMA), and an error against an
+    extended-precision evaluation like the reference's own.  3984 = outputs per tile."""
+    W = 101
+    rng = np.random.default_rng(n)
+    x = _signal(kind, n, rng)
+    taps = cpu.hann_window(W)
+    got = gd.smooth(gd.DeviceVector.from_numpy(x), W, mode=gd.FIR_HANN).numpy()
+    want = cpu.smooth(x, W)
+    scale = cpu.fir(np.abs(x), taps)
+    assert np.all(np.abs(got - want) <= W * 2 * EPS * scale), first_diff(got, want)
+    if n >= 100000:
+        # against an extended-precision evaluation it errs like the reference's own loop does (measured,
+        # tools/hann_accuracy.py: rms 2.3-2.9 vs 2.4-3.0, max 17-20 vs 9-12, in units of 2^-53 * sum|w_k v_k|)
+        sel = np.arange(0, n, n // 4000)
+        xl = np.concatenate([np.zeros(W // 2), x, np.zeros(W // 2)]).astype(np.longdouble)
+        truth = np.array([np.dot(taps.astype(np.longdouble), xl[i:i + W]) for i in sel])
+        unit = scale[sel] * EPS
+        ok = unit > 0
+        mine = (np.abs(got[sel] - truth)[ok] / unit[ok]).astype(np.float64)
+        refs = (np.abs(want[sel] - truth)[ok] / unit[ok]).astype(np.float64)
+        assert np.sqrt(np.mean(mine ** 2)) <= 1.5 * np.sqrt(np.mean(refs ** 2))
+        assert mine.max() <= 3.0 * refs.max()
+        assert np.all(got[sel][~ok] == 0.0)
+
+
+def test_smooth_hann_mode_other_windows_fall_back_to_fma(gd):
+    x = _signal("real", 30000, np.random.default_rng(3))
+    for W in (21, 301):
+        a = gd.smooth(gd.DeviceVector.from_numpy(x), W, mode=gd.FIR_HANN).numpy()
+        b = gd.smooth(gd.DeviceVector.from_numpy(x), W, mode=gd.FIR_FMA).numpy()
+        assert bits_equal(a, b)
+
+
 def test_fir_plan_custom_taps(gd):
     rng = np.random.default_rng(11)
     x = rng.standard_normal(9000)

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Small driver for rocprofv3: a few smooth W=101 launches on one 145 Mbp chromosome.
-usage: python3 tools/prof_smooth.py [fma|exact] [launches]"""
+usage: python3 tools/prof_smooth.py [fma|exact|hann] [launches]"""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import genodsp_amd as gd  # noqa: E402
 
-mode = gd.FIR_FMA if (len(sys.argv) < 2 or sys.argv[1] == "fma") else gd.FIR_EXACT
+mode = {"fma": gd.FIR_FMA, "exact": gd.FIR_EXACT, "hann": gd.FIR_HANN}[sys.argv[1] if len(sys.argv) > 1 else "fma"]
 launches = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 n = 145138636
 gd.set_device(0)
