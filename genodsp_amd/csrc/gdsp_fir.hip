@@ -422,7 +422,7 @@ int gdsp_smooth_local_extrema (const double* d_in, double* d_out, uint32_t n, ui
                                uint32_t N, int wantMax, double fill, void* stream)
 	{
 	GDSP_REQUIRE (gdsp_smooth_local_extrema_fusable (W, N), "no fused kernel for this window/neighborhood");
-	if (mode == GDSP_FIR_HANN) mode = GDSP_FIR_FMA;            // the fused kernel evaluates directly
+	if (mode == GDSP_FIR_HANN) mode = GDSP_FIR_FMA;            // ties must stay ties under the strict comparisons: direct taps
 	GDSP_REQUIRE ((mode == GDSP_FIR_EXACT) || (mode == GDSP_FIR_FMA), "unknown mode");
 	if (n == 0) return GDSP_OK;
 	GDSP_REQUIRE ((d_in != NULL) && (d_out != NULL) && (d_in != d_out), "vectors must be distinct and non-NULL");

@@ -29,8 +29,14 @@
 // Not bit-identical to the reference (different association, exact cosines instead of the
 // normalised taps' roundings): within the north star's one rounding per floating-point
 // operation, W * 2^-52 * sum|w_k v_k| as for FMA, and as close to an extended-precision
-// evaluation as the reference itself -- both asserted in tests/test_hip_parity.py.  EXACT stays
-// the default of the command line.
+// evaluation as the reference itself -- both asserted in tests/test_hip_parity.py.
+// It is also not shift invariant: which additions meet first depends on where an output falls in
+// its block of 16, so a flat stretch of input gives outputs that differ in their last bits, where
+// the direct kernels (every output the same operations in the same order) give one repeated value.
+// Operators that compare neighbours strictly (localmax after smooth) and the run collapse of the
+// report see such ties; that is why EXACT stays the default of the command line, why the fused
+// smooth+extrema kernel evaluates directly whatever the mode, and why this mode is for the
+// smoothed track as a floating-point result.
 
 #include <math.h>
 #include "gdsp_common.h"

@@ -36,6 +36,8 @@ extern "C" {
  * each output from block sums of x and of x*exp(jwe): ~25 operations per base for any tap
  * count, additions only (no differences of running sums).  Within W * 2^-52 * sum|w_k v_k| of
  * the reference, like FMA, and no further from the exact value than the reference is.
+ * Unlike EXACT and FMA it is not shift invariant (a flat input gives outputs that differ in
+ * their last bits), so gdsp_smooth_local_extrema evaluates HANN as FMA.
  * Windows without such a kernel (anything but W=101 in this build) are evaluated as FMA. */
 #define GDSP_FIR_HANN  2
 

@@ -156,3 +156,30 @@ def test_sharded_driver_gives_the_same_output(tmp_path, monkeypatch):
         assert rc == 0, err
         outs.append((out, [l for l in err.splitlines() if l.startswith("percentile")]))
     assert outs[0] == outs[1]
+
+
+def test_smooth_arithmetic_modes_on_the_command_line(tmp_path):
+    """--smooth=exact (default) prints the reference's digits; fma and hann are within one rounding per
+    operation, far below what --precision=9 shows on this signal."""
+    import numpy as np
+    rng = np.random.default_rng(8)
+    n = 9000
+    lines = []
+    for _ in range(900):
+        s = int(rng.integers(0, n - 200))
+        lines.append("chrQ %d %d %d" % (s, s + int(rng.integers(20, 200)), int(rng.integers(1, 9))))
+    iv = "\n".join(lines) + "\n"
+    outs = {}
+    for mode in ("exact", "fma", "hann"):
+        rc, out, err = run(["--precision=9", "--smooth=" + mode, "=", "smooth", "W=101"], iv, "chrQ %d\n" % n, tmp_path)
+        assert rc == 0, err
+        v = np.zeros(n)
+        for l in out.splitlines():                   # runs of equal values are collapsed: expand them
+            f = l.split()
+            v[int(f[1]):int(f[2])] = float(f[3])
+        outs[mode] = v
+        assert len(out.splitlines()) > 1000
+    for mode in ("fma", "hann"):
+        assert np.abs(outs[mode] - outs["exact"]).max() <= 2e-9
+    rc, out, err = run(["--smooth=nosuch"], "", "chrQ 10\n", tmp_path)
+    assert rc != 0

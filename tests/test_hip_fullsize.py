@@ -83,6 +83,17 @@ def test_smooth_w101_full_chromosome(gd, real):
     fma = gd.smooth(real, 101, mode=gd.FIR_FMA)
     stencil_check(fma, lambda x: cpu.smooth(x, 101), 1, 50, rng, exact=False,
                   bound_fn=lambda x: 101 * 2.0 ** -52 * cpu.fir(np.abs(x), taps))
+    del fma
+    hann = gd.smooth(real, 101, mode=gd.FIR_HANN)                 # seams of its 3984-output tiles included
+    rng2 = np.random.default_rng(9)
+    for s in [0, N - 6000, 3984 * 31000 - 3000, 3984 * 62000 - 3000] + [int(v) for v in rng2.integers(0, N - 6000, 4)]:
+        x, left, right = regenerate(1, s, 6000, 50)
+        want = cpu.smooth(x, 101)[left:left + 6000]
+        bound = (101 * 2.0 ** -52 * cpu.fir(np.abs(x), taps))[left:left + 6000]
+        assert np.all(np.abs(fetch(hann, s, 6000) - want) <= bound), s
+    lo_h, hi_h, _ = gd.genome_minmax([hann])
+    assert lo_in <= lo_h + 1e-9 and hi_h <= hi_in * (1 + 1e-12)
+    del hann
     # the index output of config 3: peaks of the smoothed track
     peaks = gd.localmax(out, 11)
     stencil_check(peaks, lambda x: cpu.local_extrema(cpu.smooth(x, 101), 11, 1, 0.0), 1, 55, rng)

@@ -438,8 +438,8 @@ def test_synth_signal_matches_cpu_generator(mode, gd):
 
 # ------------------------------------------------------------ fused chains ----
 
-@pytest.mark.parametrize("n", [1, 2, 11, 2293, 2294, 2295, 2304, 4588, 100003])
-@pytest.mark.parametrize("N", [1, 3, 11, 41, 129])
+@pytest.mark.parametrize("n", [1, 2, 11, 2293, 2294, 2295, 2304, 3973, 3974, 3975, 3984, 4588, 100003])
+@pytest.mark.parametrize("N", [1, 3, 4, 11, 41, 129])
 def test_fused_smooth_localmax_is_the_two_operators(n, N, gd):
     rng = np.random.default_rng(n + N)
     for kind in ("depth", "real"):
@@ -453,6 +453,9 @@ def test_fused_smooth_localmax_is_the_two_operators(n, N, gd):
         # fma mode: identical to the two fma-mode kernels run one after the other
         got = gd.smooth_local_extrema(d, 101, N, True, 0.0, mode=gd.FIR_FMA).numpy()
         two = gd.localmax(gd.smooth(d, 101, mode=gd.FIR_FMA), N).numpy()
+        assert bits_equal(got, two)
+        # hann mode is not shift invariant, so the fused kernel evaluates it as fma (ties stay ties)
+        got = gd.smooth_local_extrema(d, 101, N, True, 0.0, mode=gd.FIR_HANN).numpy()
         assert bits_equal(got, two)
     assert gd.lib().gdsp_smooth_local_extrema_fusable(101, 11) == 1
     assert gd.lib().gdsp_smooth_local_extrema_fusable(21, 11) == 0
