@@ -242,6 +242,9 @@ def other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_base
         def step(_):
             cnt, vals = gd.percentile([vin[i] for i in mine], [99000], allreduce=allreduce, stream=S)
             extra["percentile99"], extra["sampled"] = vals[0], cnt
+            st = gd.percentile_stats()
+            extra["percentile_route"] = {gd.SELECT_RADIX: "radix", gd.SELECT_BRACKET: "bracket"}.get(st["route"])
+            extra["percentile_stats"] = st
             for i in mine:
                 gd.binarize(tmp[i], vals[0], stream=S)
     wall_ms, dev_ms = timed_fn(None, args.steps, args.warmup, step=step)

@@ -28,6 +28,12 @@ def device_count():
     return n.value
 
 
+def current_device():
+    d = C.c_int(0)
+    call("gdsp_get_device", C.byref(d))
+    return d.value
+
+
 def set_device(i):
     call("gdsp_set_device", int(i))
 
@@ -410,9 +416,63 @@ def radix_select(histogram, p_thousandths, allreduce=None):
     return count, results
 
 
-def percentile(vecs, p_thousandths, window=1, lo=-DBL_MAX, hi=DBL_MAX, allreduce=None, stream=None):
-    """Exact percentiles of the sampled genome (percentile.c:392-751), non-destructive.
-    vecs: this rank's chromosome vectors; allreduce: see radix_select.  Returns (count, [values])."""
+class SelectSource(C.Structure):
+    """gdsp_select_source of include/genodsp_hip.h"""
+    _fields_ = [("d_v", C.c_void_p), ("n", C.c_uint32), ("device", C.c_int), ("stream", C.c_void_p)]
+
+
+REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, C.c_int)
+SELECT_AUTO, SELECT_RADIX, SELECT_BRACKET = 0, 1, 2
+
+
+def percentile(vecs, p_thousandths, window=1, lo=-DBL_MAX, hi=DBL_MAX, allreduce=None, stream=None,
+               strategy=SELECT_AUTO, sample_target=0):
+    """Exact percentiles of the sampled genome (percentile.c:392-751), non-destructive: gdsp_percentiles.
+    vecs: this rank's chromosome vectors (current device); allreduce(np.uint64 array, "sum"|"min"|"max")
+    -> the reduction over ranks (None: one rank).  Returns (count, [values])."""
+    device = current_device()
+    src = (SelectSource * max(1, len(vecs)))()
+    for i, v in enumerate(vecs):
+        src[i].d_v, src[i].n, src[i].device, src[i].stream = v.ptr, v.n, device, stream
+    pts = (C.c_uint32 * len(p_thousandths))(*[int(p) for p in p_thousandths])
+    vals = (C.c_double * len(p_thousandths))()
+    count = C.c_uint64(0)
+    failure = []
+
+    def reduce(_ctx, words, n, op):
+        try:
+            arr = np.ctypeslib.as_array(words, shape=(n,))
+            arr[:] = allreduce(arr.copy(), ("sum", "min", "max")[op])
+            return 0
+        except Exception as e:           # an exception must not unwind through the C frames
+            failure.append(e)
+            return 1
+
+    cb = REDUCE_FN(reduce) if allreduce is not None else C.cast(None, REDUCE_FN)
+    try:
+        call("gdsp_percentiles", src, len(vecs), int(window), float(lo), float(hi), pts, len(p_thousandths),
+             int(strategy), int(sample_target), cb, None, vals, C.byref(count))
+    except GdspError:
+        if failure:
+            raise failure[0]
+        raise
+    if count.value == 0:
+        return 0, []
+    return int(count.value), [float(x) for x in vals]
+
+
+def percentile_stats():
+    """What the last percentile() did: route (SELECT_RADIX / SELECT_BRACKET), population, subsample size,
+    candidates kept on this rank, percentiles that fell back, histogram passes over the population."""
+    out = (C.c_uint64 * 6)()
+    lib().gdsp_percentiles_stats(out)
+    keys = ("route", "population", "sample", "candidates", "fallbacks", "population_passes")
+    return dict(zip(keys, [int(x) for x in out]))
+
+
+def percentile_by_passes(vecs, p_thousandths, window=1, lo=-DBL_MAX, hi=DBL_MAX, allreduce=None, stream=None):
+    """The same result through the pass-level entry points (gdsp_select_histogram + host walk), kept for
+    callers that drive the passes themselves."""
     def histogram(shift, bits, prefix):
         nb = 1 << bits
         dh = DeviceBuffer((nb + 2) * 8)

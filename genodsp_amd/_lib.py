@@ -33,6 +33,7 @@ SIGNATURES = {
     "gdsp_last_error": (C.c_char_p, []),
     "gdsp_version": (C.c_char_p, []),
     "gdsp_device_count": (_int, [C.POINTER(_int)]),
+    "gdsp_get_device": (_int, [_vp]),
     "gdsp_set_device": (_int, [_int]),
     "gdsp_malloc": (_int, [C.POINTER(_vp), _sz]),
     "gdsp_free": (_int, [_vp]),
@@ -89,6 +90,8 @@ SIGNATURES = {
     "gdsp_key_to_double": (_f64, [_u64]),
     "gdsp_double_to_key": (_u64, [_f64]),
     "gdsp_percentile_rank": (_u32, [_u32, _u32]),
+    "gdsp_percentiles": (_int, [_vp, _int, _u32, _f64, _f64, _vp, _int, _int, _u32, _vp, _vp, _vp, _vp]),
+    "gdsp_percentiles_stats": (None, [_vp]),
     "gdsp_interval_tile": (_u32, []),
     "gdsp_bin_intervals": (_int, [_u32, _vp, _vp, _u32, _vp, _vp, C.POINTER(_u64)]),
     "gdsp_apply_intervals": (_int, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _int, _int, _f64, _vp]),

@@ -1,0 +1,642 @@
+// gdsp_percentile.hip -- the `percentile` operator end to end: exact order statistics of the
+// sampled genome in about one read of it.
+//
+// Reference: op_percentile_apply, percentile.c:392-751 (population = every window-th value with
+// !(v < lo) && !(v > hi), :559-561; rank of percentile p over N values = (u32)(N*p/100000),
+// :587-589, :681; rank N means the largest, :688-710).  gdsp_select.hip finds one rank by radix
+// select: five reads of the population per requested percentile.  This file keeps that as the
+// fallback and puts a bracketing step in front of it:
+//   1. a strided subsample (<= 2^24 values over all ranks) is gathered as order-preserving keys;
+//   2. for every requested percentile the subsample's order statistics a few standard deviations
+//      either side of the target rank are found (radix select over the small subsample);
+//   3. ONE pass over the population counts the values below / equal to / between / above those
+//      pivots and appends the few that fall strictly inside a bracket to a candidate list
+//      (wave-aggregated: a ballot per element slot, one global atomic per 64 candidates);
+//   4. the exact population count N and with it every rank are now known; the bin that holds a
+//      rank is either a pivot itself (heavy ties: read depth) or a bracket, where the answer is
+//      an order statistic of its candidates (radix select over that short list).
+// The subsample only decides how tight the brackets are: the counts of step 3 are exact, and a
+// rank that falls outside every bracket (or a candidate list that overflows) sends that
+// percentile through the full radix select, so the result never depends on the sampling.
+// Across GPUs the same decisions are taken everywhere because every count, histogram and flag
+// goes through the caller's reduction (RCCL all-reduce in bench.py; the host adds the devices
+// of one process itself) -- a few KiB per step, the path's only collective.
+// Traffic: 8 B per sampled base once, against 40 B with five select passes.
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <mutex>
+#include <vector>
+#include <algorithm>
+#include "gdsp_common.h"
+
+#define PC_THREADS     256
+#define PC_PER         8
+#define PC_MAX_BLOCKS  2048
+#define PC_MAX_PIVOTS  32
+#define PC_MAX_BINS    (2*PC_MAX_PIVOTS + 1)
+#define PC_WAVE_BUF    512
+#define PC_SAMPLE_TARGET (1u << 24)
+
+// sorted distinct pivots as doubles (padded with NaN, which compares false); collect bit j: keep what lies
+// strictly between pivot j-1 and pivot j (bit 0: below the first, bit m: above the last)
+struct PcPivots { double val[PC_MAX_PIVOTS];  uint64_t collect;  int m; };
+
+// ---------------------------------------------------------------- kernels ----
+// subsample: population element j*sstride of this vector, j = 0.., written to slot j as a key, or as
+// PC_NO_KEY when it does not qualify.  (gdsp_key_of folds -0.0 onto +0.0, so the image of -0.0 is
+// the one key no value has.)  No atomics: a counter bumped once per wave costs more than the gather.
+#define PC_NO_KEY 0x7FFFFFFFFFFFFFFFULL
+__global__ __launch_bounds__(PC_THREADS)
+void pc_sample_kernel (const double* __restrict__ v, uint32_t n, uint32_t window, double lo, double hi,
+                       uint32_t sstride, uint64_t* __restrict__ sample)
+	{
+	const size_t npop   = ((size_t) n + window - 1) / window;
+	const size_t nsamp  = (npop + sstride - 1) / sstride;
+	const size_t stride = (size_t) gridDim.x * PC_THREADS;
+	for (size_t j = (size_t) blockIdx.x * PC_THREADS + threadIdx.x ; j < nsamp ; j += stride)
+		{
+		const double x = v[j * sstride * window];
+		sample[j] = (!(x < lo) && !(x > hi))? gdsp_key_of (x) : PC_NO_KEY;
+		}
+	}
+
+// The counting pass.  Pivots are compared as doubles (one v_cmp each; the key image is only built
+// for the few values that are kept), and nothing is binned per element: a ballot per comparison
+// gives the wave's count of values above / equal to each pivot on the scalar unit, and the same
+// masks say which lanes sit strictly inside a collecting bin.  Bins follow from the counts on the
+// host:  below pivot 0 = total - gt[0] - eq[0],  between j-1 and j = gt[j-1] - gt[j] - eq[j],
+// above the last = gt[m-1].  NaNs pass the reference's filter and compare false with everything;
+// as keys the positive ones lie above every number, so they are counted apart (rare branch).
+// Counters: [0] total, [1..M] gt, [1+MAXP..] eq, then +NaNs, then the candidate count.
+#define PC_CTR_TOTAL 0
+#define PC_CTR_GT    1
+#define PC_CTR_EQ    (1 + PC_MAX_PIVOTS)
+#define PC_CTR_NAN   (1 + 2*PC_MAX_PIVOTS)
+#define PC_CTR_CAND  (2 + 2*PC_MAX_PIVOTS)
+#define PC_CTR_WORDS (3 + 2*PC_MAX_PIVOTS)
+
+template <int M, bool DENSE>
+__global__ __launch_bounds__(PC_THREADS)
+void pc_partition_kernel (const double* __restrict__ v, uint32_t n, uint32_t window, double lo, double hi, PcPivots P,
+                          unsigned long long* __restrict__ ctr, uint64_t* __restrict__ cand, unsigned long long cap)
+	{
+	__shared__ uint64_t wbuf[PC_THREADS/64][PC_WAVE_BUF];
+	__shared__ uint32_t wcount[PC_THREADS/64][2*M + 2];
+
+	const int    lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const size_t npop = DENSE? (size_t) n : ((size_t) n + window - 1) / window;
+	const size_t step = (size_t) gridDim.x * PC_THREADS * PC_PER;
+	uint32_t     held = 0;                                     // candidates waiting in this wave's buffer (wave uniform)
+	uint32_t     cTotal = 0, cNan = 0, cGt[M], cEq[M];         // wave uniform: they live in scalar registers
+#pragma unroll
+	for (int j=0 ; j<M ; j++) { cGt[j] = 0;  cEq[j] = 0; }
+
+	auto flush = [&] ()
+		{
+		unsigned long long base = 0;
+		if (lane == 0) base = atomicAdd (ctr + PC_CTR_CAND, (unsigned long long) held);
+		base = __shfl (base, 0, 64);
+		for (uint32_t i=lane ; i<held ; i+=64) { if (base + i < cap) cand[base + i] = wbuf[wave][i]; }
+		held = 0;
+		};
+
+	for (size_t wbase = ((size_t) blockIdx.x * (PC_THREADS/64) + wave) * 64 * PC_PER ; wbase < npop ; wbase += step)
+		{
+		const size_t g = wbase + (size_t) lane * PC_PER;
+		double x[PC_PER];
+		if (DENSE && (wbase + 64*PC_PER <= npop))
+			{
+			const double2* p = reinterpret_cast<const double2*> (v + g);
+#pragma unroll
+			for (int i=0 ; i<PC_PER/2 ; i++) { double2 d = p[i];  x[2*i] = d.x;  x[2*i+1] = d.y; }
+			}
+		else
+			{
+#pragma unroll
+			for (int i=0 ; i<PC_PER ; i++) x[i] = (g + i < npop)? v[(g + i) * (DENSE? 1 : window)] : 0.0;
+			}
+
+#pragma unroll
+		for (int i=0 ; i<PC_PER ; i++)
+			{
+			const double   xi    = x[i];
+			const uint64_t valid = __ballot ((g + i < npop) && !(xi < lo) && !(xi > hi));
+			if (valid == 0) continue;
+			cTotal += (uint32_t) __popcll (valid);
+			uint64_t keep = 0, above = valid;                  // `above`: valid lanes above the previous pivot
+#pragma unroll
+			for (int j=0 ; j<M ; j++)
+				{
+				const uint64_t gt = __ballot (xi >  P.val[j]) & valid;
+				const uint64_t eq = __ballot (xi == P.val[j]) & valid;
+				cGt[j] += (uint32_t) __popcll (gt);
+				cEq[j] += (uint32_t) __popcll (eq);
+				if ((P.collect >> j) & 1) keep |= above & ~gt & ~eq;
+				above = gt;
+				}
+			if ((P.collect >> M) & 1) keep |= above;
+			const uint64_t nan = __ballot (xi != xi) & valid;
+			if (nan != 0)
+				{
+				const uint64_t pos = __ballot ((xi != xi) && !signbit (xi)) & valid;    // they sort above every number
+				cNan += (uint32_t) __popcll (pos);
+				keep &= ~pos;
+				if ((P.collect >> P.m) & 1) keep |= pos;
+				}
+			if (keep != 0)
+				{
+				if ((keep >> lane) & 1) wbuf[wave][held + __popcll (keep & ((1ULL << lane) - 1))] = gdsp_key_of (xi);
+				held += (uint32_t) __popcll (keep);
+				__builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier ();
+				if (held > PC_WAVE_BUF - 64) flush ();
+				}
+			}
+		}
+	if (held) flush ();
+
+	if (lane == 0)
+		{
+		wcount[wave][0] = cTotal;  wcount[wave][1] = cNan;
+#pragma unroll
+		for (int j=0 ; j<M ; j++) { wcount[wave][2+j] = cGt[j];  wcount[wave][2+M+j] = cEq[j]; }
+		}
+	__syncthreads ();
+	if (threadIdx.x < 2*M + 2)
+		{
+		unsigned long long c = 0;
+		for (int w=0 ; w<PC_THREADS/64 ; w++) c += wcount[w][threadIdx.x];
+		const int t = threadIdx.x;
+		const int slot = (t == 0)? PC_CTR_TOTAL : (t == 1)? PC_CTR_NAN : (t < 2+M)? PC_CTR_GT + (t-2) : PC_CTR_EQ + (t-2-M);
+		if (c) atomicAdd (ctr + slot, c);
+		}
+	}
+
+// one digit histogram over a short list of keys, restricted to keyLo <= key <= keyHi
+__global__ __launch_bounds__(PC_THREADS)
+void pc_hist_keys_kernel (const uint64_t* __restrict__ keys, unsigned long long count, uint64_t keyLo, uint64_t keyHi,
+                          int bounded, int shift, int bits, uint64_t prefix, unsigned long long* __restrict__ hist)
+	{
+	__shared__ uint32_t lb[1 << 13];
+	const int      nbins = 1 << bits;
+	const uint64_t mask  = (uint64_t) nbins - 1;
+	const int      above = shift + bits;
+	for (int b=threadIdx.x ; b<nbins ; b+=PC_THREADS) lb[b] = 0;
+	__syncthreads ();
+	uint64_t kmin = ~0ULL, kmax = 0;
+	const size_t stride = (size_t) gridDim.x * PC_THREADS;
+	for (size_t i = (size_t) blockIdx.x * PC_THREADS + threadIdx.x ; i < count ; i += stride)
+		{
+		const uint64_t key = keys[i];
+		if (key == PC_NO_KEY) continue;
+		if (bounded && !((key >= keyLo) && (key <= keyHi))) continue;
+		if ((above < 64) && ((key >> above) != (prefix >> above))) continue;
+		atomicAdd (&lb[(uint32_t) ((key >> shift) & mask)], 1u);
+		if (key < kmin) kmin = key;
+		if (key > kmax) kmax = key;
+		}
+	__syncthreads ();
+	for (int b=threadIdx.x ; b<nbins ; b+=PC_THREADS)
+		{ uint32_t c = lb[b];  if (c) atomicAdd (&hist[b], (unsigned long long) c); }
+	for (int off=32 ; off>0 ; off>>=1)
+		{
+		uint64_t a = __shfl_down ((unsigned long long) kmin, off, 64);
+		uint64_t b = __shfl_down ((unsigned long long) kmax, off, 64);
+		if (a < kmin) kmin = a;
+		if (b > kmax) kmax = b;
+		}
+	if (((threadIdx.x & 63) == 0) && (kmin <= kmax))
+		{
+		atomicMin (&hist[nbins],   (unsigned long long) kmin);
+		atomicMax (&hist[nbins+1], (unsigned long long) kmax);
+		}
+	}
+
+// ------------------------------------------------------------- host side ----
+static const int pcShift[] = { 52, 39, 26, 13, 0 };
+static const int pcBits[]  = { 12, 13, 13, 13, 13 };
+#define PC_DIGITS 5
+#define PC_HIST_WORDS ((1 << 13) + 2)
+
+struct PcDevice                                               // scratch of one device, kept between calls
+	{
+	int       device;
+	uint64_t* hist;       // PC_HIST_WORDS
+	uint64_t* ctr;        // PC_CTR_WORDS counters of the counting pass
+	uint64_t* sample;  size_t sampleCap;
+	uint64_t* cand;    size_t candCap;
+	};
+static uint64_t   pcStats[6];
+static PcDevice   pcDev[64];
+static int        pcDevLen = 0;
+static std::mutex pcLock;
+
+static int pc_device (int device, size_t sampleCap, size_t candCap, PcDevice** out)
+	{
+	PcDevice* d = NULL;
+	for (int i=0 ; i<pcDevLen ; i++) { if (pcDev[i].device == device) d = &pcDev[i]; }
+	if (d == NULL)
+		{
+		GDSP_REQUIRE (pcDevLen < 64, "too many devices");
+		d = &pcDev[pcDevLen++];
+		memset (d, 0, sizeof(*d));
+		d->device = device;
+		GDSP_HIP_TRY (hipMalloc ((void**) &d->hist, PC_HIST_WORDS * sizeof(uint64_t)));
+		GDSP_HIP_TRY (hipMalloc ((void**) &d->ctr,  PC_CTR_WORDS * sizeof(uint64_t)));
+		}
+	if (d->sampleCap < sampleCap)
+		{
+		if (d->sample != NULL) GDSP_HIP_TRY (hipFree (d->sample));
+		d->sample = NULL;  d->sampleCap = 0;
+		GDSP_HIP_TRY (hipMalloc ((void**) &d->sample, sampleCap * sizeof(uint64_t)));
+		d->sampleCap = sampleCap;
+		}
+	if (d->candCap < candCap)
+		{
+		if (d->cand != NULL) GDSP_HIP_TRY (hipFree (d->cand));
+		d->cand = NULL;  d->candCap = 0;
+		GDSP_HIP_TRY (hipMalloc ((void**) &d->cand, candCap * sizeof(uint64_t)));
+		d->candCap = candCap;
+		}
+	*out = d;
+	return GDSP_OK;
+	}
+
+struct PcJob                                                  // one call of gdsp_percentiles
+	{
+	const gdsp_select_source* src;  int nsrc;
+	uint32_t window;  double lo, hi;
+	gdsp_reduce_fn reduce;  void* ctx;
+	std::vector<int>       devices;                           // distinct devices, in order of first use
+	std::vector<PcDevice*> scratch;                           // same order
+	std::vector<void*>     stream;                            // a stream of that device (its first source's)
+	std::vector<uint64_t>  sampleCount, candCount;            // per device
+	};
+
+#define PC_TRY(call) do { int rc_ = (call);  if (rc_ != GDSP_OK) return rc_; } while (0)
+
+static int pc_reduce (PcJob& J, uint64_t* words, size_t count, int op)
+	{
+	if (J.reduce == NULL) return GDSP_OK;
+	if (J.reduce (J.ctx, words, count, op) != 0) { gdsp_set_error ("gdsp_percentiles: the caller's reduction failed");  return GDSP_EHIP; }
+	return GDSP_OK;
+	}
+
+// which keys a histogram pass runs over
+enum { PC_OVER_VECTORS, PC_OVER_SAMPLE, PC_OVER_CANDIDATES };
+struct PcScope { int over;  int bounded;  uint64_t keyLo, keyHi; };
+
+// one digit histogram over the scope on every device of this process, summed, then reduced over ranks
+static int pc_pass (PcJob& J, const PcScope& S, int digit, uint64_t prefix, uint64_t* h)
+	{
+	const int bits = pcBits[digit], nbins = 1 << bits;
+	for (size_t d=0 ; d<J.devices.size () ; d++)
+		{
+		GDSP_HIP_TRY (hipSetDevice (J.devices[d]));
+		PC_TRY (gdsp_select_hist_init (J.scratch[d]->hist, bits, J.stream[d]));
+		if (S.over == PC_OVER_VECTORS)
+			{
+			if (d == 0) pcStats[5]++;
+			for (int i=0 ; i<J.nsrc ; i++)
+				{
+				if (J.src[i].device != J.devices[d]) continue;
+				PC_TRY (gdsp_select_histogram (J.src[i].d_v, J.src[i].n, J.window, J.lo, J.hi, pcShift[digit], bits, prefix,
+				                               J.scratch[d]->hist, J.stream[d]));
+				}
+			}
+		else
+			{
+			const uint64_t* keys  = (S.over == PC_OVER_SAMPLE)? J.scratch[d]->sample : J.scratch[d]->cand;
+			const uint64_t  count = (S.over == PC_OVER_SAMPLE)? J.sampleCount[d] : J.candCount[d];
+			if (count > 0)
+				{
+				size_t   want   = (count + PC_THREADS*4 - 1) / (PC_THREADS*4);
+				uint32_t blocks = (uint32_t) (want > 1024? 1024 : want);
+				hipLaunchKernelGGL (pc_hist_keys_kernel, dim3(blocks), dim3(PC_THREADS), 0, gdsp_stream (J.stream[d]),
+				                    keys, (unsigned long long) count, S.keyLo, S.keyHi, S.bounded, pcShift[digit], bits, prefix,
+				                    (unsigned long long*) J.scratch[d]->hist);
+				GDSP_LAUNCH_CHECK ();
+				}
+			}
+		}
+	std::vector<uint64_t> part (nbins + 2);
+	for (int b=0 ; b<nbins+2 ; b++) h[b] = 0;
+	h[nbins] = ~(uint64_t) 0;
+	for (size_t d=0 ; d<J.devices.size () ; d++)
+		{
+		GDSP_HIP_TRY (hipSetDevice (J.devices[d]));
+		GDSP_HIP_TRY (hipMemcpyAsync (part.data (), J.scratch[d]->hist, (size_t) (nbins + 2) * sizeof(uint64_t),
+		                              hipMemcpyDeviceToHost, gdsp_stream (J.stream[d])));
+		GDSP_HIP_TRY (hipStreamSynchronize (gdsp_stream (J.stream[d])));
+		for (int b=0 ; b<nbins ; b++) h[b] += part[b];
+		if (part[nbins]   < h[nbins])   h[nbins]   = part[nbins];
+		if (part[nbins+1] > h[nbins+1]) h[nbins+1] = part[nbins+1];
+		}
+	PC_TRY (pc_reduce (J, h, nbins, 0));
+	PC_TRY (pc_reduce (J, h + nbins, 1, 1));
+	PC_TRY (pc_reduce (J, h + nbins + 1, 1, 2));
+	return GDSP_OK;
+	}
+
+// keys of the given 0-based ranks within the scope; `first` is the scope's first-digit histogram
+static int pc_select (PcJob& J, const PcScope& S, const std::vector<uint64_t>& first, const std::vector<uint64_t>& ranks,
+                      std::vector<uint64_t>& keys)
+	{
+	std::vector<uint64_t> h (PC_HIST_WORDS);
+	keys.assign (ranks.size (), 0);
+	for (size_t r=0 ; r<ranks.size () ; r++)
+		{
+		uint64_t k = ranks[r], prefix = 0;
+		bool     found = false;
+		for (int digit=0 ; digit<PC_DIGITS ; digit++)
+			{
+			const int bits = pcBits[digit], nbins = 1 << bits;
+			const uint64_t* use = first.data ();
+			if (digit > 0) { PC_TRY (pc_pass (J, S, digit, prefix, h.data ()));  use = h.data (); }
+			if (use[nbins] == use[nbins+1]) { keys[r] = use[nbins];  found = true;  break; }   // one distinct value left
+			uint32_t bucket;  uint64_t within;
+			PC_TRY (gdsp_select_pick (use, bits, k, &bucket, &within));
+			prefix |= ((uint64_t) bucket) << pcShift[digit];
+			k = within;
+			}
+		if (!found) keys[r] = prefix;
+		}
+	return GDSP_OK;
+	}
+
+static uint64_t pc_total (const std::vector<uint64_t>& first)
+	{ uint64_t t = 0;  for (int b=0 ; b<(1 << pcBits[0]) ; b++) t += first[b];  return t; }
+
+// the plain route: radix select over the population for the listed percentiles
+static int pc_radix (PcJob& J, const uint32_t* pts, const std::vector<int>& which, double* values, uint64_t* count)
+	{
+	PcScope S = { PC_OVER_VECTORS, 0, 0, 0 };
+	std::vector<uint64_t> first (PC_HIST_WORDS);
+	PC_TRY (pc_pass (J, S, 0, 0, first.data ()));
+	const uint64_t N = pc_total (first);
+	*count = N;
+	if (N == 0) return GDSP_OK;
+	std::vector<uint64_t> ranks, keys;
+	for (int i : which) ranks.push_back (gdsp_percentile_rank ((uint32_t) N, pts[i]));
+	PC_TRY (pc_select (J, S, first, ranks, keys));
+	for (size_t r=0 ; r<which.size () ; r++) values[which[r]] = gdsp_value_of (keys[r]);
+	return GDSP_OK;
+	}
+
+extern "C" {
+
+int gdsp_percentiles (const gdsp_select_source* sources, int nsources, uint32_t window, double lo, double hi,
+                      const uint32_t* pThousandths, int npercentiles, int strategy, uint32_t sampleTarget,
+                      gdsp_reduce_fn reduce, void* reduceCtx, double* values, uint64_t* count)
+	{
+	GDSP_REQUIRE ((values != NULL) && (count != NULL) && (pThousandths != NULL), "NULL pointer");
+	GDSP_REQUIRE ((nsources >= 0) && (npercentiles >= 1), "nothing to do");
+	GDSP_REQUIRE ((nsources == 0) || (sources != NULL), "NULL sources");
+	GDSP_REQUIRE ((strategy >= GDSP_SELECT_AUTO) && (strategy <= GDSP_SELECT_BRACKET), "unknown strategy");
+	for (int i=0 ; i<npercentiles ; i++) GDSP_REQUIRE (pThousandths[i] <= 100000, "percentile above 100");
+	if (window == 0) window = 1;
+	if (sampleTarget == 0) sampleTarget = PC_SAMPLE_TARGET;
+
+	std::lock_guard<std::mutex> hold (pcLock);
+	memset (pcStats, 0, sizeof(pcStats));
+	int homeDevice = 0;
+	GDSP_HIP_TRY (hipGetDevice (&homeDevice));
+
+	PcJob J;
+	J.src = sources;  J.nsrc = nsources;  J.window = window;  J.lo = lo;  J.hi = hi;  J.reduce = reduce;  J.ctx = reduceCtx;
+	uint64_t localPop = 0;
+	for (int i=0 ; i<nsources ; i++)
+		{
+		GDSP_REQUIRE ((sources[i].n == 0) || (sources[i].d_v != NULL), "NULL vector");
+		localPop += ((uint64_t) sources[i].n + window - 1) / window;
+		if (std::find (J.devices.begin (), J.devices.end (), sources[i].device) == J.devices.end ())
+			{ J.devices.push_back (sources[i].device);  J.stream.push_back (sources[i].stream); }
+		}
+	if (J.devices.empty ()) { J.devices.push_back (homeDevice);  J.stream.push_back (NULL); }   // a rank without data still reduces
+	uint64_t pop = localPop;
+	PC_TRY (pc_reduce (J, &pop, 1, 0));
+
+	// ---- how: brackets need a population worth sampling and pivots that fit the counting kernel
+	const bool bracket = (strategy == GDSP_SELECT_BRACKET)
+	                  || ((strategy == GDSP_SELECT_AUTO) && (pop > (uint64_t) sampleTarget) && (2*npercentiles <= PC_MAX_PIVOTS));
+	const uint32_t sstride = (uint32_t) std::max<uint64_t> (1, (pop + sampleTarget - 1) / sampleTarget);
+
+	// scratch per device: the subsample and a candidate list sized for the expected bracket widths
+	for (size_t d=0 ; d<J.devices.size () ; d++)
+		{
+		size_t slots = 0, devPop = 0;
+		for (int i=0 ; i<nsources ; i++)
+			{
+			if (sources[i].device != J.devices[d]) continue;
+			const size_t p = ((size_t) sources[i].n + window - 1) / window;
+			devPop += p;  slots += (p + sstride - 1) / sstride;
+			}
+		size_t cands = 0;
+		if (bracket)
+			{
+			// a bracket spans ~8 standard deviations of a subsample rank: 8*sqrt(p(1-p)/s) of the population
+			const double s = (double) std::max<uint64_t> (1, pop / sstride);
+			cands = (size_t) (devPop * std::min (1.0, npercentiles * 8.0 * 0.5 / sqrt (s)) * 2) + 65536;
+			}
+		GDSP_HIP_TRY (hipSetDevice (J.devices[d]));
+		PcDevice* sc = NULL;
+		PC_TRY (pc_device (J.devices[d], bracket? slots + 64 : 0, cands, &sc));
+		J.scratch.push_back (sc);
+		}
+	J.sampleCount.assign (J.devices.size (), 0);
+	J.candCount.assign (J.devices.size (), 0);
+
+	std::vector<int> all;
+	for (int i=0 ; i<npercentiles ; i++) all.push_back (i);
+	int rc = GDSP_OK;
+	pcStats[0] = bracket? GDSP_SELECT_BRACKET : GDSP_SELECT_RADIX;
+	if (!bracket) { rc = pc_radix (J, pThousandths, all, values, count);  pcStats[1] = *count;  (void) hipSetDevice (homeDevice);  return rc; }
+
+	auto finish = [&] (int code) { (void) hipSetDevice (homeDevice);  return code; };
+
+	// ---- 1. subsample (slots of the sources of a device follow one another in its buffer)
+	for (size_t d=0 ; d<J.devices.size () ; d++)
+		{
+		GDSP_HIP_TRY (hipSetDevice (J.devices[d]));
+		size_t at = 0;
+		for (int i=0 ; i<nsources ; i++)
+			{
+			if ((sources[i].device != J.devices[d]) || (sources[i].n == 0)) continue;
+			const size_t p      = ((size_t) sources[i].n + window - 1) / window;
+			const size_t ns     = (p + sstride - 1) / sstride;
+			size_t       want   = (ns + PC_THREADS - 1) / PC_THREADS;
+			uint32_t     blocks = (uint32_t) (want > PC_MAX_BLOCKS? PC_MAX_BLOCKS : want);
+			hipLaunchKernelGGL (pc_sample_kernel, dim3(blocks), dim3(PC_THREADS), 0, gdsp_stream (J.stream[d]),
+			                    sources[i].d_v, sources[i].n, window, lo, hi, sstride, J.scratch[d]->sample + at);
+			GDSP_LAUNCH_CHECK ();
+			at += ns;
+			}
+		J.sampleCount[d] = at;                                     // slots; the ones that qualified are counted below
+		}
+	PcScope overSample = { PC_OVER_SAMPLE, 0, 0, 0 };
+	std::vector<uint64_t> sFirst (PC_HIST_WORDS);
+	PC_TRY (pc_pass (J, overSample, 0, 0, sFirst.data ()));
+	const uint64_t sTotal = pc_total (sFirst);
+	pcStats[2] = sTotal;
+	if (sTotal < 256)                                              // hardly anything qualifies
+		{ pcStats[0] = GDSP_SELECT_RADIX;  rc = pc_radix (J, pThousandths, all, values, count);  pcStats[1] = *count;  return finish (rc); }
+
+	// ---- 2. pivots: subsample order statistics either side of each target
+	std::vector<uint64_t> wantRanks;
+	std::vector<int>      slotOf (2*npercentiles, -1);           // -1: open end (0 below, ~0 above)
+	for (int i=0 ; i<npercentiles ; i++)
+		{
+		const double p  = pThousandths[i] / 100000.0;
+		const double ks = floor ((double) sTotal * p);
+		const double dl = ceil (4.0 * sqrt ((double) sTotal * p * (1.0 - p))) + 16.0;
+		if (ks - dl >= 0.0)               { slotOf[2*i]   = (int) wantRanks.size ();  wantRanks.push_back ((uint64_t) (ks - dl)); }
+		if (ks + dl <= (double) sTotal-1) { slotOf[2*i+1] = (int) wantRanks.size ();  wantRanks.push_back ((uint64_t) (ks + dl)); }
+		}
+	std::vector<uint64_t> rankKeys;
+	PC_TRY (pc_select (J, overSample, sFirst, wantRanks, rankKeys));
+	// a bracket without a subsample rank on one side is open on that side
+	std::vector<uint64_t> bLo (npercentiles), bHi (npercentiles), piv;
+	std::vector<bool>     openLo (npercentiles), openHi (npercentiles);
+	for (int i=0 ; i<npercentiles ; i++)
+		{
+		openLo[i] = (slotOf[2*i]   < 0);  bLo[i] = openLo[i]? 0 : rankKeys[slotOf[2*i]];
+		openHi[i] = (slotOf[2*i+1] < 0);  bHi[i] = openHi[i]? ~(uint64_t) 0 : rankKeys[slotOf[2*i+1]];
+		if (!openLo[i]) piv.push_back (bLo[i]);
+		if (!openHi[i]) piv.push_back (bHi[i]);
+		}
+	std::sort (piv.begin (), piv.end ());
+	piv.erase (std::unique (piv.begin (), piv.end ()), piv.end ());
+	PcPivots P;
+	memset (&P, 0, sizeof(P));
+	P.m = (int) piv.size ();
+	bool usable = (P.m >= 1) && (P.m <= PC_MAX_PIVOTS);
+	for (int j=0 ; j<PC_MAX_PIVOTS ; j++)
+		{
+		P.val[j] = (j < P.m)? gdsp_value_of (piv[j]) : NAN;
+		if ((j < P.m) && (P.val[j] != P.val[j])) usable = false;    // a NaN pivot cannot be compared as a double
+		}
+	if (!usable)
+		{ pcStats[0] = GDSP_SELECT_RADIX;  rc = pc_radix (J, pThousandths, all, values, count);  pcStats[1] = *count;  return finish (rc); }
+	for (int j=0 ; j<=P.m ; j++)                                 // open bin j: above pivot j-1, below pivot j
+		{
+		for (int i=0 ; i<npercentiles ; i++)
+			{
+			const bool fromBelow = (j == 0)?   openLo[i] : (!openLo[i]? (bLo[i] <= piv[j-1]) : true);
+			const bool toAbove   = (j == P.m)? openHi[i] : (!openHi[i]? (piv[j] <= bHi[i])   : true);
+			if (fromBelow && toAbove) P.collect |= (1ULL << j);
+			}
+		}
+
+	// ---- 3. the counting pass
+	for (size_t d=0 ; d<J.devices.size () ; d++)
+		{
+		GDSP_HIP_TRY (hipSetDevice (J.devices[d]));
+		GDSP_HIP_TRY (hipMemsetAsync (J.scratch[d]->ctr, 0, PC_CTR_WORDS * sizeof(uint64_t), gdsp_stream (J.stream[d])));
+		unsigned long long* ctr = (unsigned long long*) J.scratch[d]->ctr;
+		for (int i=0 ; i<nsources ; i++)
+			{
+			if ((sources[i].device != J.devices[d]) || (sources[i].n == 0)) continue;
+			const size_t p      = ((size_t) sources[i].n + window - 1) / window;
+			size_t       want   = (p + (size_t) PC_THREADS*PC_PER - 1) / ((size_t) PC_THREADS*PC_PER);
+			uint32_t     blocks = (uint32_t) (want > PC_MAX_BLOCKS? PC_MAX_BLOCKS : want);
+			const bool   dense  = (window == 1) && gdsp_aligned16 (sources[i].d_v);
+#define PC_LAUNCH(MM)                                                                                                          \
+			do { if (dense) hipLaunchKernelGGL ((pc_partition_kernel<MM, true>),  dim3(blocks), dim3(PC_THREADS), 0,              \
+			                                     gdsp_stream (J.stream[d]), sources[i].d_v, sources[i].n, window, lo, hi, P, ctr, \
+			                                     J.scratch[d]->cand, (unsigned long long) J.scratch[d]->candCap);                 \
+			     else       hipLaunchKernelGGL ((pc_partition_kernel<MM, false>), dim3(blocks), dim3(PC_THREADS), 0,              \
+			                                     gdsp_stream (J.stream[d]), sources[i].d_v, sources[i].n, window, lo, hi, P, ctr, \
+			                                     J.scratch[d]->cand, (unsigned long long) J.scratch[d]->candCap); } while (0)
+			if      (P.m <= 2)  PC_LAUNCH (2);
+			else if (P.m <= 4)  PC_LAUNCH (4);
+			else if (P.m <= 8)  PC_LAUNCH (8);
+			else if (P.m <= 16) PC_LAUNCH (16);
+			else                PC_LAUNCH (32);
+#undef PC_LAUNCH
+			GDSP_LAUNCH_CHECK ();
+			}
+		}
+	const int nb = 2*P.m + 1;
+	std::vector<uint64_t> raw (PC_CTR_WORDS + 1, 0), part (PC_CTR_WORDS);   // last word: an overflowed candidate list anywhere
+	for (size_t d=0 ; d<J.devices.size () ; d++)
+		{
+		GDSP_HIP_TRY (hipSetDevice (J.devices[d]));
+		GDSP_HIP_TRY (hipMemcpyAsync (part.data (), J.scratch[d]->ctr, PC_CTR_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost,
+		                              gdsp_stream (J.stream[d])));
+		GDSP_HIP_TRY (hipStreamSynchronize (gdsp_stream (J.stream[d])));
+		for (int b=0 ; b<PC_CTR_CAND ; b++) raw[b] += part[b];
+		J.candCount[d] = part[PC_CTR_CAND];
+		if (J.candCount[d] > J.scratch[d]->candCap) { raw[PC_CTR_WORDS] = 1;  J.candCount[d] = J.scratch[d]->candCap; }
+		}
+	PC_TRY (pc_reduce (J, raw.data (), PC_CTR_CAND, 0));
+	PC_TRY (pc_reduce (J, raw.data () + PC_CTR_WORDS, 1, 2));
+	const bool overflow = (raw[PC_CTR_WORDS] != 0);
+	std::vector<uint64_t> bins (nb, 0);                          // even: open bins, odd: ties on a pivot
+	for (int j=0 ; j<P.m ; j++) bins[2*j+1] = raw[PC_CTR_EQ + j];
+	bins[0] = raw[PC_CTR_TOTAL] - raw[PC_CTR_GT] - raw[PC_CTR_EQ] - raw[PC_CTR_NAN];
+	for (int j=1 ; j<P.m ; j++) bins[2*j] = raw[PC_CTR_GT + j-1] - raw[PC_CTR_GT + j] - raw[PC_CTR_EQ + j];
+	bins[2*P.m] = raw[PC_CTR_GT + P.m-1] + raw[PC_CTR_NAN];
+
+	// ---- 4. ranks are exact now; read each answer off a pivot or off its bracket's candidates
+	uint64_t N = 0;
+	for (int b=0 ; b<nb ; b++) N += bins[b];
+	*count = N;
+	pcStats[1] = N;  pcStats[5]++;
+	for (size_t d=0 ; d<J.devices.size () ; d++) pcStats[3] += J.candCount[d];
+	if (N == 0) return finish (GDSP_OK);
+	std::vector<int> fallback;
+	for (int j=0 ; j<=P.m ; j++)
+		{
+		std::vector<int>      who;
+		std::vector<uint64_t> ranks, keys;
+		uint64_t before = 0;
+		for (int b=0 ; b<2*j ; b++) before += bins[b];
+		for (int i=0 ; i<npercentiles ; i++)
+			{
+			const uint64_t k = gdsp_percentile_rank ((uint32_t) N, pThousandths[i]);
+			if ((k >= before) && (k < before + bins[2*j])) { who.push_back (i);  ranks.push_back (k - before); }
+			}
+		if (who.empty ()) continue;
+		if (overflow || !((P.collect >> j) & 1)) { fallback.insert (fallback.end (), who.begin (), who.end ());  continue; }
+		PcScope inBin = { PC_OVER_CANDIDATES, 1, (j == 0)? 0 : piv[j-1] + 1, (j == P.m)? ~(uint64_t) 0 : piv[j] - 1 };
+		std::vector<uint64_t> cFirst (PC_HIST_WORDS);
+		PC_TRY (pc_pass (J, inBin, 0, 0, cFirst.data ()));
+		if (pc_total (cFirst) != bins[2*j])
+			{ gdsp_set_error ("gdsp_percentiles: candidate list and counts disagree");  return finish (GDSP_EHIP); }
+		PC_TRY (pc_select (J, inBin, cFirst, ranks, keys));
+		for (size_t r=0 ; r<who.size () ; r++) values[who[r]] = gdsp_value_of (keys[r]);
+		}
+	for (int i=0 ; i<npercentiles ; i++)
+		{
+		const uint64_t k = gdsp_percentile_rank ((uint32_t) N, pThousandths[i]);
+		uint64_t before = 0;
+		for (int b=0 ; b<nb ; b++)
+			{
+			if ((k >= before) && (k < before + bins[b]))
+				{
+				if (b & 1) values[i] = gdsp_value_of (piv[b >> 1]);                 // the rank lands on a pivot's ties
+				break;
+				}
+			before += bins[b];
+			}
+		}
+	if (!fallback.empty ())
+		{
+		std::sort (fallback.begin (), fallback.end ());
+		fallback.erase (std::unique (fallback.begin (), fallback.end ()), fallback.end ());
+		uint64_t again = 0;
+		pcStats[4] = fallback.size ();
+		rc = pc_radix (J, pThousandths, fallback, values, &again);
+		}
+	return finish (rc);
+	}
+
+void gdsp_percentiles_stats (uint64_t out[6])
+	{
+	std::lock_guard<std::mutex> hold (pcLock);
+	memcpy (out, pcStats, sizeof(pcStats));
+	}
+
+} // extern "C"

@@ -35,6 +35,13 @@ int gdsp_set_device (int device)
 	return GDSP_OK;
 	}
 
+int gdsp_get_device (int* device)
+	{
+	GDSP_REQUIRE (device != NULL, "NULL pointer");
+	GDSP_HIP_TRY (hipGetDevice (device));
+	return GDSP_OK;
+	}
+
 int gdsp_malloc (void** d_ptr, size_t bytes)
 	{
 	GDSP_REQUIRE (d_ptr != NULL, "d_ptr is NULL");

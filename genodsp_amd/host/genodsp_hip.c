@@ -111,6 +111,7 @@ static int originOne      = false;
 static int inhibitOutput  = false;
 static int numDevices     = 1;
 int        firMode        = GDSP_FIR_EXACT;      /* --smooth=exact|fma|hann (see ops_sum.c) */
+int        selectStrategy = GDSP_SELECT_AUTO;    /* --percentile=auto|radix|bracket (see ops_percentile.c) */
 static int fuseChains     = true;                /* --nofuse: one kernel per operator          */
 
 /* a chromosome as the driver sees it: the public spec first, device state after */
@@ -166,8 +167,13 @@ static void usage (void)
 	"  --gpus=<n>                shard whole chromosomes over n GPUs (default 1)\n"
 	"  --nofuse                  run every operator as its own kernel (default: the chains\n"
 	"                            smooth=localmax|localmin and dilate=erode[=binarize] are fused)\n"
-	"  --smooth=exact|fma        arithmetic of `smooth`: exact = bit-identical to genodsp\n"
-	"                            (default); fma = fused multiply-add, one rounding per tap\n"
+	"  --smooth=exact|fma|hann   arithmetic of `smooth`: exact = bit-identical to genodsp\n"
+	"                            (default); fma = fused multiply-add, one rounding per tap;\n"
+	"                            hann = block sums of the window (fastest, same tolerance,\n"
+	"                            not shift invariant: see DESIGN.md)\n"
+	"  --percentile=auto|radix|bracket  how `percentile` finds its order statistics (same\n"
+	"                            values either way; auto brackets them from a subsample\n"
+	"                            when the genome is large)\n"
 	"  --help[=<operator>]  ?  ?<operator>   operator help\n"
 	"  --report=comments  --progress=input:<n>  --progress=operations  --version\n\n"
 	"Overlapping input intervals are summed. Input comes from stdin unless the first\n"
@@ -431,6 +437,7 @@ void sync_all_devices (void)
 
 int device_count_in_use (void) { return numDevices; }
 int device_index_of (spec* s)  { return ((xspec*) s)->device; }
+int physical_device_of (spec* s) { return ((xspec*) s)->device % physicalDevices; }   /* the GPU a logical shard runs on */
 
 /* deal chromosomes to devices longest-first onto the least loaded (LPT), then allocate */
 static void allocate_vectors (void)
@@ -948,6 +955,9 @@ static void parse_options (int _argc, char** _argv)            /* genodsp.c:284-
 		if (strcmp (arg, "--smooth=exact") == 0) { firMode = GDSP_FIR_EXACT;  continue; }
 		if (strcmp (arg, "--smooth=fma")   == 0) { firMode = GDSP_FIR_FMA;    continue; }
 		if (strcmp (arg, "--smooth=hann")  == 0) { firMode = GDSP_FIR_HANN;   continue; }
+		if (strcmp (arg, "--percentile=auto")    == 0) { selectStrategy = GDSP_SELECT_AUTO;     continue; }
+		if (strcmp (arg, "--percentile=radix")   == 0) { selectStrategy = GDSP_SELECT_RADIX;    continue; }
+		if (strcmp (arg, "--percentile=bracket") == 0) { selectStrategy = GDSP_SELECT_BRACKET;  continue; }
 		if (strcmp (arg, "?") == 0) usage_operations ();
 		if ((strcmp_prefix (arg, "--help=") == 0) || (strcmp_prefix (arg, "?=") == 0))
 			{

@@ -5,6 +5,7 @@
 
 #include "genodsp_interface.h"
 
+extern int selectStrategy;                  /* GDSP_SELECT_* (--percentile=) */
 extern int firMode;                         /* GDSP_FIR_EXACT or GDSP_FIR_FMA (--smooth=) */
 
 /* pending-interval batches: collect in file order, apply on the owning device */
@@ -21,6 +22,7 @@ void* device_workspace (size_t bytes);         /* per-device, grows on demand, k
 void* long_window_workspace (size_t* bytes);   /* lazily allocated, for windows beyond one LDS tile */
 int  device_count_in_use (void);
 int  device_index_of     (spec* s);
+int  physical_device_of  (spec* s);
 
 /* ops_common.c: helpers shared by the operator files */
 void* new_op           (char* name, size_t bytes, int atRandom);   /* zeroed control record */

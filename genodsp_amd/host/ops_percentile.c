@@ -164,88 +164,51 @@ static void percentile_name (char* varName, u32 percentile)     /* percentile.c:
 	sprintf (varName, "percentile%f", pPct);
 	}
 
-/* digit schedule over the 64-bit key: sign+exponent, then the mantissa in 13-bit digits */
-static const int digitShift[] = { 52, 39, 26, 13, 0 };
-static const int digitBits[]  = { 12, 13, 13, 13, 13 };
-#define NUM_DIGITS 5
-#define MAX_BINS   (1 << GDSP_SELECT_MAX_BITS)
-
-/* one select pass over every chromosome on every device; h_hist gets the summed counts
- * followed by the smallest and largest matching key */
-static void histogram_pass (dspop_percentile* op, int digit, u64 prefix, u64* h_hist)
-	{
-	const int bits = digitBits[digit], nbins = 1 << bits;
-	u64*  d_hist[64] = { NULL };
-	u64   part[MAX_BINS + 2];
-
-	for (int b=0 ; b<nbins+2 ; b++) h_hist[b] = 0;
-	h_hist[nbins] = ~(u64) 0;
-	int seen[64] = { 0 };
-	for (int i=0 ; chromsSorted[i]!=NULL ; i++)
-		{
-		spec* s = chromsSorted[i];
-		select_device_of (s);
-		int d = device_index_of (s);
-		if (!seen[d])
-			{
-			d_hist[d] = (u64*) get_scratch_vector ();
-			check_gdsp (gdsp_select_hist_init (d_hist[d], bits, op_stream ()), "percentile");
-			seen[d] = true;
-			}
-		check_gdsp (gdsp_select_histogram (s->valVector, s->length, op->windowSize, op->minAllowed, op->maxAllowed,
-		                                   digitShift[digit], bits, prefix, d_hist[d], op_stream ()), "percentile");
-		}
-	for (int i=0 ; chromsSorted[i]!=NULL ; i++)
-		{
-		spec* s = chromsSorted[i];
-		int d = device_index_of (s);
-		if (!seen[d]) continue;
-		select_device_of (s);
-		check_gdsp (gdsp_memcpy_d2h (part, d_hist[d], (size_t) (nbins + 2) * sizeof(u64), op_stream ()), "percentile");
-		check_gdsp (gdsp_stream_sync (op_stream ()), "percentile");
-		release_scratch_vector ((valtype*) d_hist[d]);
-		seen[d] = false;
-		for (int b=0 ; b<nbins ; b++) h_hist[b] += part[b];                 /* the sum over GPUs */
-		if (part[nbins]   < h_hist[nbins])   h_hist[nbins]   = part[nbins];
-		if (part[nbins+1] > h_hist[nbins+1]) h_hist[nbins+1] = part[nbins+1];
-		}
-	}
-
 void op_percentile_apply (dspop* _op, arg_dont_complain(char* vName), arg_dont_complain(u32 vLen), arg_dont_complain(valtype* v))
 	{
 	dspop_percentile* op = (dspop_percentile*) _op;
-	static u64 first[MAX_BINS + 2], hist[MAX_BINS + 2];
 	char  varName[100];
 	FILE* mapF = (op->mapFilename != NULL)? fopen (op->mapFilename, "wt") : NULL;
 
-	histogram_pass (op, 0, 0, first);                   /* shared by every requested percentile */
+	/* every chromosome on every GPU is one source of the population; the library adds the
+	 * devices' counts itself, so there is nothing to reduce across processes here */
+	int nsrc = 0, npct = 0;
+	for (int i=0 ; chromsSorted[i]!=NULL ; i++) nsrc++;
+	for (u32 pt=op->percentileLo ; pt<=op->percentileHi ; pt+=op->percentileStep)
+		{ npct++;  if (op->percentileStep == 0) break; }
+	gdsp_select_source* src = (gdsp_select_source*) calloc (nsrc? nsrc : 1, sizeof(gdsp_select_source));
+	u32*     pts  = (u32*)     calloc (npct, sizeof(u32));
+	valtype* vals = (valtype*) calloc (npct, sizeof(valtype));
+	if ((src == NULL) || (pts == NULL) || (vals == NULL))
+		{ fprintf (stderr, "[%s] out of memory\n", _op->name);  exit (EXIT_FAILURE); }
+	sync_all_devices ();
+	for (int i=0 ; i<nsrc ; i++)
+		{
+		spec* s = chromsSorted[i];
+		select_device_of (s);
+		src[i].d_v = s->valVector;  src[i].n = s->length;
+		src[i].device = physical_device_of (s);  src[i].stream = op_stream ();
+		}
+	npct = 0;
+	for (u32 pt=op->percentileLo ; pt<=op->percentileHi ; pt+=op->percentileStep)
+		{ pts[npct++] = pt;  if (op->percentileStep == 0) break; }
 	u64 numValues = 0;
-	for (int b=0 ; b<(1 << digitBits[0]) ; b++) numValues += first[b];
+	check_gdsp (gdsp_percentiles (src, nsrc, op->windowSize, op->minAllowed, op->maxAllowed, pts, npct,
+	                              selectStrategy, 0, NULL, NULL, vals, &numValues), "percentile");
+	if (nsrc > 0) select_device_of (chromsSorted[0]);
+	free (src);
 	if (numValues == 0)
 		{
 		fprintf (stderr, "[%s] percentile can't be computed;  no input values meet the criteria\n", _op->name);
 		if (mapF != NULL) fclose (mapF);
+		free (pts);  free (vals);
 		return;
 		}
 
-	for (u32 pt=op->percentileLo ; pt<=op->percentileHi ; pt+=op->percentileStep)
+	for (int ip=0 ; ip<npct ; ip++)
 		{
-		u64     k = gdsp_percentile_rank ((u32) numValues, pt);
-		u64     prefix = 0;
-		valtype pVal = 0;
-		int     found = false;
-		for (int digit=0 ; digit<NUM_DIGITS ; digit++)
-			{
-			const int bits = digitBits[digit], nbins = 1 << bits;
-			u64* h = first;
-			if (digit > 0) { histogram_pass (op, digit, prefix, hist);  h = hist; }
-			if (h[nbins] == h[nbins+1]) { pVal = gdsp_key_to_double (h[nbins]);  found = true;  break; }
-			u32 bucket;  u64 within;
-			check_gdsp (gdsp_select_pick (h, bits, k, &bucket, &within), "percentile");
-			prefix |= ((u64) bucket) << digitShift[digit];
-			k = within;
-			}
-		if (!found) pVal = gdsp_key_to_double (prefix);
+		u32     pt   = pts[ip];
+		valtype pVal = vals[ip];
 
 		float pPct = pt / ((float) percentileStepUnits);
 		percentile_name (varName, pt);
@@ -255,7 +218,7 @@ void op_percentile_apply (dspop* _op, arg_dont_complain(char* vName), arg_dont_c
 		else if (!op->quiet)
 			fprintf (stderr, "percentile %.3f is " valtypeFmtPrec "\n", pPct, op->valPrecision, pVal);
 		if (mapF != NULL) fprintf (mapF, valtypeFmtPrec " %.3f\n", op->valPrecision, pVal, pPct);
-		if (op->percentileStep == 0) break;
 		}
 	if (mapF != NULL) fclose (mapF);
+	free (pts);  free (vals);
 	}

@@ -52,6 +52,7 @@ const char* gdsp_version    (void);
 /* ---- runtime plumbing (what genodsp.c:865-878 / :1890-2037 do with calloc) ---- */
 int gdsp_device_count   (int* count);
 int gdsp_set_device     (int device);
+int gdsp_get_device     (int* device);
 int gdsp_malloc         (void** d_ptr, size_t bytes);
 int gdsp_free           (void* d_ptr);
 int gdsp_host_alloc     (void** h_ptr, size_t bytes);          /* pinned staging  */
@@ -196,6 +197,32 @@ double   gdsp_key_to_double (uint64_t key);
 uint64_t gdsp_double_to_key (double v);
 /* Host: the reference's rank formula, percentile.c:587-589 and :688-710 */
 uint32_t gdsp_percentile_rank (uint32_t numValues, uint32_t pThousandths);
+
+/* op_percentile_apply (percentile.c:392-751) end to end: the exact percentiles of the sampled
+ * genome -- every window-th value v with !(v < lo) && !(v > hi) of every source vector --
+ * non-destructive.  values[i] = the order statistic of rank gdsp_percentile_rank(count, p[i]);
+ * *count = the population size (0: nothing qualifies, values untouched).
+ * Sources may sit on several devices of this process (the counts are added on the host); with
+ * one process per GPU pass `reduce`, which must replace words[0..count) by their sum (op 0),
+ * minimum (op 1) or maximum (op 2) over all ranks and return 0 -- every rank then takes the same
+ * decisions and gets the same values.  That reduction (a few KiB per step) is the path's only
+ * collective.
+ * strategy: AUTO brackets the ranks with pivots from a strided subsample of `sampleTarget`
+ * values (0 = 2^24) and settles all percentiles in one counting pass over the population when it
+ * is larger than that, RADIX is five histogram passes per percentile (the fallback of AUTO
+ * whenever a bracket misses), BRACKET forces the first route (tests). */
+typedef struct gdsp_select_source { const double* d_v; uint32_t n; int device; void* stream; } gdsp_select_source;
+typedef int (*gdsp_reduce_fn) (void* ctx, uint64_t* words, size_t count, int op);
+#define GDSP_SELECT_AUTO    0
+#define GDSP_SELECT_RADIX   1
+#define GDSP_SELECT_BRACKET 2
+int gdsp_percentiles (const gdsp_select_source* sources, int nsources, uint32_t window, double lo, double hi,
+                      const uint32_t* pThousandths, int npercentiles, int strategy, uint32_t sampleTarget,
+                      gdsp_reduce_fn reduce, void* reduceCtx, double* values, uint64_t* count);
+/* what the last gdsp_percentiles call of this process did: [0] route taken (GDSP_SELECT_RADIX or
+ * _BRACKET), [1] population, [2] subsample size, [3] candidates kept on this rank, [4] percentiles
+ * that fell back to the radix route, [5] histogram passes over the population */
+void gdsp_percentiles_stats (uint64_t out[6]);
 
 /* ---- genodsp.c read_intervals / add.c / multiply.c ------------------------------ */
 

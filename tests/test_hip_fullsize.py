@@ -127,12 +127,21 @@ def test_percentile_rank_bracketing_full_chromosome(gd, depth, real):
         for pt in (50000, 99000):
             cnt, (val,) = gd.percentile([vec], [pt])
             assert cnt == N
+            stats = gd.percentile_stats()                # brackets from the subsample, one read of the population
+            assert stats["route"] == gd.SELECT_BRACKET and stats["fallbacks"] == 0 and stats["population_passes"] == 1, stats
+            radix_cnt, (radix_val,) = gd.percentile([vec], [pt], strategy=gd.SELECT_RADIX)
+            assert (radix_cnt, radix_val) == (cnt, val)
             k = gd.lib().gdsp_percentile_rank(cnt, pt)
             # exact order statistic: #(v < val) <= k < #(v <= val); counted with the device reduction
             _, _, le = gd.genome_minmax([vec], 1, -gd.DBL_MAX, val)
             below = np.nextafter(val, -np.inf)
             _, _, lt = gd.genome_minmax([vec], 1, -gd.DBL_MAX, below)
             assert lt <= k < le, (pt, val, lt, k, le)
+        cnt, vals = gd.percentile([vec], [0, 500, 10000, 25000, 50000, 75000, 90000, 99000, 99990, 100000])
+        stats = gd.percentile_stats()
+        assert stats["route"] == gd.SELECT_BRACKET and stats["fallbacks"] == 0 and stats["population_passes"] == 1, stats
+        assert vals == sorted(vals) and vals == gd.percentile(
+            [vec], [0, 500, 10000, 25000, 50000, 75000, 90000, 99000, 99990, 100000], strategy=gd.SELECT_RADIX)[1]
         # the signal is untouched
         assert bits_equal(fetch(vec, 12345678, 4096),
                           cpu.synth_coverage(SEED, CHROM, 12345678, 4096, 0 if vec is depth else 1))

@@ -1,0 +1,56 @@
+"""GPU: the one-process-per-GPU path of bench.py with two ranks sharing the one visible GPU (gloo for the
+reductions).  What is checked is the N>1 plumbing -- LPT sharding of the chromosomes, the reduction
+callback of gdsp_percentiles (counts, histograms and flags summed over ranks so that every rank takes
+the same decisions), max-over-ranks timing -- not a speed."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _bench(ranks, workload, scale):
+    common = ["bench.py", "--gpus", str(ranks), "--workload", workload, "--scale", str(scale), "--steps", "1",
+              "--warmup", "0", "--no-cpu-baseline"]
+    if ranks == 1:
+        cmd = [sys.executable] + common
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + common + ["--rehearse-on-one-gpu"]
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout                      # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_percentile_over_two_ranks_equals_one_rank():
+    # 0.08 of the genome = 247 Mbp: above the 2^24 values where the bracketing route starts
+    one = _bench(1, "percentile", 0.08)
+    two = _bench(2, "percentile", 0.08)
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    assert two["sampled"] == one["sampled"] == one["config"]["bases"]
+    assert two["percentile99"] == one["percentile99"]
+    assert two["percentile_route"] == one["percentile_route"] == "bracket"
+
+
+def test_smooth_over_two_ranks_reports_the_whole_job():
+    two = _bench(2, "smooth", 0.02)
+    assert two["n_gpus"] == 2 and two["parity"]["ok"] and two["scaling"] == "strong"
+    assert two["config"]["bases"] == sum(max(1, int(n * 0.02)) for n in
+                                         [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973,
+                                          145138636, 138394717, 133797422, 135086622, 133275309, 114364328, 107043718,
+                                          101991189, 90338345, 83257441, 80373285, 58617616, 64444167, 46709983,
+                                          50818468, 156040895, 57227415])

@@ -349,12 +349,38 @@ def test_percentile_exact_order_statistic(kind, gd):
     pts = [0, 1, 500, 25000, 50000, 90000, 99000, 99999, 100000]
     for window, lo, hi in ((1, -cpu.DBL_MAX, cpu.DBL_MAX), (1, 2.2250738585072014e-308, cpu.DBL_MAX),
                            (7, -1.0, 30.0)):
-        cnt, got = gd.percentile(dv, pts, window, lo, hi)
         wcnt, want = cpu.percentile(vecs, pts, window, lo, hi)
-        assert cnt == wcnt
-        assert list(got) == list(want), (window, lo, hi)
+        # every route gives the reference's values: five radix passes per percentile, brackets from a
+        # subsample (forced here: the population is far below the 2^24 where AUTO starts to sample; small
+        # subsamples give wide brackets, 64 values give brackets that miss and fall back), the pass-level API
+        for strategy, target in ((gd.SELECT_AUTO, 0), (gd.SELECT_RADIX, 0), (gd.SELECT_BRACKET, 1 << 15),
+                                 (gd.SELECT_BRACKET, 4096), (gd.SELECT_BRACKET, 300)):
+            cnt, got = gd.percentile(dv, pts, window, lo, hi, strategy=strategy, sample_target=target)
+            assert cnt == wcnt, (strategy, target)
+            assert list(got) == list(want), (window, lo, hi, strategy, target, gd.percentile_stats())
+            stats = gd.percentile_stats()
+            assert stats["population"] == wcnt
+            if strategy == gd.SELECT_BRACKET and target >= 4096:
+                assert stats["route"] == gd.SELECT_BRACKET and stats["population_passes"] <= 1 + 5 * stats["fallbacks"]
+        cnt, got = gd.percentile_by_passes(dv, pts, window, lo, hi)
+        assert cnt == wcnt and list(got) == list(want)
     for d, v in zip(dv, vecs):
         assert bits_equal(d.numpy(), v)                    # untouched
+
+
+def test_percentile_brackets_on_awkward_populations(gd):
+    rng = np.random.default_rng(23)
+    n = 200000
+    cases = {"constant": np.full(n, 3.25), "two values": np.where(rng.random(n) < 0.3, -1.0, 2.0),
+             "sorted": np.sort(rng.standard_normal(n)), "sawtooth": (np.arange(n) % 509).astype(np.float64),
+             "signed zeros": np.where(rng.random(n) < 0.5, 0.0, -0.0) * 1.0,
+             "one outlier": np.concatenate([np.zeros(n - 1), [1e300]])}
+    pts = [0, 100, 30000, 50000, 70000, 99900, 100000]
+    for name, x in cases.items():
+        wcnt, want = cpu.percentile([x], pts, 1, -cpu.DBL_MAX, cpu.DBL_MAX)
+        for target in (1 << 14, 1000):
+            cnt, got = gd.percentile([gd.DeviceVector.from_numpy(x)], pts, strategy=gd.SELECT_BRACKET, sample_target=target)
+            assert cnt == wcnt and list(got) == list(want), (name, target, gd.percentile_stats())
 
 
 def test_percentile_empty_sample(gd):
