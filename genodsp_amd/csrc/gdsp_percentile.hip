@@ -24,6 +24,7 @@
 // Traffic: 8 B per sampled base once, against 40 B with five select passes.
 
 #include <math.h>
+#include <float.h>
 #include <stdlib.h>
 #include <string.h>
 #include <mutex>
@@ -62,115 +63,170 @@ void pc_sample_kernel (const double* __restrict__ v, uint32_t n, uint32_t window
 		}
 	}
 
-// The counting pass.  Pivots are compared as doubles (one v_cmp each; the key image is only built
-// for the few values that are kept), and nothing is binned per element: a ballot per comparison
-// gives the wave's count of values above / equal to each pivot on the scalar unit, and the same
-// masks say which lanes sit strictly inside a collecting bin.  Bins follow from the counts on the
-// host:  below pivot 0 = total - gt[0] - eq[0],  between j-1 and j = gt[j-1] - gt[j] - eq[j],
-// above the last = gt[m-1].  NaNs pass the reference's filter and compare false with everything;
-// as keys the positive ones lie above every number, so they are counted apart (rare branch).
-// Counters: [0] total, [1..M] gt, [1+MAXP..] eq, then +NaNs, then the candidate count.
-#define PC_CTR_TOTAL 0
-#define PC_CTR_GT    1
-#define PC_CTR_EQ    (1 + PC_MAX_PIVOTS)
-#define PC_CTR_NAN   (1 + 2*PC_MAX_PIVOTS)
-#define PC_CTR_CAND  (2 + 2*PC_MAX_PIVOTS)
-#define PC_CTR_WORDS (3 + 2*PC_MAX_PIVOTS)
+// The counting pass.  Nothing is binned and nothing is masked per element: every lane counts, for
+// each pivot, the values above it and the values equal to it (a v_cmp_f64 and an add-with-carry
+// each), and -- only when the operator has --min/--max bounds -- the values >= lo and > hi.  Counts
+// restricted to the population follow by subtraction on the host, because lo <= pivots <= hi:
+//     population          = #(x >= lo) - #(x > hi) + NaNs        (NaNs pass the reference's filter)
+//     above pivot j       = #(x > p_j) - #(x > hi)
+//     below pivot 0       = population - above_0 - equal_0 - positive NaNs
+//     between j-1 and j   = #(x > p_{j-1}) - #(x > p_j) - equal_j
+//     above the last      = above_{m-1} + positive NaNs          (as keys they lie above every number)
+// The compare masks also say which lanes sit strictly inside a collecting bin; their key images
+// are appended to the candidate list through a per-wave buffer.  Non-finite values are the rare
+// branch (one v_cmp_class per element): NaNs are counted by sign; without bounds the infinities are
+// what the default bounds -DBL_MAX..DBL_MAX exclude, so they are counted to be subtracted.
+// Elements past the end of a vector are read as -inf, which every count ignores or excludes.
+#define PC_CTR_GELO   0
+#define PC_CTR_GT     1
+#define PC_CTR_EQ     (1 + PC_MAX_PIVOTS)
+#define PC_CTR_NANPOS (1 + 2*PC_MAX_PIVOTS)
+#define PC_CTR_NANNEG (2 + 2*PC_MAX_PIVOTS)
+#define PC_CTR_GTHI   (3 + 2*PC_MAX_PIVOTS)            // bounded: #(x > hi); unbounded: #(+inf)
+#define PC_CTR_NEGINF (4 + 2*PC_MAX_PIVOTS)            // unbounded: #(-inf), padding included
+#define PC_CTR_WORDS  (5 + 2*PC_MAX_PIVOTS)
 
-template <int M, bool DENSE>
+// One workgroup walks up to 16 consecutive 32 KiB tiles (a contiguous stretch, dealt so that each XCD
+// covers a contiguous eighth of the vector; fewer on short vectors, to keep >= ~1000 workgroups); the
+// next tile's loads are in flight while the current one is counted.  (Measured: 2 tiles per workgroup
+// is 15 % slower, a 2048-workgroup grid-stride loop the same as this.)  Counters go to one of PC_REPL replicas (workgroup id mod PC_REPL) so that the
+// end-of-workgroup atomics do not queue on a handful of addresses; the host adds the replicas.
+#define PC_TILE         (PC_THREADS * 16)
+#define PC_TILES_PER_WG 16                              // at most
+#define PC_MIN_WGS      1024
+#define PC_REPL         64
+#define PC_CTR_ALL      (PC_REPL * PC_CTR_WORDS + 1)      // replicas, then the candidate count
+
+template <int M, bool BOUNDED, bool DENSE>
 __global__ __launch_bounds__(PC_THREADS)
 void pc_partition_kernel (const double* __restrict__ v, uint32_t n, uint32_t window, double lo, double hi, PcPivots P,
-                          unsigned long long* __restrict__ ctr, uint64_t* __restrict__ cand, unsigned long long cap)
+                          unsigned long long* __restrict__ ctr, uint64_t* __restrict__ cand, unsigned long long cap,
+                          uint32_t ntiles, uint32_t tilesPerWG)
 	{
+	constexpr int NC = 2*M + 5;                                // counters of this instantiation
 	__shared__ uint64_t wbuf[PC_THREADS/64][PC_WAVE_BUF];
-	__shared__ uint32_t wcount[PC_THREADS/64][2*M + 2];
+	__shared__ uint32_t wcount[PC_THREADS/64][NC];
 
-	const int    lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const size_t npop = DENSE? (size_t) n : ((size_t) n + window - 1) / window;
-	const size_t step = (size_t) gridDim.x * PC_THREADS * PC_PER;
-	uint32_t     held = 0;                                     // candidates waiting in this wave's buffer (wave uniform)
-	uint32_t     cTotal = 0, cNan = 0, cGt[M], cEq[M];         // wave uniform: they live in scalar registers
+	const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const size_t   npop = DENSE? (size_t) n : ((size_t) n + window - 1) / window;
+	const uint32_t wg   = gdsp_xcd_tile (blockIdx.x, gridDim.x);
+	const uint32_t t0   = wg * tilesPerWG;
+	const uint32_t t1   = (t0 + tilesPerWG < ntiles)? t0 + tilesPerWG : ntiles;
+	unsigned long long* candCount = ctr + (size_t) PC_REPL * PC_CTR_WORDS;
+	uint32_t held = 0;                                         // candidates waiting in this wave's buffer (wave uniform)
+	uint32_t cGt[M], cEq[M], cGeLo = 0, cGtHi = 0, cNanPos = 0, cNanNeg = 0, cNegInf = 0;   // per lane
+	uint64_t take[M+1];                                        // all ones where bin j collects (scalar)
 #pragma unroll
 	for (int j=0 ; j<M ; j++) { cGt[j] = 0;  cEq[j] = 0; }
+#pragma unroll
+	for (int j=0 ; j<=M ; j++) take[j] = ((P.collect >> j) & 1)? ~0ULL : 0ULL;
+	const uint64_t takeTop = ((P.collect >> P.m) & 1)? ~0ULL : 0ULL;    // bin m (pivots beyond m are NaN pads)
 
 	auto flush = [&] ()
 		{
 		unsigned long long base = 0;
-		if (lane == 0) base = atomicAdd (ctr + PC_CTR_CAND, (unsigned long long) held);
+		if (lane == 0) base = atomicAdd (candCount, (unsigned long long) held);
 		base = __shfl (base, 0, 64);
 		for (uint32_t i=lane ; i<held ; i+=64) { if (base + i < cap) cand[base + i] = wbuf[wave][i]; }
 		held = 0;
 		};
 
-	for (size_t wbase = ((size_t) blockIdx.x * (PC_THREADS/64) + wave) * 64 * PC_PER ; wbase < npop ; wbase += step)
+	// element e of a tile is read by thread (e/2) % 256 in its load (e/2) / 256: 16 bytes per lane, coalesced
+	auto load = [&] (uint32_t tile, double2 (&d)[8])
 		{
-		const size_t g = wbase + (size_t) lane * PC_PER;
-		double x[PC_PER];
-		if (DENSE && (wbase + 64*PC_PER <= npop))
+		const size_t base = (size_t) tile * PC_TILE;
+		if (DENSE && (base + PC_TILE <= npop))
 			{
-			const double2* p = reinterpret_cast<const double2*> (v + g);
+			const double2* p = reinterpret_cast<const double2*> (v + base) + threadIdx.x;
 #pragma unroll
-			for (int i=0 ; i<PC_PER/2 ; i++) { double2 d = p[i];  x[2*i] = d.x;  x[2*i+1] = d.y; }
+			for (int u=0 ; u<8 ; u++) d[u] = p[u*PC_THREADS];
 			}
 		else
 			{
 #pragma unroll
-			for (int i=0 ; i<PC_PER ; i++) x[i] = (g + i < npop)? v[(g + i) * (DENSE? 1 : window)] : 0.0;
+			for (int u=0 ; u<8 ; u++)
+				{
+				const size_t e = base + 2 * ((size_t) u*PC_THREADS + threadIdx.x);
+				d[u].x = (e   < npop)? v[e       * (DENSE? 1 : window)] : -INFINITY;
+				d[u].y = (e+1 < npop)? v[(e + 1) * (DENSE? 1 : window)] : -INFINITY;
+				}
 			}
+		};
 
-#pragma unroll
-		for (int i=0 ; i<PC_PER ; i++)
+	auto count = [&] (double x)
+		{
+		uint64_t keep = 0, above = ~0ULL, gthi = 0;
+		if (BOUNDED)
 			{
-			const double   xi    = x[i];
-			const uint64_t valid = __ballot ((g + i < npop) && !(xi < lo) && !(xi > hi));
-			if (valid == 0) continue;
-			cTotal += (uint32_t) __popcll (valid);
-			uint64_t keep = 0, above = valid;                  // `above`: valid lanes above the previous pivot
-#pragma unroll
-			for (int j=0 ; j<M ; j++)
-				{
-				const uint64_t gt = __ballot (xi >  P.val[j]) & valid;
-				const uint64_t eq = __ballot (xi == P.val[j]) & valid;
-				cGt[j] += (uint32_t) __popcll (gt);
-				cEq[j] += (uint32_t) __popcll (eq);
-				if ((P.collect >> j) & 1) keep |= above & ~gt & ~eq;
-				above = gt;
-				}
-			if ((P.collect >> M) & 1) keep |= above;
-			const uint64_t nan = __ballot (xi != xi) & valid;
-			if (nan != 0)
-				{
-				const uint64_t pos = __ballot ((xi != xi) && !signbit (xi)) & valid;    // they sort above every number
-				cNan += (uint32_t) __popcll (pos);
-				keep &= ~pos;
-				if ((P.collect >> P.m) & 1) keep |= pos;
-				}
-			if (keep != 0)
-				{
-				if ((keep >> lane) & 1) wbuf[wave][held + __popcll (keep & ((1ULL << lane) - 1))] = gdsp_key_of (xi);
-				held += (uint32_t) __popcll (keep);
-				__builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");
-				__builtin_amdgcn_wave_barrier ();
-				if (held > PC_WAVE_BUF - 64) flush ();
-				}
+			const bool a = (x >= lo), b = (x > hi);
+			cGeLo += a;  cGtHi += b;
+			above = __ballot (a);  gthi = __ballot (b);
 			}
+#pragma unroll
+		for (int j=0 ; j<M ; j++)
+			{
+			const bool g = (x >  P.val[j]);
+			const bool e = (x == P.val[j]);
+			cGt[j] += g;
+			cEq[j] += e;
+			const uint64_t gt = __ballot (g), eq = __ballot (e);
+			keep |= above & ~gt & ~eq & take[j];
+			above = gt;
+			}
+		keep = (keep | (above & take[M])) & ~gthi;             // (with fewer than M pivots the top bin is met inside the loop)
+		const uint64_t odd = __ballot (!__builtin_isfinite (x));
+		if (odd != 0)
+			{
+			const bool     nanp = (x != x) && !signbit (x), nann = (x != x) && signbit (x);
+			const bool     infp = !BOUNDED && (x ==  INFINITY), infn = !BOUNDED && (x == -INFINITY);
+			cNanPos += nanp;  cNanNeg += nann;
+			if (!BOUNDED) { cGtHi += infp;  cNegInf += infn; }
+			keep &= ~odd;                                      // no infinity is in the population, and a NaN
+			keep |= __ballot (nann) & take[0];                 // sits in the bottom or in the top bin
+			keep |= __ballot (nanp) & takeTop;
+			}
+		if (keep != 0)
+			{
+			if ((keep >> lane) & 1) wbuf[wave][held + __popcll (keep & ((1ULL << lane) - 1))] = gdsp_key_of (x);
+			held += (uint32_t) __popcll (keep);
+			__builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier ();
+			if (held > PC_WAVE_BUF - 64) flush ();
+			}
+		};
+
+	double2 cur[8], nxt[8];
+	if (t0 < t1) load (t0, cur);
+	for (uint32_t tile=t0 ; tile<t1 ; tile++)
+		{
+		if (tile + 1 < t1) load (tile + 1, nxt);
+#pragma unroll
+		for (int u=0 ; u<8 ; u++) { count (cur[u].x);  count (cur[u].y); }
+#pragma unroll
+		for (int u=0 ; u<8 ; u++) cur[u] = nxt[u];
 		}
 	if (held) flush ();
 
-	if (lane == 0)
+	auto wave_sum = [&] (uint32_t c)
 		{
-		wcount[wave][0] = cTotal;  wcount[wave][1] = cNan;
+		for (int off=32 ; off>0 ; off>>=1) c += __shfl_down (c, off, 64);
+		return c;
+		};
+	uint32_t mine[NC];
+	mine[0] = cGeLo;  mine[1] = cGtHi;  mine[2] = cNanPos;  mine[3] = cNanNeg;  mine[4] = cNegInf;
 #pragma unroll
-		for (int j=0 ; j<M ; j++) { wcount[wave][2+j] = cGt[j];  wcount[wave][2+M+j] = cEq[j]; }
-		}
+	for (int j=0 ; j<M ; j++) { mine[5+j] = cGt[j];  mine[5+M+j] = cEq[j]; }
+#pragma unroll
+	for (int k=0 ; k<NC ; k++) { const uint32_t c = wave_sum (mine[k]);  if (lane == 0) wcount[wave][k] = c; }
 	__syncthreads ();
-	if (threadIdx.x < 2*M + 2)
+	if (threadIdx.x < NC)
 		{
 		unsigned long long c = 0;
 		for (int w=0 ; w<PC_THREADS/64 ; w++) c += wcount[w][threadIdx.x];
 		const int t = threadIdx.x;
-		const int slot = (t == 0)? PC_CTR_TOTAL : (t == 1)? PC_CTR_NAN : (t < 2+M)? PC_CTR_GT + (t-2) : PC_CTR_EQ + (t-2-M);
-		if (c) atomicAdd (ctr + slot, c);
+		const int slot = (t == 0)? PC_CTR_GELO : (t == 1)? PC_CTR_GTHI : (t == 2)? PC_CTR_NANPOS : (t == 3)? PC_CTR_NANNEG
+		               : (t == 4)? PC_CTR_NEGINF : (t < 5+M)? PC_CTR_GT + (t-5) : PC_CTR_EQ + (t-5-M);
+		if (c) atomicAdd (ctr + (size_t) (blockIdx.x % PC_REPL) * PC_CTR_WORDS + slot, c);
 		}
 	}
 
@@ -224,7 +280,7 @@ struct PcDevice                                               // scratch of one 
 	{
 	int       device;
 	uint64_t* hist;       // PC_HIST_WORDS
-	uint64_t* ctr;        // PC_CTR_WORDS counters of the counting pass
+	uint64_t* ctr;        // PC_CTR_ALL counters of the counting pass
 	uint64_t* sample;  size_t sampleCap;
 	uint64_t* cand;    size_t candCap;
 	};
@@ -244,7 +300,7 @@ static int pc_device (int device, size_t sampleCap, size_t candCap, PcDevice** o
 		memset (d, 0, sizeof(*d));
 		d->device = device;
 		GDSP_HIP_TRY (hipMalloc ((void**) &d->hist, PC_HIST_WORDS * sizeof(uint64_t)));
-		GDSP_HIP_TRY (hipMalloc ((void**) &d->ctr,  PC_CTR_WORDS * sizeof(uint64_t)));
+		GDSP_HIP_TRY (hipMalloc ((void**) &d->ctr,  PC_CTR_ALL * sizeof(uint64_t)));
 		}
 	if (d->sampleCap < sampleCap)
 		{
@@ -398,6 +454,7 @@ int gdsp_percentiles (const gdsp_select_source* sources, int nsources, uint32_t 
 	for (int i=0 ; i<npercentiles ; i++) GDSP_REQUIRE (pThousandths[i] <= 100000, "percentile above 100");
 	if (window == 0) window = 1;
 	if (sampleTarget == 0) sampleTarget = PC_SAMPLE_TARGET;
+	if (!(lo <= hi)) strategy = GDSP_SELECT_RADIX;                // only NaNs can pass such a filter: no brackets
 
 	std::lock_guard<std::mutex> hold (pcLock);
 	memset (pcStats, 0, sizeof(pcStats));
@@ -529,55 +586,67 @@ int gdsp_percentiles (const gdsp_select_source* sources, int nsources, uint32_t 
 			}
 		}
 
-	// ---- 3. the counting pass
+	// ---- 3. the counting pass (bounds as far out as the defaults only keep the infinities away)
+	const bool bounded = !((lo <= -DBL_MAX) && (hi >= DBL_MAX));
+	uint64_t   padded  = 0;                                      // elements the kernels count, padding included
 	for (size_t d=0 ; d<J.devices.size () ; d++)
 		{
 		GDSP_HIP_TRY (hipSetDevice (J.devices[d]));
-		GDSP_HIP_TRY (hipMemsetAsync (J.scratch[d]->ctr, 0, PC_CTR_WORDS * sizeof(uint64_t), gdsp_stream (J.stream[d])));
+		GDSP_HIP_TRY (hipMemsetAsync (J.scratch[d]->ctr, 0, PC_CTR_ALL * sizeof(uint64_t), gdsp_stream (J.stream[d])));
 		unsigned long long* ctr = (unsigned long long*) J.scratch[d]->ctr;
 		for (int i=0 ; i<nsources ; i++)
 			{
 			if ((sources[i].device != J.devices[d]) || (sources[i].n == 0)) continue;
-			const size_t p      = ((size_t) sources[i].n + window - 1) / window;
-			size_t       want   = (p + (size_t) PC_THREADS*PC_PER - 1) / ((size_t) PC_THREADS*PC_PER);
-			uint32_t     blocks = (uint32_t) (want > PC_MAX_BLOCKS? PC_MAX_BLOCKS : want);
-			const bool   dense  = (window == 1) && gdsp_aligned16 (sources[i].d_v);
-#define PC_LAUNCH(MM)                                                                                                          \
-			do { if (dense) hipLaunchKernelGGL ((pc_partition_kernel<MM, true>),  dim3(blocks), dim3(PC_THREADS), 0,              \
+			const size_t   p      = ((size_t) sources[i].n + window - 1) / window;
+			const uint32_t ntiles = (uint32_t) ((p + PC_TILE - 1) / PC_TILE);
+			const uint32_t perWG  = std::max<uint32_t> (1, std::min<uint32_t> (PC_TILES_PER_WG, ntiles / PC_MIN_WGS));
+			const uint32_t blocks = (ntiles + perWG - 1) / perWG;
+			const bool     dense  = (window == 1) && gdsp_aligned16 (sources[i].d_v);
+#define PC_LAUNCH_B(MM, BB)                                                                                                    \
+			do { if (dense) hipLaunchKernelGGL ((pc_partition_kernel<MM, BB, true>),  dim3(blocks), dim3(PC_THREADS), 0,          \
 			                                     gdsp_stream (J.stream[d]), sources[i].d_v, sources[i].n, window, lo, hi, P, ctr, \
-			                                     J.scratch[d]->cand, (unsigned long long) J.scratch[d]->candCap);                 \
-			     else       hipLaunchKernelGGL ((pc_partition_kernel<MM, false>), dim3(blocks), dim3(PC_THREADS), 0,              \
+			                                     J.scratch[d]->cand, (unsigned long long) J.scratch[d]->candCap, ntiles, perWG);  \
+			     else       hipLaunchKernelGGL ((pc_partition_kernel<MM, BB, false>), dim3(blocks), dim3(PC_THREADS), 0,          \
 			                                     gdsp_stream (J.stream[d]), sources[i].d_v, sources[i].n, window, lo, hi, P, ctr, \
-			                                     J.scratch[d]->cand, (unsigned long long) J.scratch[d]->candCap); } while (0)
+			                                     J.scratch[d]->cand, (unsigned long long) J.scratch[d]->candCap, ntiles, perWG); } while (0)
+#define PC_LAUNCH(MM) do { if (bounded) PC_LAUNCH_B (MM, true);  else PC_LAUNCH_B (MM, false); } while (0)
+			padded += (uint64_t) ntiles * PC_TILE;
 			if      (P.m <= 2)  PC_LAUNCH (2);
 			else if (P.m <= 4)  PC_LAUNCH (4);
 			else if (P.m <= 8)  PC_LAUNCH (8);
 			else if (P.m <= 16) PC_LAUNCH (16);
 			else                PC_LAUNCH (32);
+#undef PC_LAUNCH_B
 #undef PC_LAUNCH
 			GDSP_LAUNCH_CHECK ();
 			}
 		}
 	const int nb = 2*P.m + 1;
-	std::vector<uint64_t> raw (PC_CTR_WORDS + 1, 0), part (PC_CTR_WORDS);   // last word: an overflowed candidate list anywhere
+	std::vector<uint64_t> raw (PC_CTR_WORDS + 2, 0), part (PC_CTR_ALL);   // + padded count, + an overflowed candidate list anywhere
 	for (size_t d=0 ; d<J.devices.size () ; d++)
 		{
 		GDSP_HIP_TRY (hipSetDevice (J.devices[d]));
-		GDSP_HIP_TRY (hipMemcpyAsync (part.data (), J.scratch[d]->ctr, PC_CTR_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost,
+		GDSP_HIP_TRY (hipMemcpyAsync (part.data (), J.scratch[d]->ctr, PC_CTR_ALL * sizeof(uint64_t), hipMemcpyDeviceToHost,
 		                              gdsp_stream (J.stream[d])));
 		GDSP_HIP_TRY (hipStreamSynchronize (gdsp_stream (J.stream[d])));
-		for (int b=0 ; b<PC_CTR_CAND ; b++) raw[b] += part[b];
-		J.candCount[d] = part[PC_CTR_CAND];
-		if (J.candCount[d] > J.scratch[d]->candCap) { raw[PC_CTR_WORDS] = 1;  J.candCount[d] = J.scratch[d]->candCap; }
+		for (int r=0 ; r<PC_REPL ; r++)
+			for (int b=0 ; b<PC_CTR_WORDS ; b++) raw[b] += part[(size_t) r * PC_CTR_WORDS + b];
+		J.candCount[d] = part[(size_t) PC_REPL * PC_CTR_WORDS];
+		if (J.candCount[d] > J.scratch[d]->candCap) { raw[PC_CTR_WORDS + 1] = 1;  J.candCount[d] = J.scratch[d]->candCap; }
 		}
-	PC_TRY (pc_reduce (J, raw.data (), PC_CTR_CAND, 0));
-	PC_TRY (pc_reduce (J, raw.data () + PC_CTR_WORDS, 1, 2));
-	const bool overflow = (raw[PC_CTR_WORDS] != 0);
+	raw[PC_CTR_WORDS] = padded;
+	PC_TRY (pc_reduce (J, raw.data (), PC_CTR_WORDS + 1, 0));
+	PC_TRY (pc_reduce (J, raw.data () + PC_CTR_WORDS + 1, 1, 2));
+	const bool overflow = (raw[PC_CTR_WORDS + 1] != 0);
+	// counts within the population (see the kernel's header): every "above" loses what lies above hi
+	const uint64_t nans  = raw[PC_CTR_NANPOS] + raw[PC_CTR_NANNEG];
+	const uint64_t total = bounded? raw[PC_CTR_GELO] - raw[PC_CTR_GTHI] + nans
+	                              : raw[PC_CTR_WORDS] - raw[PC_CTR_GTHI] - raw[PC_CTR_NEGINF];
 	std::vector<uint64_t> bins (nb, 0);                          // even: open bins, odd: ties on a pivot
 	for (int j=0 ; j<P.m ; j++) bins[2*j+1] = raw[PC_CTR_EQ + j];
-	bins[0] = raw[PC_CTR_TOTAL] - raw[PC_CTR_GT] - raw[PC_CTR_EQ] - raw[PC_CTR_NAN];
+	bins[0] = total - (raw[PC_CTR_GT] - raw[PC_CTR_GTHI]) - raw[PC_CTR_EQ] - raw[PC_CTR_NANPOS];
 	for (int j=1 ; j<P.m ; j++) bins[2*j] = raw[PC_CTR_GT + j-1] - raw[PC_CTR_GT + j] - raw[PC_CTR_EQ + j];
-	bins[2*P.m] = raw[PC_CTR_GT + P.m-1] + raw[PC_CTR_NAN];
+	bins[2*P.m] = (raw[PC_CTR_GT + P.m-1] - raw[PC_CTR_GTHI]) + raw[PC_CTR_NANPOS];
 
 	// ---- 4. ranks are exact now; read each answer off a pivot or off its bracket's candidates
 	uint64_t N = 0;

@@ -374,13 +374,31 @@ def test_percentile_brackets_on_awkward_populations(gd):
     cases = {"constant": np.full(n, 3.25), "two values": np.where(rng.random(n) < 0.3, -1.0, 2.0),
              "sorted": np.sort(rng.standard_normal(n)), "sawtooth": (np.arange(n) % 509).astype(np.float64),
              "signed zeros": np.where(rng.random(n) < 0.5, 0.0, -0.0) * 1.0,
-             "one outlier": np.concatenate([np.zeros(n - 1), [1e300]])}
+             "one outlier": np.concatenate([np.zeros(n - 1), [1e300]]),
+             "infinities": np.where(rng.random(n) < 0.01, np.inf, np.where(rng.random(n) < 0.01, -np.inf,
+                                                                           rng.standard_normal(n)))}
     pts = [0, 100, 30000, 50000, 70000, 99900, 100000]
     for name, x in cases.items():
         wcnt, want = cpu.percentile([x], pts, 1, -cpu.DBL_MAX, cpu.DBL_MAX)
         for target in (1 << 14, 1000):
             cnt, got = gd.percentile([gd.DeviceVector.from_numpy(x)], pts, strategy=gd.SELECT_BRACKET, sample_target=target)
             assert cnt == wcnt and list(got) == list(want), (name, target, gd.percentile_stats())
+        for lo, hi in ((-0.5, 0.75), (2.2250738585072014e-308, cpu.DBL_MAX)):      # --min/--max: the bounded kernel
+            wcnt, want = cpu.percentile([x], pts, 1, lo, hi)
+            cnt, got = gd.percentile([gd.DeviceVector.from_numpy(x)], pts, 1, lo, hi, strategy=gd.SELECT_BRACKET,
+                                     sample_target=1 << 14)
+            assert cnt == wcnt and (cnt == 0 or list(got) == list(want)), (name, lo, hi, gd.percentile_stats())
+    # NaNs pass the reference's filter; as keys the positive ones sort above every number, the negative ones
+    # below.  The reference's qsort has no defined order for them, so the two routes are held to each other.
+    x = rng.standard_normal(n)
+    x[rng.integers(0, n, 300)] = np.nan
+    x[rng.integers(0, n, 200)] = -np.nan
+    x[rng.integers(0, n, 100)] = np.inf
+    d = gd.DeviceVector.from_numpy(x)
+    for lo, hi in ((-cpu.DBL_MAX, cpu.DBL_MAX), (-1.0, 1.5)):
+        a = gd.percentile([d], [0, 10, 50000, 99990, 100000], 1, lo, hi, strategy=gd.SELECT_RADIX)
+        b = gd.percentile([d], [0, 10, 50000, 99990, 100000], 1, lo, hi, strategy=gd.SELECT_BRACKET, sample_target=1 << 14)
+        assert a[0] == b[0] and np.array_equal(np.array(a[1]), np.array(b[1]), equal_nan=True), (lo, hi, a, b)
 
 
 def test_percentile_empty_sample(gd):
