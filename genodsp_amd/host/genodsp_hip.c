@@ -19,6 +19,7 @@
  */
 #include <stdlib.h>
 #include <stdio.h>
+#include <math.h>
 #include <string.h>
 #include <stdarg.h>
 #include <float.h>
@@ -772,6 +773,86 @@ void read_intervals (FILE* f, int valCol, int origin1, int overlapOp, int clear,
 	}
 
 /* ---------------------------------------------------------------- text output */
+/* Output lines are formatted by hand into a large buffer: with millions of runs the report is bound
+ * by fprintf otherwise.  Same characters as the reference's "%s\t%d\t%d\t%.*f\n" (genodsp.c:1640-1668). */
+#define OUTBUF_BYTES (1 << 20)
+static char  outBuf[OUTBUF_BYTES + 512];
+static char* outAt = outBuf;
+
+static void out_flush (FILE* f)
+	{ if (outAt != outBuf) { fwrite (outBuf, 1, (size_t) (outAt - outBuf), f);  outAt = outBuf; } }
+
+static char* put_text (char* p, const char* t) { while (*t != 0) *(p++) = *(t++);  return p; }
+
+static char* put_int (char* p, int v)                                   /* %d */
+	{
+	char digits[12];
+	int  n = 0;
+	unsigned int u = (v < 0)? 0u - (unsigned int) v : (unsigned int) v;
+	if (v < 0) *(p++) = '-';
+	do { digits[n++] = (char) ('0' + u % 10);  u /= 10; } while (u != 0);
+	while (n > 0) *(p++) = digits[--n];
+	return p;
+	}
+
+static char* put_u64 (char* p, unsigned long long u, int minDigits)
+	{
+	char digits[24];
+	int  n = 0;
+	do { digits[n++] = (char) ('0' + u % 10);  u /= 10; } while (u != 0);
+	while (n < minDigits) digits[n++] = '0';
+	while (n > 0) *(p++) = digits[--n];
+	return p;
+	}
+
+static char* put_fixed (char* p, valtype v, int precision)              /* %.*f */
+	{
+	static const unsigned long long pow10[] = { 1ull, 10ull, 100ull, 1000ull, 10000ull, 100000ull, 1000000ull, 10000000ull,
+	                                            100000000ull, 1000000000ull };
+	if ((precision >= 0) && (precision <= 9) && (fabs (v) * (double) pow10[precision] < 9.0e18))    /* (a NaN fails) */
+		{
+		/* v = m * 2^e exactly, so v * 10^precision = m * 10^precision / 2^-e in 128 bits: round that to the
+		 * nearest integer, ties to even, which is how printf rounds the exact decimal expansion
+		 * (held to snprintf on 20 M values of every kind, tools/check_output_format.c) */
+		int e;
+		const double    a = fabs (v);
+		const long long m = (long long) ldexp (frexp (a, &e), 53);
+		e -= 53;
+		if (e > -120)
+			{
+			unsigned __int128 scaled = (unsigned __int128) (unsigned long long) m * pow10[precision];
+			unsigned long long q;
+			if (e >= 0) q = (unsigned long long) (scaled << e);
+			else
+				{
+				const int shift = -e;
+				const unsigned __int128 rem  = scaled & ((((unsigned __int128) 1) << shift) - 1);
+				const unsigned __int128 half = ((unsigned __int128) 1) << (shift - 1);
+				q = (unsigned long long) (scaled >> shift);
+				if ((rem > half) || ((rem == half) && (q & 1))) q++;
+				}
+			if (signbit (v)) *(p++) = '-';
+			p = put_u64 (p, q / pow10[precision], 1);
+			if (precision > 0) { *(p++) = '.';  p = put_u64 (p, q % pow10[precision], precision); }
+			return p;
+			}
+		}
+	return p + snprintf (p, 400, valtypeFmtPrec, precision, v);
+	}
+
+static void out_line (FILE* f, const char* chrom, int start, int end, int withVal, valtype v, int precision, int na)
+	{
+	char* p = outAt;
+	p = put_text (p, chrom);  *(p++) = '\t';
+	p = put_int (p, start);   *(p++) = '\t';
+	p = put_int (p, end);
+	if (na)           { *(p++) = '\t';  *(p++) = 'N';  *(p++) = 'A'; }
+	else if (withVal) { *(p++) = '\t';  p = put_fixed (p, v, precision); }
+	*(p++) = '\n';
+	outAt = p;
+	if (outAt - outBuf > OUTBUF_BYTES) out_flush (f);
+	}
+
 /* report_intervals, genodsp.c:1561-1691: runs come from the device
  * (gdsp_report_runs), the NA bookkeeping and formatting are done here */
 void report_intervals (FILE* f, int precision, int noValues, int collapse, int uncovered, int origin1)
@@ -815,13 +896,13 @@ void report_intervals (FILE* f, int precision, int noValues, int collapse, int u
 			{
 			u32 outputStart = s->start + runStart[r], outputEnd = s->start + runEnd[r];
 			if ((uncovered == uncovered_NA) && (outputStart != prevOutputEnd))
-				fprintf (f, "%s\t%d\t%d\tNA\n", s->chrom, prevOutputEnd+o, outputStart);
-			if (noValues) fprintf (f, "%s\t%d\t%d\n", s->chrom, outputStart+o, outputEnd);
-			else          fprintf (f, "%s\t%d\t%d\t" valtypeFmtPrec "\n", s->chrom, outputStart+o, outputEnd, precision, runVal[r]);
+				out_line (f, s->chrom, (int) (prevOutputEnd+o), (int) outputStart, false, 0.0, 0, true);
+			out_line (f, s->chrom, (int) (outputStart+o), (int) outputEnd, !noValues, runVal[r], precision, false);
 			prevOutputEnd = outputEnd;
 			}
 		if ((uncovered == uncovered_NA) && (s->start + s->length != prevOutputEnd))
-			fprintf (f, "%s\t%d\t%d\tNA\n", s->chrom, prevOutputEnd+o, s->start + s->length);
+			out_line (f, s->chrom, (int) (prevOutputEnd+o), (int) (s->start + s->length), false, 0.0, 0, true);
+		out_flush (f);
 		free (runStart);  free (runEnd);  free (runVal);
 		}
 	if (trackOperations) tracking_report ("output(--done--)\n");

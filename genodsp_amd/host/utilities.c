@@ -46,10 +46,23 @@ int string_to_int (const char* s)
 	return v;
 	}
 
+/* 1 to 9 decimal digits and nothing else: what nearly every field of an interval file is.  Same
+ * value as the general conversions below give, without the cost of sscanf (ingest is bound by it). */
+static int plain_digits (const char* s, u32* v)
+	{
+	u32 x = 0;
+	int n = 0;
+	for ( ; (s[n] >= '0') && (s[n] <= '9') ; n++) { if (n == 9) return false;  x = 10*x + (u32) (s[n] - '0'); }
+	if ((n == 0) || (s[n] != 0)) return false;
+	*v = x;
+	return true;
+	}
+
 int string_to_u32 (const char* s)
 	{
 	u32  v;
 	char extra;
+	if (plain_digits (s, &v)) return (int) v;
 	if ((s[0] == '-') || (sscanf (s, "%u%c", &v, &extra) != 1)) die ("is not an unsigned integer", s);
 	return (int) v;
 	}
@@ -99,6 +112,8 @@ int try_string_to_double (const char* s, double* v)
 	double      x;
 	char        extra;
 
+	u32 whole;
+	if (plain_digits (s, &whole)) { if (v != NULL) *v = (double) whole;  return true; }   /* exact: < 2^53 */
 	while ((*t == ' ') || (*t == '\t') || (*t == '\n')) t++;
 	if (*t == 0) return false;
 	for (size_t i=0 ; i<sizeof(named)/sizeof(named[0]) ; i++)

@@ -83,3 +83,14 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(L, "SO_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(L.GdspError):
         L.lib()
+
+
+def test_driver_output_formatter_prints_what_printf_prints():
+    """genodsp_hip formats its output lines by hand (the report is bound by fprintf otherwise); the function is
+    pulled out of the driver's source and held to snprintf("%.*f") on 2 M values: integers, decimal-looking
+    values near ties, dyadic fractions, random bit patterns, precisions 0..9."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run(["bash", "tools/check_output_format.sh", "2000000"], cwd=root, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    assert p.stdout.strip().splitlines()[-1] == "bad=0", p.stdout[-2000:]
