@@ -474,72 +474,7 @@ static void allocate_vectors (void)
 	}
 
 /* ---------------------------------------------------------------- text ingest */
-int read_interval (FILE* f, char* buffer, int bufferLen, int valCol,     /* genodsp.c:1384-1534 */
-                   char** _chrom, u32* _start, u32* _end, valtype* _val)
-	{
-	static u64 lineNumber = 0;
-	static int missingEol = false;
-	char *scan, *mark, *field;
-
-	for (;;)
-		{
-		if (fgets (buffer, bufferLen, f) == NULL) return false;
-		lineNumber++;
-		if (missingEol)
-			{ fprintf (stderr, "problem at line %s, line is longer than internal buffer\n", ucommatize (lineNumber-1));  exit (EXIT_FAILURE); }
-		size_t len = strlen (buffer);
-		if (len != 0) missingEol = (buffer[len-1] != '\n');
-		if (strcmp_prefix (buffer, "track ") == 0) continue;
-
-		int progressNow = (reportInputProgress != 0)
-		               && ((lineNumber == 1) || (lineNumber % reportInputProgress == 0));
-		scan = skip_whitespace (buffer);
-		if (*scan == 0)
-			{ if (progressNow) fprintf (stderr, "progress: input line %s\n", ucommatize (lineNumber));  continue; }
-		if (*scan == '#')
-			{
-			if (reportComments)   fprintf (stderr, "input line %s: %s", ucommatize (lineNumber), scan);
-			else if (progressNow) fprintf (stderr, "progress: input line %s\n", ucommatize (lineNumber));
-			continue;
-			}
-		if (progressNow) fprintf (stderr, "progress: input line %s\n", ucommatize (lineNumber));
-		break;
-		}
-
-	char* chrom = scan = buffer;
-	if (*scan == ' ')
-		{ fprintf (stderr, "problem at line %s, line contains no chromosome or begins with whitespace\n", ucommatize (lineNumber));  exit (EXIT_FAILURE); }
-	mark = skip_darkspace (scan);  scan = skip_whitespace (mark);  if (*mark != 0) *mark = 0;
-	if (*scan == 0)
-		{ fprintf (stderr, "problem at line %s, line contains no interval start\n", ucommatize (lineNumber));  exit (EXIT_FAILURE); }
-	field = scan;
-	mark = skip_darkspace (scan);  scan = skip_whitespace (mark);  if (*mark != 0) *mark = 0;
-	u32 start = (u32) string_to_u32 (field);
-	if (*scan == 0)
-		{ fprintf (stderr, "problem at line %s, line contains no interval end\n", ucommatize (lineNumber));  exit (EXIT_FAILURE); }
-	field = scan;
-	mark = skip_darkspace (scan);  scan = skip_whitespace (mark);  if (*mark != 0) *mark = 0;
-	u32 end = (u32) string_to_u32 (field);
-
-	valtype val = 1.0;
-	if ((valCol != -1) && (_val != NULL))
-		{
-		for (int col=3 ; col<=valCol ; col++)
-			{
-			if (*scan == 0)
-				{ fprintf (stderr, "problem at line %s, line contains no interval value\n", ucommatize (lineNumber));  exit (EXIT_FAILURE); }
-			field = scan;
-			mark = skip_darkspace (scan);  scan = skip_whitespace (mark);
-			}
-		if (*mark != 0) *mark = 0;
-		val = string_to_valtype (field);
-		}
-	if (_chrom != NULL) *_chrom = chrom;
-	if (_start != NULL) *_start = start;
-	if (_end   != NULL) *_end   = end;
-	if (_val   != NULL) *_val   = val;
-	return true;
-	}
+/* (read_interval, the line reader, is ingest.c) */
 
 /* Pending intervals per chromosome, in file order, flushed to the device in
  * batches: pinned staging -> hipMemcpyAsync -> gdsp_apply_intervals. */

@@ -58,6 +58,16 @@ static int plain_digits (const char* s, u32* v)
 	return true;
 	}
 
+int try_string_to_u32 (const char* s, u32* out)
+	{
+	u32  v;
+	char extra;
+	if (plain_digits (s, &v)) { *out = v;  return true; }
+	if ((s[0] == '-') || (sscanf (s, "%u%c", &v, &extra) != 1)) return false;
+	*out = v;
+	return true;
+	}
+
 int string_to_u32 (const char* s)
 	{
 	u32  v;

@@ -16,6 +16,7 @@ int    string_to_int          (const char* s);
 int    string_to_u32          (const char* s);
 int    string_to_unitized_int (const char* s, int byThousands);       /* 10K, 1.5M, 2G                 */
 double string_to_double       (const char* s);                        /* also inf, -inf, 1/inf         */
+int    try_string_to_u32      (const char* s, u32* v);
 int    try_string_to_double   (const char* s, double* v);
 char*  skip_whitespace        (char* s);
 char*  skip_darkspace         (char* s);

@@ -183,3 +183,61 @@ def test_smooth_arithmetic_modes_on_the_command_line(tmp_path):
         assert np.abs(outs[mode] - outs["exact"]).max() <= 2e-9
     rc, out, err = run(["--smooth=nosuch"], "", "chrQ 10\n", tmp_path)
     assert rc != 0
+
+
+def _reads(rng, n_lines, chrom_len, with_values):
+    lines = []
+    for i in range(n_lines):
+        c = "chr%d" % (1 + int(rng.integers(0, 3)))
+        a = int(rng.integers(0, chrom_len - 300))
+        b = a + int(rng.integers(1, 300))
+        if with_values:
+            lines.append("%s\t%d\t%d\t%s" % (c, a, b, ("%d" % rng.integers(1, 9)) if i % 3 else ("%.3f" % (rng.random() * 4))))
+        else:
+            lines.append("%s %d %d" % (c, a, b))
+        if i % 5000 == 17:
+            lines.append("# a comment")
+        if i % 7000 == 23:
+            lines.append("track name=x")
+        if i % 9000 == 31:
+            lines.append("")
+    return lines
+
+
+@pytest.mark.parametrize("with_values", [False, True])
+def test_threaded_ingest_reads_what_the_line_reader_reads(with_values, tmp_path, monkeypatch):
+    """The block reader (ingest.c: 16 MiB blocks cut into one stretch per thread) against the line-at-a-time
+    reader it replaces (GDSP_INGEST_THREADS=1): same output, and for broken input the same first complaint."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    chroms = "chr1 400000\nchr2 300000\nchr3 200000\n"
+    good = _reads(rng, 120000, 200000, with_values)                 # ~2.5 MB: several stretches
+    args = ["--precision=3", "=", "smooth", "W=11"] if with_values else ["--novalue"]
+
+    def both(lines, final_newline=True):
+        text = "\n".join(lines) + ("\n" if final_newline else "")
+        got = []
+        for threads in ("1", "7"):
+            monkeypatch.setenv("GDSP_INGEST_THREADS", threads)
+            got.append(run(args, text, chroms, tmp_path))
+        assert got[0] == got[1], (got[0][0], got[1][0], got[0][2][-300:], got[1][2][-300:])
+        return got[0]
+
+    rc, out, err = both(good)
+    assert rc == 0 and len(out.splitlines()) > 1000
+    rc2, out2, _ = both(good, final_newline=False)
+    assert (rc2, out2) == (rc, out)
+    for where in (3, 60000, len(good) - 2):                          # first, middle and last stretch
+        for bad in ("chr1 12", "chr1", "chr1 x12 40", "chr1 12 -4", " chr1 5 9", "chr2 7 9 " + ("zz" if with_values else "1"),
+                    "chr1 5 " + "9" * 1100, "chr1\t10\t20\t1\t" + "x" * 1200):
+            lines = list(good)
+            lines[where] = bad
+            rc, out, err = both(lines)
+            if bad.endswith("zz") or "x12" in bad or "-4" in bad or len(bad) > 1000 or bad in ("chr1 12", "chr1", " chr1 5 9"):
+                assert rc != 0 and err != "", bad
+    # two broken lines: the earlier one is the one reported
+    lines = list(good)
+    lines[90000] = "chr1 1"
+    lines[20000] = "chr1 zz 4"
+    rc, out, err = both(lines)
+    assert rc != 0 and "zz" in err
