@@ -57,6 +57,10 @@ def main():
                     help="debugging: every rank uses GPU 0 and the gloo backend, to exercise the N>1 code path "
                          "where only one GPU exists (numbers from such a run mean nothing)")
     ap.add_argument("--nofuse", action="store_true", help="peaks/morph workloads: one kernel per operator")
+    ap.add_argument("--sharding", choices=["chromosomes", "bases"], default="chromosomes",
+                    help="chromosomes = whole chromosomes dealt longest-first over the ranks (BASELINE's sharding, the "
+                         "default); bases = every rank takes an equal stretch of the concatenated genome, chromosomes "
+                         "cut where needed and each piece carrying the half window of neighbours it needs (smooth only)")
     ap.add_argument("--workload", choices=["smooth", "peaks", "morph", "percentile"], default="smooth",
                     help="smooth = BASELINE configs[1] (the metric); the others are configs[2..4], "
                          "reported in the same shape for DESIGN.md, never the driver's number")
@@ -92,14 +96,21 @@ def main():
     lengths = [max(1, int(n * args.scale)) for _, n in GENOME]
     total_bases = sum(lengths)
     lpt_shards = gd.lpt_shards
-    mine = lpt_shards(lengths, world)[rank]
+    if args.sharding == "bases" and args.workload != "smooth":
+        raise SystemExit("--sharding bases is implemented for the smooth workload")
+    # a piece = (chromosome, first base held, first base owned, end of owned): whole chromosomes hold what they own;
+    # a cut chromosome also holds (WINDOW-1)/2 neighbours either side of what it owns
+    shards = shard_pieces(lengths, world, args.sharding, lpt_shards)
+    pieces = dict(enumerate(shards[rank])) if args.sharding == "bases" else {c: (c, 0, 0, lengths[c]) for c, _, _, _ in shards[rank]}
+    mine = list(pieces)
+    held = {k: piece_extent(pieces[k], lengths) for k in mine}          # (lo, hi) of the bases resident for piece k
 
-    # ---- resident signal: in/out vector per chromosome of this rank, generated in HBM
+    # ---- resident signal: in/out vector per piece of this rank, generated in HBM
     stream = gd.Stream()
-    vin = {i: gd.DeviceVector(lengths[i]) for i in mine}
-    vout = {i: gd.DeviceVector(lengths[i]) for i in mine}
-    for i in mine:
-        gd.synth_coverage(SEED, i, 0, lengths[i], mode=1, out=vin[i], stream=stream.handle)
+    vin = {k: gd.DeviceVector(held[k][1] - held[k][0]) for k in mine}
+    vout = {k: gd.DeviceVector(held[k][1] - held[k][0]) for k in mine}
+    for k in mine:
+        gd.synth_coverage(SEED, pieces[k][0], held[k][0], held[k][1] - held[k][0], mode=1, out=vin[k], stream=stream.handle)
     stream.sync()
 
     def step(mode):
@@ -143,13 +154,15 @@ def main():
 
     # ---- parity spot check against the CPU oracle (checker only): sampled windows of the
     #      longest local chromosome, exact mode must be bit-identical, fma within tolerance
-    parity = spot_check(gd, vin, vout, mine, lengths, stream)
+    parity = spot_check(gd, vin, vout, pieces, held, lengths, stream)
 
     def roofline(mode, dev_ms_per_step):
         # per launch: algorithmic bytes = 16 B/base x bases of that launch; averaged over the
         # rank with the most bases (the one that sets the step time)
-        bases_rank = max(sum(lengths[i] for i in sh) for sh in lpt_shards(lengths, world))
-        launches = max(1, len(lpt_shards(lengths, world)[0]))
+        owned = [sum(b - a for _, _, a, b in sh) for sh in shards]
+        busiest = max(range(world), key=lambda r: owned[r])
+        bases_rank = owned[busiest]
+        launches = max(1, len(shards[busiest]))
         avg_launch_ms = dev_ms_per_step / launches
         achieved = BYTES_PER_BASE * bases_rank / (dev_ms_per_step * 1e-3) / 1e9
         kernel = KERNELS[mode]
@@ -178,7 +191,9 @@ def main():
         "data": "synthetic",
         "config": {"workload": "smooth W=101 on 24-chrom 3.1 Gbp synthetic signal (BASELINE configs[1])",
                    "window": WINDOW, "chromosomes": len(GENOME), "bases": total_bases,
-                   "fir_mode": args.mode, "sharding": "whole chromosomes, LPT over ranks",
+                   "fir_mode": args.mode,
+                   "sharding": "whole chromosomes, LPT over ranks" if args.sharding == "chromosomes"
+                               else "equal stretches of the concatenated genome, pieces with a half-window halo",
                    "signal": "read-depth-like x U(0.5,1.5), seed %d" % SEED},
         "roofline": roofline(args.mode, dev_ms),
         "other_modes": [{"fir_mode": m, "value": round(total_bases / (w * 1e-3) / 1e9, 2),
@@ -192,6 +207,28 @@ def main():
         print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def shard_pieces(lengths, world, sharding, lpt_shards):
+    """Per rank, the pieces (chromosome, unused, first owned base, end of owned bases) it processes."""
+    if sharding == "chromosomes":
+        return [[(c, 0, 0, lengths[c]) for c in sh] for sh in lpt_shards(lengths, world)]
+    total = sum(lengths)
+    cuts = [total * r // world for r in range(world + 1)]
+    shards, start = [[] for _ in range(world)], 0
+    for c, n in enumerate(lengths):
+        for r in range(world):
+            a, b = max(cuts[r], start), min(cuts[r + 1], start + n)
+            if a < b:
+                shards[r].append((c, 0, a - start, b - start))
+        start += n
+    return shards
+
+
+def piece_extent(piece, lengths):
+    c, _, a, b = piece
+    half = (WINDOW - 1) // 2
+    return max(0, a - half), min(lengths[c], b + half)
 
 
 def other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_bases, vin, vout, stream, timed_fn,
@@ -277,28 +314,31 @@ def measured_traffic(kernel, algorithmic_bytes_per_launch):
     return None if ratio is None else int(ratio * algorithmic_bytes_per_launch)
 
 
-def spot_check(gd, vin, vout, mine, lengths, stream):
+def spot_check(gd, vin, vout, pieces, held, lengths, stream):
     from oracle import cpu                           # the checker; never on the measured path
-    i = max(mine, key=lambda k: lengths[k])
-    n = lengths[i]
+    k = max(pieces, key=lambda q: pieces[q][3] - pieces[q][2])
+    c, _, a, b = pieces[k]                           # owned bases [a,b) of chromosome c, resident [lo,hi)
+    lo, hi = held[k]
+    n = lengths[c]
     rng = np.random.default_rng(1)
     half = (WINDOW - 1) // 2
-    starts = [0, max(0, n - 4096)] + [int(s) for s in rng.integers(0, max(1, n - 4096), 6)]
+    span = min(4096, b - a)
+    starts = [a, b - span] + [int(s) for s in rng.integers(a, max(a + 1, b - span), 6)]
     taps = cpu.hann_window(WINDOW)
-    out = {"chromosome": GENOME[i][0], "windows": len(starts), "window_len": min(4096, n)}
+    out = {"chromosome": GENOME[c][0], "owned": [a, b], "windows": len(starts), "window_len": span}
     worst = {"fma": 0.0, "hann": 0.0}
     exact_ok = True
     for mode, key in ((gd.FIR_EXACT, "exact"), (gd.FIR_FMA, "fma"), (gd.FIR_HANN, "hann")):
-        gd.smooth(vin[i], WINDOW, out=vout[i], mode=mode, stream=stream.handle)
+        gd.smooth(vin[k], WINDOW, out=vout[k], mode=mode, stream=stream.handle)
         stream.sync()
         for s in starts:
-            m = min(4096, n - s)
-            lo, hi = max(0, s - half), min(n, s + m + half)
-            x = cpu.synth_coverage(SEED, i, lo, hi - lo, 1)
-            xp = np.concatenate([np.zeros(half - (s - lo)), x, np.zeros(half - (hi - (s + m)))])
+            m = min(span, b - s)
+            xlo, xhi = max(0, s - half), min(n, s + m + half)
+            x = cpu.synth_coverage(SEED, c, xlo, xhi - xlo, 1)
+            xp = np.concatenate([np.zeros(half - (s - xlo)), x, np.zeros(half - (xhi - (s + m)))])
             # zero-padded FIR of the padded stretch, then cut the m outputs that belong to [s, s+m)
             want = cpu.fir(xp, taps)[half:half + m] if xp.size > 2 * half else cpu.fir(xp, taps)
-            got = vout[i].buf.download(np.float64, m, vout[i].offset + 8 * s)
+            got = vout[k].buf.download(np.float64, m, vout[k].offset + 8 * (s - lo))
             if key == "exact":
                 exact_ok = exact_ok and (got.tobytes() == want.tobytes())
             else:

@@ -21,9 +21,9 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _bench(ranks, workload, scale):
+def _bench(ranks, workload, scale, extra=()):
     common = ["bench.py", "--gpus", str(ranks), "--workload", workload, "--scale", str(scale), "--steps", "1",
-              "--warmup", "0", "--no-cpu-baseline"]
+              "--warmup", "0", "--no-cpu-baseline"] + list(extra)
     if ranks == 1:
         cmd = [sys.executable] + common
     else:
@@ -54,3 +54,14 @@ def test_smooth_over_two_ranks_reports_the_whole_job():
                                           145138636, 138394717, 133797422, 135086622, 133275309, 114364328, 107043718,
                                           101991189, 90338345, 83257441, 80373285, 58617616, 64444167, 46709983,
                                           50818468, 156040895, 57227415])
+
+
+def test_smooth_over_equal_stretches_of_the_genome():
+    """--sharding bases: chromosomes are cut so that every rank owns the same number of bases; a cut piece holds
+    the half window of neighbours it needs, and its owned outputs must be those of the whole chromosome."""
+    one = _bench(1, "smooth", 0.02, ["--sharding", "bases"])
+    two = _bench(2, "smooth", 0.02, ["--sharding", "bases"])
+    for r in (one, two):
+        assert r["parity"]["ok"] and r["parity"]["exact_bit_identical"]
+        assert "equal stretches" in r["config"]["sharding"]
+    assert two["roofline"]["algorithmic_bytes_per_launch"] * two["roofline"]["launches_per_step"] <= 16 * (two["config"]["bases"] // 2 + 1)
