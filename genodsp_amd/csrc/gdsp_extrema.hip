@@ -16,19 +16,21 @@
 // reference's pick depends on its scan history).
 //
 // HBM-bound (16 B/base).  A workgroup stages a tile plus its halo in LDS with
-// 16-byte loads; every lane then produces two adjacent outputs and stores them
-// as one 16-byte word.  Windows up to 32 bases are scanned directly from LDS, up
-// to 256 by log2 doubling in LDS, longer ones with the van Herk / Gil-Werman
-// decomposition (prefix and suffix extremes over window-long segments, three
-// comparisons per base for any window).
+// 16-byte loads.  Windows up to 16 bases are scanned directly from LDS (two
+// adjacent outputs per lane); windows of 17 .. 3584 bases use the block form
+// (extrema_blocks_kernel: tail of a block + whole blocks from one level of a
+// sparse table + head of a block, four comparisons per base for any window,
+// 5.5-6.0 TB/s measured from 33 to 2049 bases); longer ones the van Herk /
+// Gil-Werman decomposition over window-long segments in one LDS tile, and past
+// that gdsp_longwin.hip through HBM workspace.
 
 #include <float.h>
+#include <stdlib.h>
 #include "gdsp_common.h"
 
 #define EX_THREADS 256
 #define EX_TILE    4096              // outputs per workgroup
-#define EX_DIRECT_MAX_SPAN 32        // windows up to this many bases are scanned directly
-#define EX_DOUBLING_MAX_SPAN 256     // up to here: log2 doubling; beyond: segment prefix/suffix extremes
+#define EX_DIRECT_MAX_SPAN 16        // windows up to this many bases are scanned directly
 #define EX_LDS_DOUBLES 18432         // 144 KiB of the 160 KiB LDS
 
 template <bool MAX> __device__ __forceinline__ bool ex_beats (double a, double b)
@@ -67,7 +69,7 @@ __device__ __forceinline__ double ex_seg_carry (double val, bool flag, double pa
 	}
 
 // LOCAL: localmin/localmax semantics; otherwise bestmin/bestmax
-enum { EX_DIRECT = 0, EX_DOUBLING = 1, EX_SEGMENTS = 2 };
+enum { EX_DIRECT = 0, EX_SEGMENTS = 2 };
 
 template <bool MAX, bool LOCAL, int METHOD>
 __global__ __launch_bounds__(EX_THREADS)
@@ -109,41 +111,6 @@ void extrema_kernel (const double* __restrict__ in, double* __restrict__ out, ui
 			int64_t g = tileStart + o;
 			if (g + 1 < (int64_t) n) *reinterpret_cast<double2*> (out + g) = make_double2 (e0, e1);
 			else if (g < (int64_t) n) out[g] = e0;
-			}
-		return;
-		}
-
-	if (METHOD == EX_DOUBLING)
-		{
-		// medium windows: after step s, cur[i] = extreme of x[i .. i+2^s); ping-pong between two
-		// LDS arrays, log2(span) sweeps, then every window is two lookups
-		double* cur = lds;
-		double* nxt = lds + L;
-		int     lg  = 0;
-		while ((2 << lg) <= span) lg++;              // 2^lg <= span < 2^(lg+1)
-		for (int s=0 ; s<lg ; s++)
-			{
-			const int half = 1 << s;
-			for (int p=threadIdx.x ; p+2*half<=L ; p+=EX_THREADS) nxt[p] = ex_pick<MAX> (cur[p], cur[p+half]);
-			__syncthreads ();
-			double* swap = cur;  cur = nxt;  nxt = swap;
-			}
-		const int     w2 = 1 << lg;
-		const double* mm = cur + sh;
-		for (int o = 2*threadIdx.x ; o < tile ; o += 2*EX_THREADS)
-			{
-			int64_t g = tileStart + o;
-			if (g >= (int64_t) n) break;
-			double e0 = ex_pick<MAX> (mm[o],   mm[o   + span - w2]);
-			double e1 = ex_pick<MAX> (mm[o+1], mm[o+1 + span - w2]);
-			if (LOCAL)
-				{
-				double c0 = in[g], c1 = (g + 1 < (int64_t) n)? in[g+1] : 0.0;   // staged copy consumed: centres from L2
-				e0 = ex_beats<MAX> (e0, c0)? fill : c0;
-				e1 = ex_beats<MAX> (e1, c1)? fill : c1;
-				}
-			if (g + 1 < (int64_t) n) *reinterpret_cast<double2*> (out + g) = make_double2 (e0, e1);
-			else                     out[g] = e0;
 			}
 		return;
 		}
@@ -216,6 +183,162 @@ void extrema_kernel (const double* __restrict__ in, double* __restrict__ out, ui
 		}
 	}
 
+// ------------------------------------------------------------- block form ----
+// Windows of 17 .. EXB_MAX_SPAN bases.  The staged tile is cut into blocks of 16; a window [a,b] is
+// the tail of a's block + the whole blocks between + the head of b's block, and an extreme does
+// not mind overlap, so the blocks between are two overlapping power-of-two ranges of block
+// extremes (one level of a sparse table, built by doubling over the 256 block extremes of the tile).
+// One thread owns one block as the right end b of 16 windows: prefix extremes of its own block in
+// registers, then one backward walk over the 16+dr elements that hold the 16 left ends, finishing
+// one output per step -- four v_max_f64 per base whatever the window, ~45 B/base of LDS traffic
+// against 16 B/base of HBM.  The LDS image has a pitch of 17 per block of 16, so the lane-strided
+// reads of both walks are conflict free (the same layout as gdsp_hann.hip).
+#define EXB_THREADS  256
+#define EXB_G        16
+#define EXB_PITCH    17
+#define EXB_ELEMS    (EXB_THREADS * EXB_G)
+#define EXB_MIN_SPAN 17
+#define EXB_MAX_SPAN 3584
+
+template <bool MAX, bool LOCAL>
+__global__ __launch_bounds__(EXB_THREADS)
+void extrema_blocks_kernel (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t ntiles,
+                            int rgt, int dq, int dr, int level, int sh, double fill)
+	{
+	__shared__ __attribute__((aligned(16))) double lds[EXB_THREADS * EXB_PITCH];
+	__shared__ double blockExt[2][EXB_THREADS];
+	const double pad   = MAX? -INFINITY : INFINITY;           // never beats anything, like "outside the vector"
+	const int    haloL = dq + 1;                              // leading blocks that only feed
+	const int    outs  = (EXB_THREADS - haloL) * EXB_G - 2*sh; // outputs stored per tile (even)
+	const int    nt    = dq - 1;                              // whole blocks always between
+	const int    lead  = haloL * EXB_G - rgt + sh;            // staged elements before output 0 of the tile (even)
+	const uint32_t tile = gdsp_xcd_tile (blockIdx.x, ntiles);
+	const int64_t  out0 = (int64_t) tile * outs;
+	const int64_t  e0   = out0 - lead;
+	const int      p    = threadIdx.x;
+
+	// ---- stage 4096 elements
+	if ((e0 >= 0) && (e0 + EXB_ELEMS <= (int64_t) n))
+		{
+		const double2* src = reinterpret_cast<const double2*> (in + e0);
+		double2 r[EXB_G/2];
+#pragma unroll
+		for (int u=0 ; u<EXB_G/2 ; u++) r[u] = src[u*EXB_THREADS + p];
+#pragma unroll
+		for (int u=0 ; u<EXB_G/2 ; u++)
+			{
+			const int e = 2 * (u*EXB_THREADS + p);
+			double* dst = lds + e + (e >> 4);
+			dst[0] = r[u].x;  dst[1] = r[u].y;
+			}
+		}
+	else
+		{
+		for (int e=p ; e<EXB_ELEMS ; e+=EXB_THREADS)
+			{
+			const int64_t g = e0 + e;
+			lds[e + (e >> 4)] = ((g >= 0) && (g < (int64_t) n))? in[g] : pad;
+			}
+		}
+	__syncthreads ();
+
+	// ---- prefix extremes of the own block; its extreme to the table
+	double P[EXB_G];
+		{
+		const double* xb = lds + p * EXB_PITCH;
+		double run = pad;
+#pragma unroll
+		for (int u=0 ; u<EXB_G ; u++) { run = ex_pick<MAX> (run, xb[u]);  P[u] = run; }
+		blockExt[0][p] = run;
+		}
+	__syncthreads ();
+	// one level of the sparse table: entry q covers blocks q .. q + 2^level - 1
+	for (int l=1 ; l<=level ; l++)
+		{
+		const int    half = 1 << (l - 1);
+		const double a    = blockExt[(l-1) & 1][p];
+		const double b    = (p + half < EXB_THREADS)? blockExt[(l-1) & 1][p + half] : pad;
+		blockExt[l & 1][p] = ex_pick<MAX> (a, b);
+		__syncthreads ();
+		}
+
+	// ---- one output per left end
+	const bool live = (p >= haloL);
+	if (live)
+		{
+		const double* ext = blockExt[level & 1];
+		double T = pad;                                           // whole blocks p-nt .. p-1
+		if (nt > 0) T = ex_pick<MAX> (ext[p - nt], ext[p - (1 << level)]);
+		const double* lb = lds + (p - dq) * EXB_PITCH;            // block of the left ends of s >= dr
+		const double* la = lb - EXB_PITCH + EXB_G;                // the block before it, indexed by u - dr < 0
+		const double* cx = lds;                                   // centres (LOCAL): element 16p + u - rgt
+		double run = pad;
+#pragma unroll
+		for (int u=2*EXB_G-2 ; u>=0 ; u--)
+			{
+			if (u >= EXB_G + dr) continue;                          // (uniform) the walk starts at u = 15 + dr
+			if (u == dr - 1) { T = ex_pick<MAX> (T, run);  run = pad; }   // that block is whole for the remaining windows
+			const int rel = u - dr;
+			run = ex_pick<MAX> (run, (rel >= 0)? lb[rel] : la[rel]);
+			if (u < EXB_G)
+				{
+				double e = ex_pick<MAX> (ex_pick<MAX> (run, T), P[u]);
+				if (LOCAL)
+					{
+					const int    c = EXB_G * p + u - rgt;
+					const double v = cx[c + (c >> 4)];
+					e = ex_beats<MAX> (e, v)? fill : v;
+					}
+				P[u] = e;
+				}
+			}
+		}
+	__syncthreads ();                                              // every read of the staged inputs is done
+
+	// ---- results back through LDS: thread haloL + k holds outputs 16k - sh .. 16k + 15 - sh of the tile
+	if (live)
+		{
+		double* mine = lds + (p - haloL) * EXB_PITCH;
+#pragma unroll
+		for (int u=0 ; u<EXB_G ; u++) mine[u] = P[u];
+		}
+	__syncthreads ();
+	if (out0 + outs <= (int64_t) n)
+		{
+		double2* dst = reinterpret_cast<double2*> (out + out0);
+		for (int q=p ; q<outs/2 ; q+=EXB_THREADS)
+			{
+			const int o = 2*q + sh;
+			const int o1 = o + 1;
+			dst[q] = make_double2 (lds[o + (o >> 4)], lds[o1 + (o1 >> 4)]);
+			}
+		}
+	else
+		{
+		for (int q=p ; q<outs ; q+=EXB_THREADS)
+			{
+			const int o = q + sh;
+			if (out0 + q < (int64_t) n) out[out0 + q] = lds[o + (o >> 4)];
+			}
+		}
+	}
+
+template <bool MAX, bool LOCAL>
+static void extrema_blocks_launch (const double* d_in, double* d_out, uint32_t n, uint32_t lft, uint32_t rgt, double fill,
+                                   hipStream_t s)
+	{
+	const int d  = (int) (lft + rgt);                             // left end = right end - d
+	const int dq = d / EXB_G, dr = d % EXB_G;
+	const int nt = dq - 1;
+	int level = 0;
+	while ((2 << level) <= nt) level++;                           // largest power of two <= nt (nt >= 1 here)
+	const int sh   = ((dq + 1) * EXB_G - (int) rgt) & 1;          // keeps the first staged element even
+	const int outs = (EXB_THREADS - (dq + 1)) * EXB_G - 2*sh;
+	const uint32_t ntiles = (uint32_t) (((uint64_t) n + outs - 1) / outs);
+	hipLaunchKernelGGL ((extrema_blocks_kernel<MAX, LOCAL>), dim3(ntiles), dim3(EXB_THREADS), 0, s,
+	                    d_in, d_out, n, ntiles, (int) rgt, dq, dr, level, sh, fill);
+	}
+
 template <bool MAX, bool LOCAL>
 static int extrema_launch (const double* d_in, double* d_out, uint32_t n, uint32_t lft, uint32_t rgt,
                            double fill, void* stream)
@@ -229,15 +352,19 @@ static int extrema_launch (const double* d_in, double* d_out, uint32_t n, uint32
 	if (lft > n) lft = n;
 	if (rgt > n) rgt = n;
 	const uint64_t span   = (uint64_t) lft + rgt + 1;
+	if ((span >= EXB_MIN_SPAN) && (span <= EXB_MAX_SPAN))
+		{
+		extrema_blocks_launch<MAX, LOCAL> (d_in, d_out, n, lft, rgt, fill, gdsp_stream (stream));
+		GDSP_LAUNCH_CHECK ();
+		return GDSP_OK;
+		}
 	const bool     direct = (span <= EX_DIRECT_MAX_SPAN);
-	const bool     medium = (span <= EX_DOUBLING_MAX_SPAN);
 	int            tile   = EX_TILE;
 	size_t         ldsDoubles;
 	if (direct) ldsDoubles = (size_t) tile + span + 2;
 	else
 		{
-		// two ping-pong arrays of tile+span; the tile is the smallest that keeps the halo <= tile/2
-		// that still fits
+		// two arrays of tile+span; the tile is the smallest that keeps the halo <= tile/2 that still fits
 		tile = 1024;
 		while (((uint64_t) tile < 2*(span-1)) && (2*(2*(uint64_t) tile + span + 2) <= EX_LDS_DOUBLES)) tile *= 2;
 		ldsDoubles = 2 * ((size_t) tile + span + 2);
@@ -253,9 +380,6 @@ static int extrema_launch (const double* d_in, double* d_out, uint32_t n, uint32
 	hipStream_t    s      = gdsp_stream (stream);
 	if (direct)
 		hipLaunchKernelGGL ((extrema_kernel<MAX, LOCAL, EX_DIRECT>),  dim3(ntiles), dim3(EX_THREADS), bytes, s,
-		                    d_in, d_out, n, ntiles, lft, rgt, fill, tile);
-	else if (medium)
-		hipLaunchKernelGGL ((extrema_kernel<MAX, LOCAL, EX_DOUBLING>), dim3(ntiles), dim3(EX_THREADS), bytes, s,
 		                    d_in, d_out, n, ntiles, lft, rgt, fill, tile);
 	else
 		{

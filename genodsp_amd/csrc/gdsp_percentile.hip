@@ -460,6 +460,7 @@ int gdsp_percentiles (const gdsp_select_source* sources, int nsources, uint32_t 
 	memset (pcStats, 0, sizeof(pcStats));
 	int homeDevice = 0;
 	GDSP_HIP_TRY (hipGetDevice (&homeDevice));
+	struct Home { int device;  ~Home () { (void) hipSetDevice (device); } } home = { homeDevice };   // whatever path returns
 
 	PcJob J;
 	J.src = sources;  J.nsrc = nsources;  J.window = window;  J.lo = lo;  J.hi = hi;  J.reduce = reduce;  J.ctx = reduceCtx;
@@ -509,9 +510,9 @@ int gdsp_percentiles (const gdsp_select_source* sources, int nsources, uint32_t 
 	for (int i=0 ; i<npercentiles ; i++) all.push_back (i);
 	int rc = GDSP_OK;
 	pcStats[0] = bracket? GDSP_SELECT_BRACKET : GDSP_SELECT_RADIX;
-	if (!bracket) { rc = pc_radix (J, pThousandths, all, values, count);  pcStats[1] = *count;  (void) hipSetDevice (homeDevice);  return rc; }
+	if (!bracket) { rc = pc_radix (J, pThousandths, all, values, count);  pcStats[1] = *count;  return rc; }
 
-	auto finish = [&] (int code) { (void) hipSetDevice (homeDevice);  return code; };
+	auto finish = [&] (int code) { return code; };
 
 	// ---- 1. subsample (slots of the sources of a device follow one another in its buffer)
 	for (size_t d=0 ; d<J.devices.size () ; d++)

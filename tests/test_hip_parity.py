@@ -337,6 +337,28 @@ def test_cumulative_sum(n, gd):
     assert np.abs(got - want).max() <= 2 * n * EPS * np.abs(want).max()
 
 
+@pytest.mark.parametrize("W", [17, 18, 32, 33, 48, 49, 50, 64, 65, 255, 256, 257, 2048, 2049, 3583, 3584, 3585])
+def test_best_and_local_extrema_block_form_seams(W, gd):
+    """Windows of 17..3584 bases run in the block form (extrema_blocks_kernel); its tile holds
+    (256 - (W-1)//16 - 1) * 16 outputs (2 fewer when the alignment shift is needed), so the vector lengths
+    here put its seams, the vector ends and a ragged last tile under the comparison."""
+    d = W - 1
+    outs = (256 - (d // 16 + 1)) * 16 if W <= 3584 else 4096
+    rng = np.random.default_rng(W)
+    for n in sorted({1, W - 1, W, outs - 2, outs - 1, outs, outs + 1, 2 * outs - 3, 3 * outs + 7, 50021}):
+        if n < 1:
+            continue
+        x = _signal("real", n, rng) if n % 2 else _signal("depth", n, rng)
+        dv = gd.DeviceVector.from_numpy(x)
+        for want_max in (True, False):
+            got = gd.best_extrema(dv, W, want_max).numpy()
+            assert bits_equal(got, cpu.best_extrema(x, W, 1 if want_max else 0)), (n, want_max, first_diff(
+                got, cpu.best_extrema(x, W, 1 if want_max else 0)))
+        if W % 2:
+            got = gd.local_extrema(dv, W, True, -3.0).numpy()
+            assert bits_equal(got, cpu.local_extrema(x, W, 1, -3.0)), n
+
+
 # -------------------------------------------------------------- percentile ----
 
 @pytest.mark.parametrize("kind", ["depth", "real", "noise"])
