@@ -39,6 +39,9 @@
 // smoothed track as a floating-point result.
 
 #include <math.h>
+#include <string.h>
+#include <algorithm>
+#include <mutex>
 #include "gdsp_common.h"
 
 #define HN_THREADS 256
@@ -271,8 +274,236 @@ static void hann_launch (const double* d_in, double* d_out, uint32_t n, hipStrea
 	hipLaunchKernelGGL ((hann_blocks_kernel<W>), dim3(ntiles), dim3(HN_THREADS), 0, s, d_in, d_out, n, ntiles, K);
 	}
 
+// ------------------------------------------------------ any window, 81 .. 2001 ----
+// The same evaluation with the geometry as run-time numbers: dq, dr, the number of whole blocks
+// between (their rotations come from a small table in HBM, read as scalars), the halo.  Only the
+// number of direct taps E stays a template parameter: the cancellation in S - C is bounded by the
+// smallest tap that goes through the block sums, and the bound of one rounding per operation
+// grows with W, which makes E ~ sqrt(0.15 W) enough (8 for W = 101, 16 for 1001, 20 for 2001);
+// E also carries the parity that keeps a tile's first element 16-byte aligned.
+#define HN_RT_MAX_NT 128
+struct HannRT
+	{
+	int    DQ, DR, NT, HALO_L, HALO_R, LO, LEAD, OUT;
+	double scale;
+	double edge[24];                                               // 1 - cos(w k), k = 1..E
+	double ownC[HN_G], ownS[HN_G];
+	double leftC[2*HN_G], leftS[2*HN_G];                           // exp(+j w (u - DM)), u = 0..15+DR
+	double demC[HN_G], demS[HN_G];                                 // exp(+j w (W-E - s))
+	};
+
+template <int E>
+__global__ __launch_bounds__(HN_THREADS)
+void hann_blocks_rt_kernel (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t ntiles,
+                            HannRT K, const double2* __restrict__ rot)
+	{
+	constexpr int NEDGE = HN_G + E - 1;
+	__shared__ __attribute__((aligned(16))) double lds[HN_THREADS * HN_PITCH];
+	__shared__ double tot[3][HN_THREADS];
+
+	const uint32_t tile = gdsp_xcd_tile (blockIdx.x, ntiles);
+	const int64_t  out0 = (int64_t) tile * K.OUT;
+	const int64_t  e0   = out0 - K.LEAD;                          // first staged element (even)
+	const int      p    = threadIdx.x;
+	const bool     live = (p >= K.HALO_L) && (p < HN_THREADS - K.HALO_R);
+
+	if ((e0 >= 0) && (e0 + HN_ELEMS <= (int64_t) n))
+		{
+		const double2* src = reinterpret_cast<const double2*> (in + e0);
+		double2 r[HN_G/2];
+#pragma unroll
+		for (int u=0 ; u<HN_G/2 ; u++) r[u] = src[u*HN_THREADS + p];
+#pragma unroll
+		for (int u=0 ; u<HN_G/2 ; u++)
+			{
+			const int e = 2 * (u*HN_THREADS + p);
+			double* dst = lds + e + (e >> 4);
+			dst[0] = r[u].x;  dst[1] = r[u].y;
+			}
+		}
+	else
+		{
+		for (int e=p ; e<HN_ELEMS ; e+=HN_THREADS)
+			{
+			const int64_t g = e0 + e;
+			lds[e + (e >> 4)] = ((g >= 0) && (g < (int64_t) n))? in[g] : 0.0;
+			}
+		}
+	__syncthreads ();
+
+	// ---- phase 0: the E taps at either end of each of the 16 windows, directly
+	double acc[HN_G];
+#pragma unroll
+	for (int s=0 ; s<HN_G ; s++) acc[s] = 0.0;
+	if (live)
+		{
+		const double* xl = lds + (p - K.HALO_L) * HN_PITCH;         // element b'-BACK of s=0 is xl[LO]
+#pragma unroll
+		for (int j=0 ; j<NEDGE ; j++)
+			{
+			const int    o = K.LO + j;
+			const double x = xl[o + (o >> 4)];
+#pragma unroll
+			for (int s=0 ; s<HN_G ; s++)
+				{ if ((j - s >= 0) && (j - s < E)) acc[s] = __builtin_fma (K.edge[j-s], x, acc[s]); }
+			}
+		const double* xr = lds + p * HN_PITCH;
+#pragma unroll
+		for (int j=1 ; j<=NEDGE ; j++)
+			{
+			const double x = xr[j + (j >> 4)];
+#pragma unroll
+			for (int s=0 ; s<HN_G ; s++)
+				{ if ((j - s >= 1) && (j - s <= E)) acc[s] = __builtin_fma (K.edge[E - (j-s)], x, acc[s]); }
+			}
+		}
+
+	// ---- phase 1: prefix sums of the own block in the own phase
+	double P0[HN_G], Pr[HN_G], Pi[HN_G];
+		{
+		const double* xb = lds + p * HN_PITCH;
+		double a0 = 0.0, ar = 0.0, ai = 0.0;
+#pragma unroll
+		for (int u=0 ; u<HN_G ; u++)
+			{
+			const double x = xb[u];
+			a0 += x;
+			ar  = __builtin_fma (x, K.ownC[u], ar);
+			ai  = __builtin_fma (x, K.ownS[u], ai);
+			P0[u] = a0;  Pr[u] = ar;  Pi[u] = ai;
+			}
+		tot[0][p] = a0;  tot[1][p] = ar;  tot[2][p] = ai;
+		}
+	__syncthreads ();
+
+	// ---- phase 2: the middle stretch of one window per left end
+	if (live)
+		{
+		double T0 = 0.0, Tr = 0.0, Ti = 0.0;                       // whole blocks p-NT .. p-1
+		for (int d=K.NT ; d>=1 ; d--)
+			{
+			const double  b0 = tot[0][p-d], br = tot[1][p-d], bi = tot[2][p-d];
+			const double2 w  = rot[d-1];                            // exp(-j w 16 d)
+			T0 += b0;
+			Tr += __builtin_fma (br, w.x, -(bi * w.y));
+			Ti += __builtin_fma (br, w.y,   bi * w.x);
+			}
+		const double* lb = lds + (p - K.DQ) * HN_PITCH;             // block of the left ends of s >= DR
+		const double* la = lb - HN_PITCH + HN_G;                    // the block before it, indexed by u - DR < 0
+		double s0 = 0.0, sr = 0.0, si = 0.0;
+#pragma unroll
+		for (int u=2*HN_G-2 ; u>=0 ; u--)
+			{
+			if (u >= HN_G + K.DR) continue;                         // (uniform) the walk starts at u = 15 + DR
+			if (u == K.DR - 1) { T0 += s0;  Tr += sr;  Ti += si;  s0 = 0.0;  sr = 0.0;  si = 0.0; }
+			const int    rel = u - K.DR;
+			const double x   = (rel >= 0)? lb[rel] : la[rel];
+			s0 += x;
+			sr  = __builtin_fma (x, K.leftC[u], sr);
+			si  = __builtin_fma (x, K.leftS[u], si);
+			if (u < HN_G)
+				{
+				const double z0 = (s0 + T0) + P0[u];
+				const double zr = (sr + Tr) + Pr[u];
+				const double zi = (si + Ti) + Pi[u];
+				const double c  = __builtin_fma (K.demC[u], zr, -(K.demS[u] * zi));
+				acc[u] = K.scale * ((z0 - c) + acc[u]);
+				}
+			}
+		}
+	__syncthreads ();
+
+	if (live)
+		{
+		double* mine = lds + (p - K.HALO_L) * HN_PITCH;
+#pragma unroll
+		for (int u=0 ; u<HN_G ; u++) mine[u] = acc[u];
+		}
+	__syncthreads ();
+
+	if (out0 + K.OUT <= (int64_t) n)
+		{
+		double2* dst = reinterpret_cast<double2*> (out + out0);
+		for (int q=p ; q<K.OUT/2 ; q+=HN_THREADS)
+			{
+			const int o = 2*q;
+			const double* src = lds + o + (o >> 4);
+			dst[q] = make_double2 (src[0], src[1]);
+			}
+		}
+	else
+		{
+		for (int o=p ; o<K.OUT ; o+=HN_THREADS)
+			{ if (out0 + o < (int64_t) n) out[out0 + o] = lds[o + (o >> 4)]; }
+		}
+	}
+
+// plans of the run-time kernel, cached per (device, W): the geometry and the rotation table in HBM
+struct HannPlanRT { int device;  uint32_t W;  int E;  HannRT K;  double2* d_rot; };
+#define HN_PLAN_CACHE 32
+static HannPlanRT hannPlans[HN_PLAN_CACHE];
+static int        hannPlanLen = 0;
+static std::mutex hannPlanLock;
+
+static int hann_direct_taps (uint32_t W)                            // E: enough taps, right parity, an instantiated value
+	{
+	static const int allowed[] = { 8, 9, 12, 13, 16, 17, 20, 21 };
+	const int H    = (int) (W - 1) / 2;
+	const int need = std::max (8, (int) ceil (sqrt (0.15 * W)));
+	for (int e : allowed) { if ((e >= need) && (((H - e) & 1) == 0)) return e; }
+	return -1;
+	}
+
+static int hann_plan_rt (uint32_t W, HannPlanRT** out)
+	{
+	int device = 0;
+	GDSP_HIP_TRY (hipGetDevice (&device));
+	std::lock_guard<std::mutex> hold (hannPlanLock);
+	for (int i=0 ; i<hannPlanLen ; i++)
+		{ if ((hannPlans[i].device == device) && (hannPlans[i].W == W)) { *out = &hannPlans[i];  return GDSP_OK; } }
+	GDSP_REQUIRE (hannPlanLen < HN_PLAN_CACHE, "too many different smoothing windows in one run");
+	HannPlanRT* pl = &hannPlans[hannPlanLen];
+	memset (pl, 0, sizeof(*pl));
+	pl->device = device;  pl->W = W;
+	const int E = pl->E = hann_direct_taps (W);
+	const int H = (int) (W - 1) / 2, DM = (int) W - 2*E - 1, BACK = DM + E;
+	HannRT& K = pl->K;
+	K.DQ = DM / HN_G;  K.DR = DM % HN_G;  K.NT = K.DQ - 1;
+	K.HALO_L = (BACK + HN_G - 1) / HN_G;  K.HALO_R = (HN_G - 1 + E) / HN_G;
+	K.LO   = K.HALO_L * HN_G - BACK;
+	K.LEAD = K.HALO_L * HN_G - (H - E);
+	K.OUT  = (HN_THREADS - K.HALO_L - K.HALO_R) * HN_G;
+	const double pi = 3.14159265358979323846264;
+	const long   M  = (long) W + 1;
+	auto cs = [&] (long m, double* c, double* sn)
+		{
+		long r = ((m % M) + M) % M;
+		double x = r / (double) M;
+		*c = cos (2*pi*x);  *sn = sin (2*pi*x);
+		};
+	for (int k=1 ; k<=E ; k++)            { double c, sn;  cs (k, &c, &sn);  K.edge[k-1] = 1 - c; }
+	for (int u=0 ; u<HN_G ; u++)          cs (u, &K.ownC[u], &K.ownS[u]);
+	for (int u=0 ; u<HN_G + K.DR ; u++)   cs ((long) u - DM, &K.leftC[u], &K.leftS[u]);
+	for (int u=0 ; u<HN_G ; u++)          cs ((long) W - E - u, &K.demC[u], &K.demS[u]);
+	double total = 0.0;                                            // as gdsp_hann_taps sums it (sum.c:632-645)
+	for (uint32_t k=0 ; k<W ; k++)
+		{
+		const uint32_t kk = (k <= (uint32_t) H)? k : W-1-k;
+		total += (1 - cos (2*pi*((kk+1) / (double) M))) / 2;
+		}
+	K.scale = 0.5 / total;
+	double2 h_rot[HN_RT_MAX_NT];
+	for (int d=1 ; d<=K.NT ; d++) cs (-(long) HN_G * d, &h_rot[d-1].x, &h_rot[d-1].y);
+	GDSP_HIP_TRY (hipMalloc ((void**) &pl->d_rot, sizeof(h_rot)));
+	GDSP_HIP_TRY (hipMemcpy (pl->d_rot, h_rot, sizeof(h_rot), hipMemcpyHostToDevice));
+	hannPlanLen++;
+	*out = pl;
+	return GDSP_OK;
+	}
+
 // 1 when GDSP_FIR_HANN has a kernel for this window
-bool gdsp_hann_blocks_available (uint32_t W) { return W == 101; }
+bool gdsp_hann_blocks_available (uint32_t W)
+	{ return (W & 1) && (W >= 81) && (W <= 2001) && (hann_direct_taps (W) > 0); }   // (below ~80 taps the direct kernel is faster)
 
 int gdsp_hann_blocks_apply (const double* d_in, double* d_out, uint32_t n, uint32_t W, void* stream)
 	{
@@ -280,7 +511,26 @@ int gdsp_hann_blocks_apply (const double* d_in, double* d_out, uint32_t n, uint3
 	if (n == 0) return GDSP_OK;
 	GDSP_REQUIRE ((d_in != NULL) && (d_out != NULL) && (d_in != d_out), "vectors must be distinct and non-NULL");
 	GDSP_REQUIRE (gdsp_aligned16 (d_in) && gdsp_aligned16 (d_out), "vectors must be 16-byte aligned");
-	hann_launch<101> (d_in, d_out, n, gdsp_stream (stream));
+	hipStream_t s = gdsp_stream (stream);
+	if (W == 101) { hann_launch<101> (d_in, d_out, n, s);  GDSP_LAUNCH_CHECK ();  return GDSP_OK; }
+	HannPlanRT* pl = NULL;
+	int rc = hann_plan_rt (W, &pl);
+	if (rc != GDSP_OK) return rc;
+	GDSP_REQUIRE ((pl->K.DQ >= 2) && (pl->K.NT <= HN_RT_MAX_NT) && (pl->K.OUT >= 512) && ((pl->K.LEAD & 1) == 0), "window outside the block-sum kernel's range");
+	const uint32_t ntiles = (uint32_t) (((uint64_t) n + pl->K.OUT - 1) / pl->K.OUT);
+#define HN_RT_LAUNCH(EE) hipLaunchKernelGGL ((hann_blocks_rt_kernel<EE>), dim3(ntiles), dim3(HN_THREADS), 0, s, d_in, d_out, n, ntiles, pl->K, pl->d_rot)
+	switch (pl->E)
+		{
+		case 8:  HN_RT_LAUNCH (8);   break;
+		case 9:  HN_RT_LAUNCH (9);   break;
+		case 12: HN_RT_LAUNCH (12);  break;
+		case 13: HN_RT_LAUNCH (13);  break;
+		case 16: HN_RT_LAUNCH (16);  break;
+		case 17: HN_RT_LAUNCH (17);  break;
+		case 20: HN_RT_LAUNCH (20);  break;
+		default: HN_RT_LAUNCH (21);  break;
+		}
+#undef HN_RT_LAUNCH
 	GDSP_LAUNCH_CHECK ();
 	return GDSP_OK;
 	}

@@ -38,7 +38,7 @@ extern "C" {
  * the reference, like FMA, and no further from the exact value than the reference is.
  * Unlike EXACT and FMA it is not shift invariant (a flat input gives outputs that differ in
  * their last bits), so gdsp_smooth_local_extrema evaluates HANN as FMA.
- * Windows without such a kernel (anything but W=101 in this build) are evaluated as FMA. */
+ * Odd windows of 81..2001 taps have such a kernel (W=101 a dedicated one); others are evaluated as FMA. */
 #define GDSP_FIR_HANN  2
 
 /* interval overlap operators, values as genodsp_interface.h:157-159 */
