@@ -453,7 +453,8 @@ int gdsp_percentiles (const gdsp_select_source* sources, int nsources, uint32_t 
 	GDSP_REQUIRE ((strategy >= GDSP_SELECT_AUTO) && (strategy <= GDSP_SELECT_BRACKET), "unknown strategy");
 	for (int i=0 ; i<npercentiles ; i++) GDSP_REQUIRE (pThousandths[i] <= 100000, "percentile above 100");
 	if (window == 0) window = 1;
-	if (sampleTarget == 0) sampleTarget = PC_SAMPLE_TARGET;
+	const bool defaultTarget = (sampleTarget == 0);
+	if (defaultTarget) sampleTarget = PC_SAMPLE_TARGET;
 	if (!(lo <= hi)) strategy = GDSP_SELECT_RADIX;                // only NaNs can pass such a filter: no brackets
 
 	std::lock_guard<std::mutex> hold (pcLock);
@@ -479,6 +480,9 @@ int gdsp_percentiles (const gdsp_select_source* sources, int nsources, uint32_t 
 	// ---- how: brackets need a population worth sampling and pivots that fit the counting kernel
 	const bool bracket = (strategy == GDSP_SELECT_BRACKET)
 	                  || ((strategy == GDSP_SELECT_AUTO) && (pop > (uint64_t) sampleTarget) && (2*npercentiles <= PC_MAX_PIVOTS));
+	// a gathered value costs a 64-byte sector: no more than one value in 64, which still brackets a rank within
+	// 8*sqrt(64/pop) of the population (a 249 Mbp chromosome: 3.9 M values sampled, ~0.2 % kept as candidates)
+	if (defaultTarget) sampleTarget = (uint32_t) std::min<uint64_t> (PC_SAMPLE_TARGET, std::max<uint64_t> (1u << 16, pop / 64));
 	const uint32_t sstride = (uint32_t) std::max<uint64_t> (1, (pop + sampleTarget - 1) / sampleTarget);
 
 	// scratch per device: the subsample and a candidate list sized for the expected bracket widths
