@@ -37,6 +37,10 @@
 // report see such ties; that is why EXACT stays the default of the command line, why the fused
 // smooth+extrema kernel evaluates directly whatever the mode, and why this mode is for the
 // smoothed track as a floating-point result.
+// Range: the block sums add up to 85 unweighted inputs, so inputs beyond DBL_MAX/128 overflow where the
+// weighted sum would not, and a window that holds an infinity yields NaN (inf - inf) where direct
+// evaluation yields the infinity; a NaN input gives NaN for exactly the windows that hold it, as in
+// the reference.
 
 #include <math.h>
 #include <string.h>
