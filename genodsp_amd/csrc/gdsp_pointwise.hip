@@ -147,6 +147,55 @@ void minmax_kernel (const double* __restrict__ v, uint32_t n, uint32_t window, d
 		}
 	}
 
+// window 1, 16-byte aligned: a workgroup walks 32 KiB tiles (grid stride) with the tile's eight
+// 16-byte loads per lane issued together; the grid-stride loop above reads one value per lane at a time
+__global__ __launch_bounds__(PW_THREADS)
+void minmax_dense_kernel (const double* __restrict__ v, uint32_t n, double lo, double hi, double* __restrict__ result)
+	{
+	double   mn = DBL_MAX, mx = -DBL_MAX;
+	uint32_t cnt = 0;
+	auto take = [&] (double x)
+		{
+		const bool in = !(x < lo) && !(x > hi);
+		if (in && (x < mn)) mn = x;
+		if (in && (x > mx)) mx = x;
+		cnt += in;
+		};
+	const uint32_t ntiles = (uint32_t) (((uint64_t) n + PW_TILE - 1) / PW_TILE);
+	for (uint32_t tile=blockIdx.x ; tile<ntiles ; tile+=gridDim.x)
+		{
+		const size_t base = (size_t) tile * PW_TILE;
+		if (base + PW_TILE <= (size_t) n)
+			{
+			const double2* p = reinterpret_cast<const double2*> (v + base) + threadIdx.x;
+			double2 d[PW_UNROLL];
+#pragma unroll
+			for (int u=0 ; u<PW_UNROLL ; u++) d[u] = p[u*PW_THREADS];
+#pragma unroll
+			for (int u=0 ; u<PW_UNROLL ; u++) { take (d[u].x);  take (d[u].y); }
+			}
+		else
+			{
+			for (size_t i = base + threadIdx.x ; i < (size_t) n ; i += PW_THREADS) take (v[i]);
+			}
+		}
+	for (int off=32 ; off>0 ; off>>=1)
+		{
+		double   omn = __shfl_down (mn, off, 64);
+		double   omx = __shfl_down (mx, off, 64);
+		uint32_t oc  = __shfl_down (cnt, off, 64);
+		if (omn < mn) mn = omn;
+		if (omx > mx) mx = omx;
+		cnt += oc;
+		}
+	if (((threadIdx.x & 63) == 0) && (cnt != 0))
+		{
+		atomic_min_f64 (&result[0], mn);
+		atomic_max_f64 (&result[1], mx);
+		atomicAdd (&result[2], (double) cnt);
+		}
+	}
+
 // ------------------------------------------------------------------- map ----
 // op_map_apply, map.c:194-381: piecewise-linear mapping through a table of (in, out) knots
 // sorted by `in`.  Values at or below the first knot / at or above the last take that knot's
@@ -289,6 +338,14 @@ int gdsp_minmax_update (const double* d_v, uint32_t n, uint32_t window, double l
 	if (n == 0) return GDSP_OK;
 	GDSP_REQUIRE ((d_v != NULL) && (d_minmax != NULL), "NULL pointer");
 	if (window == 0) window = 1;
+	if ((window == 1) && gdsp_aligned16 (d_v))
+		{
+		size_t   tiles  = ((size_t) n + PW_TILE - 1) / PW_TILE;
+		uint32_t blocks = (uint32_t) (tiles > PW_MAX_BLOCKS? PW_MAX_BLOCKS : tiles);
+		hipLaunchKernelGGL (minmax_dense_kernel, dim3(blocks), dim3(PW_THREADS), 0, gdsp_stream (stream), d_v, n, lo, hi, d_minmax);
+		GDSP_LAUNCH_CHECK ();
+		return GDSP_OK;
+		}
 	size_t   nsamp  = ((size_t) n + window - 1) / window;
 	size_t   want   = (nsamp + (size_t) PW_THREADS*4 - 1) / ((size_t) PW_THREADS*4);
 	uint32_t blocks = (uint32_t) (want < 1? 1 : (want > PW_MAX_BLOCKS? PW_MAX_BLOCKS : want));
