@@ -153,23 +153,25 @@ void pc_partition_kernel (const double* __restrict__ v, uint32_t n, uint32_t win
 			}
 		};
 
+	// counter += 1 in the lanes of a compare mask: one add-with-carry fed by the mask.  Written as an
+	// instruction because the compiler otherwise sinks these adds below the rare branches and keeps
+	// every mask alive until then (eight v_writelane / v_readlane per value)
+	auto bump = [] (uint32_t& counter, uint64_t mask)
+		{ asm volatile ("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(counter) : "s"(mask) : "vcc"); };
+
 	auto count = [&] (double x)
 		{
 		uint64_t keep = 0, above = ~0ULL, gthi = 0;
 		if (BOUNDED)
 			{
-			const bool a = (x >= lo), b = (x > hi);
-			cGeLo += a;  cGtHi += b;
-			above = __ballot (a);  gthi = __ballot (b);
+			above = __ballot (x >= lo);  gthi = __ballot (x > hi);
+			bump (cGeLo, above);  bump (cGtHi, gthi);
 			}
 #pragma unroll
 		for (int j=0 ; j<M ; j++)
 			{
-			const bool g = (x >  P.val[j]);
-			const bool e = (x == P.val[j]);
-			cGt[j] += g;
-			cEq[j] += e;
-			const uint64_t gt = __ballot (g), eq = __ballot (e);
+			const uint64_t gt = __ballot (x >  P.val[j]), eq = __ballot (x == P.val[j]);
+			bump (cGt[j], gt);  bump (cEq[j], eq);
 			keep |= above & ~gt & ~eq & take[j];
 			above = gt;
 			}
