@@ -284,6 +284,81 @@ cli_case("cli_clump", APPENDIX_C_CH, ["--novalue", "=", "clump", "1.5", "L=8"], 
 cli_case("cli_anticlump_show", APPENDIX_C_CH, ["--novalue", "--uncovered:show", "=", "anticlump", "0.5", "L=12", "--one=2"],
          APPENDIX_C_IV)
 
+# ---- random pipelines through the reference BINARY (whole driver: ingest -> operators -> report), stored as a
+#      digest of its stdout: sha256, line count, first and last lines.  Signal kept away from the chromosome ends
+#      and windows kept short of them, so that none of the reference's out-of-bounds reads (SURVEY Appendix B
+#      #1-2) is provoked; percentile only with --preserve, which leaves the signal usable afterwards.
+import hashlib  # noqa: E402
+
+
+def random_cli_case(k):
+    r = np.random.default_rng(SEED + 7000 + k)
+    lens = [int(r.integers(6000, 9000)), int(r.integers(4000, 6000))]
+    chroms_text = "".join("chr%s %d\n" % ("RQ"[i], n) for i, n in enumerate(lens))
+    lines = []
+    for i, n in enumerate(lens):
+        for _ in range(int(r.integers(30, 90))):
+            a = int(r.integers(1500, n - 1800))
+            b = a + int(r.integers(1, 260))
+            lines.append("chr%s\t%d\t%d\t%d" % ("RQ"[i], a, b, int(r.integers(1, 7))))
+    order = r.permutation(len(lines))
+    stdin = "\n".join(lines[j] for j in order) + "\n"
+    args = ["--precision=%d" % int(r.integers(0, 7))]
+    if r.random() < 0.3:
+        args.append("--novalue")
+    if r.random() < 0.3:
+        args.append("--uncovered:%s" % r.choice(["show", "NA"]))
+    if r.random() < 0.2:
+        args.append("--nocollapse")
+    if r.random() < 0.2:
+        args.append("--origin=one")
+    menu = [lambda: ["smooth", "W=%d" % int(r.choice([5, 11, 51, 101]))],
+            lambda: ["localmax", "N=%d" % int(r.choice([3, 11, 41]))],
+            lambda: ["localmin", "N=%d" % int(r.choice([5, 21])), "--infinity=50"],
+            lambda: ["bestmax", "W=%d" % int(r.choice([4, 30, 300]))],
+            lambda: ["bestmin", "W=%d" % int(r.choice([9, 100]))],
+            lambda: ["dilate", "%d" % int(r.integers(1, 300))],
+            lambda: ["erode", "%d" % int(r.integers(1, 120))],
+            lambda: ["close", "%d" % int(r.integers(2, 400)), "--threshold=%d" % int(r.integers(0, 3))],
+            lambda: ["open", "%d" % int(r.integers(2, 100))],
+            lambda: ["binarize", "%d" % int(r.integers(0, 5))],
+            lambda: ["clip", "--min=1", "--max=%d" % int(r.integers(3, 9))],
+            lambda: ["erase", "--max=%d" % int(r.integers(1, 4))],
+            lambda: ["addconst", "%g" % float(r.integers(-2, 3))],
+            lambda: ["abs"],
+            lambda: ["invert", "2.5"],
+            lambda: ["slidingsum", "W=%d" % int(r.choice([4, 50, 501]))],
+            lambda: ["sum", "W=%d" % int(r.choice([10, 100]))],
+            lambda: ["cumulativesum"],
+            lambda: ["clump", "%g" % (float(r.integers(1, 6)) + 0.5), "--length=%d" % int(r.choice([10, 150]))],
+            lambda: ["anticlump", "0.5", "--length=%d" % int(r.choice([20, 400]))],
+            lambda: ["percentile", "%d" % int(r.choice([50, 90, 99])), "--min=1/inf", "--quiet", "--preserve=@keep@"]]
+    pct = None
+    for _ in range(int(r.integers(1, 6))):
+        op = menu[int(r.integers(0, len(menu)))]()
+        if op[0] == "percentile":
+            pct = op[1]
+        args += ["="] + op
+        if pct is not None and op[0] != "percentile" and r.random() < 0.5:
+            args += ["=", "binarize", "--threshold=percentile%s" % pct]
+            pct = None
+    name = "cli_random_%02d" % k
+    files = {"keep": ""} if "--preserve=@keep@" in args else {}
+    chrom_path = "/tmp/golden_%s.chroms" % name
+    with open(chrom_path, "w") as f:
+        f.write(chroms_text)
+    real = [a.replace("@keep@", "/tmp/golden_%s_keep" % name) for a in args]
+    rc, out, err = ref.run_cli(["--chromosomes=" + chrom_path] + real, stdin)
+    body = out.splitlines()
+    cases.append({"name": name, "kind": "cli_digest", "chroms_text": chroms_text, "args": args, "files": files,
+                  "stdin": stdin, "returncode": rc, "sha256": hashlib.sha256(out.encode()).hexdigest(),
+                  "lines": len(body), "head": body[:5], "tail": body[-3:],
+                  "stderr_percentile": [l for l in err.splitlines() if l.startswith("percentile ")]})
+
+
+for k in range(48):
+    random_cli_case(k)
+
 np.savez_compressed(os.path.join(HERE, "golden.npz"), **arrays)
 with open(os.path.join(HERE, "golden.json"), "w") as f:
     json.dump({"seed": SEED, "cases": cases}, f, indent=1)

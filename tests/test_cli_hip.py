@@ -61,6 +61,25 @@ def test_cli_stdout_matches_reference(case, tmp_path):
             assert line in err.splitlines()
 
 
+DIGEST_CASES = [c for c in golden().meta["cases"] if c["kind"] == "cli_digest"]
+
+
+@pytest.mark.parametrize("case", DIGEST_CASES, ids=[c["name"] for c in DIGEST_CASES])
+def test_cli_random_pipelines_match_the_reference_binary(case, tmp_path):
+    """48 random command lines (global flags, one to five random operators, shuffled valued intervals over two
+    chromosomes) recorded from the reference binary as a digest of its stdout: the whole driver -- ingest,
+    operators, named variables, report -- must print the same bytes."""
+    import hashlib
+    assert case["returncode"] == 0
+    rc, out, err = run(case["args"], case["stdin"], case["chroms_text"], tmp_path, case.get("files"))
+    assert rc == 0, err
+    body = out.splitlines()
+    assert body[:5] == case["head"] and body[-3:] == case["tail"] and len(body) == case["lines"], (case["args"], body[:5], case["head"])
+    assert hashlib.sha256(out.encode()).hexdigest() == case["sha256"], case["args"]
+    for line in case["stderr_percentile"]:
+        assert line in err.splitlines()
+
+
 def test_named_variable_feeds_threshold(tmp_path):
     """percentile -> binarize --threshold=<variable> (README.md:111-118 in the reference); here the
     signal survives percentile, so no re-input is needed."""
