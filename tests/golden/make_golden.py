@@ -359,6 +359,73 @@ def random_cli_case(k):
 for k in range(48):
     random_cli_case(k)
 
+
+def random_file_case(k):
+    """as above, with interval-file operators: loose (overlapping, any order) files for the operators that take
+    them, sorted disjoint ones for the operators that walk the gaps between intervals"""
+    r = np.random.default_rng(SEED + 9000 + k)
+    lens = [int(r.integers(3000, 5000)), int(r.integers(1500, 2500)), 400]
+    names = ["chrF", "chrG", "chrH"]
+    chroms_text = "".join("%s %d\n" % (c, n) for c, n in zip(names, lens))
+
+    def loose(count):
+        out = []
+        for _ in range(count):
+            i = int(r.integers(0, 3))
+            a = int(r.integers(0, lens[i] - 120))
+            out.append("%s %d %d %s" % (names[i], a, a + int(r.integers(1, 120)), "%.2f" % (r.random() * 5 - 1)))
+        return "\n".join(out) + "\n"
+
+    def disjoint():
+        out = []
+        for i in range(3):
+            pos = int(r.integers(0, 60))
+            while pos < lens[i] - 150:
+                e = pos + int(r.integers(1, 140))
+                out.append("%s %d %d %s" % (names[i], pos, e, "%.2f" % (r.random() * 4 + 0.25)))
+                pos = e + int(r.integers(0, 160))
+        return "\n".join(out) + "\n"
+
+    files, args = {}, ["--precision=%d" % int(r.integers(0, 6))]
+    if r.random() < 0.4:
+        args.append("--uncovered:show")
+    for j in range(int(r.integers(1, 4))):
+        key = "f%d" % j
+        op = str(r.choice(["add", "subtract", "mask", "or", "minwith", "maxwith", "multiply", "divide", "masknot", "and",
+                           "minover", "maxover", "input", "smooth", "binarize", "dilate"]))
+        if op in ("smooth", "binarize", "dilate"):
+            args += ["=", op] + {"smooth": ["W=11"], "binarize": ["1"], "dilate": ["15"]}[op]
+            continue
+        files[key] = disjoint() if op in ("multiply", "divide", "masknot", "and", "minover", "maxover") else loose(int(r.integers(5, 60)))
+        extra = {"mask": ["--mask=%d" % int(r.integers(-2, 3))], "masknot": ["--mask=7"], "divide": ["--infinity=99"],
+                 "minover": ["--infinity=50"], "maxover": ["--zero=-1"],
+                 "input": ["--missing=%d" % int(r.integers(0, 3)), "--overlap=%s" % r.choice(["sum", "min", "max"])]}.get(op, [])
+        if op == "or" and r.random() < 0.5:
+            extra = ["--novalue"]
+        args += ["=", op, "@%s@" % key] + extra
+    name = "cli_random_files_%02d" % k
+    stdin = loose(int(r.integers(20, 120)))
+    chrom_path = "/tmp/golden_%s.chroms" % name
+    with open(chrom_path, "w") as f:
+        f.write(chroms_text)
+    real = []
+    for a in args:
+        for key, text in files.items():
+            path = "/tmp/golden_%s_%s" % (name, key)
+            with open(path, "w") as f:
+                f.write(text)
+            a = a.replace("@%s@" % key, path)
+        real.append(a)
+    rc, out, err = ref.run_cli(["--chromosomes=" + chrom_path] + real, stdin)
+    body = out.splitlines()
+    cases.append({"name": name, "kind": "cli_digest", "chroms_text": chroms_text, "args": args, "files": files,
+                  "stdin": stdin, "returncode": rc, "sha256": hashlib.sha256(out.encode()).hexdigest(),
+                  "lines": len(body), "head": body[:5], "tail": body[-3:], "stderr_percentile": []})
+
+
+for k in range(40):
+    random_file_case(k)
+
 np.savez_compressed(os.path.join(HERE, "golden.npz"), **arrays)
 with open(os.path.join(HERE, "golden.json"), "w") as f:
     json.dump({"seed": SEED, "cases": cases}, f, indent=1)
