@@ -240,7 +240,7 @@ def other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_base
     mode = gd.FIR_EXACT if args.mode == "exact" else gd.FIR_FMA
     extra = {}
     if args.workload == "peaks":          # configs[2]: smooth W=101 = localmax N=11
-        name, bytes_per_base = "smooth W=101 = localmax N=11", (32 if args.nofuse else 16)
+        name, bytes_per_base = "smooth W=101 = localmax N=11", 32
 
         def step(_):
             for i in mine:
@@ -250,7 +250,7 @@ def other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_base
                 else:
                     gd.smooth_local_extrema(vin[i], WINDOW, 11, True, 0.0, out=tmp[i], mode=mode, stream=S)
     elif args.workload == "morph":        # configs[3]: dilate 1001 = erode 1001 = binarize
-        name, bytes_per_base = "dilate 1001 = erode 1001 = binarize", (48 if args.nofuse else 16)
+        name, bytes_per_base = "dilate 1001 = erode 1001 = binarize", 48
         left, right = gd.split_length(1001)
 
         def step(_):
@@ -297,8 +297,11 @@ def other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_base
               "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                            "algorithmic_bytes_per_base": bytes_per_base,
-                           "note": "bytes the launched kernels must move: one read and one write of the signal per kernel "
-                                   "(a fused chain is one kernel), 8 B/base for the percentile pass"}}
+                           "hbm_bytes_per_base_moved": (16 if (args.workload in ("peaks", "morph") and not args.nofuse)
+                                                        else bytes_per_base),
+                           "note": "credited as SURVEY 8(d) credits it: 16 B per operator executed (8 B for the percentile "
+                                   "pass), whether or not the chain is fused; a fused chain moves 16 B/base in all, so its "
+                                   "achieved figure can exceed what HBM delivers"}}
     result.update(extra)
     if rank == 0:
         print(json.dumps(result))
