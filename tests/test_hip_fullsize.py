@@ -35,7 +35,7 @@ def real(gd):
     return gd.synth_coverage(SEED, CHROM, 0, N, 1)
 
 
-def windows(rng, length=6000, count=6):
+def windows(rng, length=6000, count=165):                 # >= 10^6 positions per check (SURVEY 8d "verification at scale")
     seams = [2304 * 54021 - 3000, 4096 * 30000 - 3000, 16384 * 7000 - 3000]     # tile boundaries of the kernels
     return [0, N - length] + seams + [int(s) for s in rng.integers(0, N - length, count)]
 
