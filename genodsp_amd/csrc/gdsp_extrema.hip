@@ -16,8 +16,8 @@
 // reference's pick depends on its scan history).
 //
 // HBM-bound (16 B/base).  A workgroup stages a tile plus its halo in LDS with
-// 16-byte loads.  Windows up to 16 bases are scanned directly from LDS (two
-// adjacent outputs per lane); windows of 17 .. 3584 bases use the block form
+// 16-byte loads.  Windows up to 4 bases are scanned directly from LDS (two
+// adjacent outputs per lane); windows of 5 .. 3584 bases use the block form
 // (extrema_blocks_kernel: tail of a block + whole blocks from one level of a
 // sparse table + head of a block, four comparisons per base for any window,
 // 5.5-6.0 TB/s measured from 33 to 2049 bases); longer ones the van Herk /
@@ -30,7 +30,7 @@
 
 #define EX_THREADS 256
 #define EX_TILE    4096              // outputs per workgroup
-#define EX_DIRECT_MAX_SPAN 16        // windows up to this many bases are scanned directly
+#define EX_DIRECT_MAX_SPAN 4         // windows up to this many bases are scanned directly
 #define EX_LDS_DOUBLES 18432         // 144 KiB of the 160 KiB LDS
 
 template <bool MAX> __device__ __forceinline__ bool ex_beats (double a, double b)
@@ -184,7 +184,7 @@ void extrema_kernel (const double* __restrict__ in, double* __restrict__ out, ui
 	}
 
 // ------------------------------------------------------------- block form ----
-// Windows of 17 .. EXB_MAX_SPAN bases.  The staged tile is cut into blocks of 16; a window [a,b] is
+// Windows of 5 .. EXB_MAX_SPAN bases.  The staged tile is cut into blocks of G = 16 (8, 4 for short windows); a window [a,b] is
 // the tail of a's block + the whole blocks between + the head of b's block, and an extreme does
 // not mind overlap, so the blocks between are two overlapping power-of-two ranges of block
 // extremes (one level of a sparse table, built by doubling over the 256 block extremes of the tile).
@@ -194,61 +194,63 @@ void extrema_kernel (const double* __restrict__ in, double* __restrict__ out, ui
 // against 16 B/base of HBM.  The LDS image has a pitch of 17 per block of 16, so the lane-strided
 // reads of both walks are conflict free (the same layout as gdsp_hann.hip).
 #define EXB_THREADS  256
-#define EXB_G        16
-#define EXB_PITCH    17
-#define EXB_ELEMS    (EXB_THREADS * EXB_G)
-#define EXB_MIN_SPAN 17
+#define EXB_MIN_SPAN 5
 #define EXB_MAX_SPAN 3584
 
-template <bool MAX, bool LOCAL>
+// G = elements per block (and per thread): 16 for windows of 17 bases and more, 8 for 9..16, 4 for 5..8 --
+// a window has to reach past its right end's block for the decomposition to apply
+template <bool MAX, bool LOCAL, int G>
 __global__ __launch_bounds__(EXB_THREADS)
 void extrema_blocks_kernel (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t ntiles,
                             int rgt, int dq, int dr, int level, int sh, double fill)
 	{
-	__shared__ __attribute__((aligned(16))) double lds[EXB_THREADS * EXB_PITCH];
+	constexpr int PITCH = G + 1;
+	constexpr int ELEMS = EXB_THREADS * G;
+	constexpr int LOG_G = (G == 16)? 4 : ((G == 8)? 3 : 2);
+	__shared__ __attribute__((aligned(16))) double lds[EXB_THREADS * PITCH];
 	__shared__ double blockExt[2][EXB_THREADS];
 	const double pad   = MAX? -INFINITY : INFINITY;           // never beats anything, like "outside the vector"
 	const int    haloL = dq + 1;                              // leading blocks that only feed
-	const int    outs  = (EXB_THREADS - haloL) * EXB_G - 2*sh; // outputs stored per tile (even)
+	const int    outs  = (EXB_THREADS - haloL) * G - 2*sh;    // outputs stored per tile (even)
 	const int    nt    = dq - 1;                              // whole blocks always between
-	const int    lead  = haloL * EXB_G - rgt + sh;            // staged elements before output 0 of the tile (even)
+	const int    lead  = haloL * G - rgt + sh;                // staged elements before output 0 of the tile (even)
 	const uint32_t tile = gdsp_xcd_tile (blockIdx.x, ntiles);
 	const int64_t  out0 = (int64_t) tile * outs;
 	const int64_t  e0   = out0 - lead;
 	const int      p    = threadIdx.x;
 
-	// ---- stage 4096 elements
-	if ((e0 >= 0) && (e0 + EXB_ELEMS <= (int64_t) n))
+	// ---- stage 256*G elements
+	if ((e0 >= 0) && (e0 + ELEMS <= (int64_t) n))
 		{
 		const double2* src = reinterpret_cast<const double2*> (in + e0);
-		double2 r[EXB_G/2];
+		double2 r[G/2];
 #pragma unroll
-		for (int u=0 ; u<EXB_G/2 ; u++) r[u] = src[u*EXB_THREADS + p];
+		for (int u=0 ; u<G/2 ; u++) r[u] = src[u*EXB_THREADS + p];
 #pragma unroll
-		for (int u=0 ; u<EXB_G/2 ; u++)
+		for (int u=0 ; u<G/2 ; u++)
 			{
 			const int e = 2 * (u*EXB_THREADS + p);
-			double* dst = lds + e + (e >> 4);
+			double* dst = lds + e + (e >> LOG_G);
 			dst[0] = r[u].x;  dst[1] = r[u].y;
 			}
 		}
 	else
 		{
-		for (int e=p ; e<EXB_ELEMS ; e+=EXB_THREADS)
+		for (int e=p ; e<ELEMS ; e+=EXB_THREADS)
 			{
 			const int64_t g = e0 + e;
-			lds[e + (e >> 4)] = ((g >= 0) && (g < (int64_t) n))? in[g] : pad;
+			lds[e + (e >> LOG_G)] = ((g >= 0) && (g < (int64_t) n))? in[g] : pad;
 			}
 		}
 	__syncthreads ();
 
 	// ---- prefix extremes of the own block; its extreme to the table
-	double P[EXB_G];
+	double P[G];
 		{
-		const double* xb = lds + p * EXB_PITCH;
+		const double* xb = lds + p * PITCH;
 		double run = pad;
 #pragma unroll
-		for (int u=0 ; u<EXB_G ; u++) { run = ex_pick<MAX> (run, xb[u]);  P[u] = run; }
+		for (int u=0 ; u<G ; u++) { run = ex_pick<MAX> (run, xb[u]);  P[u] = run; }
 		blockExt[0][p] = run;
 		}
 	__syncthreads ();
@@ -269,24 +271,23 @@ void extrema_blocks_kernel (const double* __restrict__ in, double* __restrict__ 
 		const double* ext = blockExt[level & 1];
 		double T = pad;                                           // whole blocks p-nt .. p-1
 		if (nt > 0) T = ex_pick<MAX> (ext[p - nt], ext[p - (1 << level)]);
-		const double* lb = lds + (p - dq) * EXB_PITCH;            // block of the left ends of s >= dr
-		const double* la = lb - EXB_PITCH + EXB_G;                // the block before it, indexed by u - dr < 0
-		const double* cx = lds;                                   // centres (LOCAL): element 16p + u - rgt
+		const double* lb = lds + (p - dq) * PITCH;                // block of the left ends of s >= dr
+		const double* la = lb - PITCH + G;                        // the block before it, indexed by u - dr < 0
 		double run = pad;
 #pragma unroll
-		for (int u=2*EXB_G-2 ; u>=0 ; u--)
+		for (int u=2*G-2 ; u>=0 ; u--)
 			{
-			if (u >= EXB_G + dr) continue;                          // (uniform) the walk starts at u = 15 + dr
+			if (u >= G + dr) continue;                              // (uniform) the walk starts at u = G-1 + dr
 			if (u == dr - 1) { T = ex_pick<MAX> (T, run);  run = pad; }   // that block is whole for the remaining windows
 			const int rel = u - dr;
 			run = ex_pick<MAX> (run, (rel >= 0)? lb[rel] : la[rel]);
-			if (u < EXB_G)
+			if (u < G)
 				{
 				double e = ex_pick<MAX> (ex_pick<MAX> (run, T), P[u]);
 				if (LOCAL)
 					{
-					const int    c = EXB_G * p + u - rgt;
-					const double v = cx[c + (c >> 4)];
+					const int    c = G * p + u - rgt;                   // the centre of this window
+					const double v = lds[c + (c >> LOG_G)];
 					e = ex_beats<MAX> (e, v)? fill : v;
 					}
 				P[u] = e;
@@ -295,12 +296,12 @@ void extrema_blocks_kernel (const double* __restrict__ in, double* __restrict__ 
 		}
 	__syncthreads ();                                              // every read of the staged inputs is done
 
-	// ---- results back through LDS: thread haloL + k holds outputs 16k - sh .. 16k + 15 - sh of the tile
+	// ---- results back through LDS: thread haloL + k holds outputs G*k - sh .. G*k + G-1 - sh of the tile
 	if (live)
 		{
-		double* mine = lds + (p - haloL) * EXB_PITCH;
+		double* mine = lds + (p - haloL) * PITCH;
 #pragma unroll
-		for (int u=0 ; u<EXB_G ; u++) mine[u] = P[u];
+		for (int u=0 ; u<G ; u++) mine[u] = P[u];
 		}
 	__syncthreads ();
 	if (out0 + outs <= (int64_t) n)
@@ -310,7 +311,7 @@ void extrema_blocks_kernel (const double* __restrict__ in, double* __restrict__ 
 			{
 			const int o = 2*q + sh;
 			const int o1 = o + 1;
-			dst[q] = make_double2 (lds[o + (o >> 4)], lds[o1 + (o1 >> 4)]);
+			dst[q] = make_double2 (lds[o + (o >> LOG_G)], lds[o1 + (o1 >> LOG_G)]);
 			}
 		}
 	else
@@ -318,24 +319,24 @@ void extrema_blocks_kernel (const double* __restrict__ in, double* __restrict__ 
 		for (int q=p ; q<outs ; q+=EXB_THREADS)
 			{
 			const int o = q + sh;
-			if (out0 + q < (int64_t) n) out[out0 + q] = lds[o + (o >> 4)];
+			if (out0 + q < (int64_t) n) out[out0 + q] = lds[o + (o >> LOG_G)];
 			}
 		}
 	}
 
-template <bool MAX, bool LOCAL>
+template <bool MAX, bool LOCAL, int G>
 static void extrema_blocks_launch (const double* d_in, double* d_out, uint32_t n, uint32_t lft, uint32_t rgt, double fill,
                                    hipStream_t s)
 	{
 	const int d  = (int) (lft + rgt);                             // left end = right end - d
-	const int dq = d / EXB_G, dr = d % EXB_G;
+	const int dq = d / G, dr = d % G;
 	const int nt = dq - 1;
 	int level = 0;
-	while ((2 << level) <= nt) level++;                           // largest power of two <= nt (nt >= 1 here)
-	const int sh   = ((dq + 1) * EXB_G - (int) rgt) & 1;          // keeps the first staged element even
-	const int outs = (EXB_THREADS - (dq + 1)) * EXB_G - 2*sh;
+	while ((2 << level) <= nt) level++;                           // largest power of two <= nt (0 when nt <= 1)
+	const int sh   = ((dq + 1) * G - (int) rgt) & 1;              // keeps the first staged element even
+	const int outs = (EXB_THREADS - (dq + 1)) * G - 2*sh;
 	const uint32_t ntiles = (uint32_t) (((uint64_t) n + outs - 1) / outs);
-	hipLaunchKernelGGL ((extrema_blocks_kernel<MAX, LOCAL>), dim3(ntiles), dim3(EXB_THREADS), 0, s,
+	hipLaunchKernelGGL ((extrema_blocks_kernel<MAX, LOCAL, G>), dim3(ntiles), dim3(EXB_THREADS), 0, s,
 	                    d_in, d_out, n, ntiles, (int) rgt, dq, dr, level, sh, fill);
 	}
 
@@ -354,7 +355,9 @@ static int extrema_launch (const double* d_in, double* d_out, uint32_t n, uint32
 	const uint64_t span   = (uint64_t) lft + rgt + 1;
 	if ((span >= EXB_MIN_SPAN) && (span <= EXB_MAX_SPAN))
 		{
-		extrema_blocks_launch<MAX, LOCAL> (d_in, d_out, n, lft, rgt, fill, gdsp_stream (stream));
+		if      (span >= 17) extrema_blocks_launch<MAX, LOCAL, 16> (d_in, d_out, n, lft, rgt, fill, gdsp_stream (stream));
+		else if (span >= 9)  extrema_blocks_launch<MAX, LOCAL, 8>  (d_in, d_out, n, lft, rgt, fill, gdsp_stream (stream));
+		else                 extrema_blocks_launch<MAX, LOCAL, 4>  (d_in, d_out, n, lft, rgt, fill, gdsp_stream (stream));
 		GDSP_LAUNCH_CHECK ();
 		return GDSP_OK;
 		}

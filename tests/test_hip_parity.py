@@ -354,13 +354,14 @@ def test_cumulative_sum(n, gd):
     assert np.abs(got - want).max() <= 2 * n * EPS * np.abs(want).max()
 
 
-@pytest.mark.parametrize("W", [17, 18, 32, 33, 48, 49, 50, 64, 65, 255, 256, 257, 2048, 2049, 3583, 3584, 3585])
+@pytest.mark.parametrize("W", [4, 5, 6, 7, 8, 9, 10, 11, 12, 15, 16, 17, 18, 32, 33, 48, 49, 50, 64, 65, 255, 256, 257, 2048, 2049, 3583, 3584, 3585])
 def test_best_and_local_extrema_block_form_seams(W, gd):
-    """Windows of 17..3584 bases run in the block form (extrema_blocks_kernel); its tile holds
-    (256 - (W-1)//16 - 1) * 16 outputs (2 fewer when the alignment shift is needed), so the vector lengths
+    """Windows of 5..3584 bases run in the block form (extrema_blocks_kernel, blocks of 4, 8 or 16); its tile
+    holds (256 - (W-1)//G - 1) * G outputs (2 fewer when the alignment shift is needed), so the vector lengths
     here put its seams, the vector ends and a ragged last tile under the comparison."""
     d = W - 1
-    outs = (256 - (d // 16 + 1)) * 16 if W <= 3584 else 4096
+    G = 16 if W >= 17 else (8 if W >= 9 else 4)
+    outs = (256 - (d // G + 1)) * G if 5 <= W <= 3584 else 4096
     rng = np.random.default_rng(W)
     for n in sorted({1, W - 1, W, outs - 2, outs - 1, outs, outs + 1, 2 * outs - 3, 3 * outs + 7, 50021}):
         if n < 1:
