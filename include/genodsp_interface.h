@@ -40,16 +40,47 @@ typedef uint64_t u64;
 #define false 0
 #endif
 
-/* ---- values along the chromosomes (reference :20-26) ---- */
-typedef double valtype;
-#define string_to_valtype(s)       ((valtype) string_to_double(s))
-#define try_string_to_valtype(s,v) try_string_to_double(s,(valtype*)v)
-#define valtypeFmt     "%f"
-#define valtypeFmtPrec "%.*f"
-#define valtypeMax     DBL_MAX
-#define valtypePuny    DBL_MIN
+/* ---- host services an operator may call: same names and argument meaning as the reference's
+ *      (:167-190).  Declared first because they only need the scalar types. ---- */
+typedef double valtype;                            /* what a chromosome holds per base (:20) */
+struct spec;
+struct dspop;
 
-/* ---- chromosomes of interest (reference :37-57) ---- */
+void chastise (const char* format, ...);           /* message, the operator's usage text, exit */
+void tracking_report (const char* format, ...);    /* --progress=operations                    */
+struct spec* find_chromosome_spec (char* chrom);
+
+valtype* get_scratch_vector (void);                /* DEVICE scratch, longest-chromosome sized */
+void release_scratch_vector (valtype* v);
+
+int named_global_exists (char* name, valtype* val);           /* the percentile -> threshold channel */
+valtype get_named_global (char* name, valtype defaultVal);
+void set_named_global (char* name, valtype val);
+void report_named_globals (FILE* f, char* indent);
+
+int read_interval (FILE* f, char* buffer, int bufferLen, int valCol, char** chrom, uint32_t* start, uint32_t* end, valtype* val);
+void read_intervals (FILE* f, int valCol, int originOne, int overlapOp, int clear, valtype missingVal);
+void report_intervals (FILE* f, int precision, int noOutputValues, int collapseRuns, int showUncovered, int originOne);
+
+/* what read_intervals does where intervals overlap, and how report_intervals writes zero stretches */
+enum { ri_overlapSum = 0, ri_overlapMin = 1, ri_overlapMax = 2 };
+enum { uncovered_hide = 0, uncovered_show = 1, uncovered_NA = -1 };
+
+extern int trackOperations, reportComments;
+extern u32 reportInputProgress;
+
+/* ---- values (:20-26): text <-> valtype goes through utilities.h's double conversions ---- */
+#define valtypeMax  DBL_MAX
+#define valtypePuny DBL_MIN
+#define valtypeFmt "%f"
+#define valtypeFmtPrec "%.*f"
+#define string_to_valtype(text) ((valtype) string_to_double (text))
+#define try_string_to_valtype(text,out) try_string_to_double (text, (valtype*) (out))
+#ifndef M_PI
+#define M_PI 3.14159265358979323846264
+#endif
+
+/* ---- chromosomes of interest (:37-57).  Field order and types are the reference's. ---- */
 typedef struct spec
 	{
 	struct spec* next;        /* list in chromosome-file order (= output order)     */
@@ -63,29 +94,21 @@ typedef struct spec
 extern spec*  chromsOfInterest;   /* file order                                       */
 extern spec** chromsSorted;       /* longest first, NULL terminated (processing order) */
 
-/* ---- operator function groups (reference :76-125) ---- */
-struct dspop;
-#define opfuncargs_short (char*,int,FILE*,char*)
-#define opfuncargs_usage (char*,FILE*,char*)
-#define opfuncargs_parse (char*,int,char**)
-#define opfuncargs_free  (struct dspop*)
-#define opfuncargs_apply (struct dspop*,char*,u32,valtype*)
+/* ---- operator function groups (:76-125): five functions per operator X --
+ *      X_short, X_usage, X_parse, X_free, X_apply -- declared by dspprototypes(X) and
+ *      entered into the operator table by dspinforecord("name", X) ---- */
+typedef void (*opfunc_short) (char* name, int nameWidth, FILE* f, char* indent);
+typedef void (*opfunc_usage) (char* name, FILE* f, char* indent);
+typedef struct dspop* (*opfunc_parse) (char* name, int argc, char** argv);
+typedef void (*opfunc_free) (struct dspop* op);
+typedef void (*opfunc_apply) (struct dspop* op, char* vName, u32 vLen, valtype* v);
 
-typedef void          (*opfunc_short) opfuncargs_short;
-typedef void          (*opfunc_usage) opfuncargs_usage;
-typedef struct dspop* (*opfunc_parse) opfuncargs_parse;
-typedef void          (*opfunc_free)  opfuncargs_free;
-typedef void          (*opfunc_apply) opfuncargs_apply;
+#define dspprototypes(X)                                                       \
+	void X##_short (char*, int, FILE*, char*);  void X##_usage (char*, FILE*, char*);  \
+	struct dspop* X##_parse (char*, int, char**);  void X##_free (struct dspop*);       \
+	void X##_apply (struct dspop*, char*, u32, valtype*);
 
-#define dspprototypes(funcName) \
-void          funcName##_short opfuncargs_short; \
-void          funcName##_usage opfuncargs_usage; \
-struct dspop* funcName##_parse opfuncargs_parse; \
-void          funcName##_free  opfuncargs_free;  \
-void          funcName##_apply opfuncargs_apply;
-
-/* every operator's private record starts with this */
-typedef struct dspop
+typedef struct dspop              /* every operator's private record starts with this */
 	{
 	struct dspop* next;
 	char*         name;
@@ -95,7 +118,7 @@ typedef struct dspop
 	                             walks chromsSorted itself                            */
 	} dspop;
 
-typedef struct dspinfo
+typedef struct dspinfo            /* a row of the operator table; an alias row has only its name */
 	{
 	char*        name;
 	opfunc_short funcShort;
@@ -105,44 +128,8 @@ typedef struct dspinfo
 	opfunc_apply funcApply;
 	} dspinfo;
 
-#define dspinforecord(name,funcName) \
-	{ name, funcName##_short, funcName##_usage, funcName##_parse, funcName##_free, funcName##_apply }
-#define dspinfoalias(name) \
-	{ name, NULL, NULL, NULL, NULL, NULL }
-
-/* ---- miscellany (reference :133-159) ---- */
-#ifndef M_PI
-#define M_PI 3.14159265358979323846264
-#endif
-
-extern int trackOperations;
-extern int reportComments;
-extern u32 reportInputProgress;
-
-#define uncovered_NA   -1
-#define uncovered_show 1
-#define uncovered_hide 0
-
-#define ri_overlapSum 0
-#define ri_overlapMin 1
-#define ri_overlapMax 2
-
-/* ---- host services (reference :167-190), same names and argument meaning ---- */
-void     chastise               (const char* format, ...);
-spec*    find_chromosome_spec   (char* chrom);
-void     read_intervals         (FILE* f, int valCol, int originOne,
-                                 int overlapOp, int clear, valtype missingVal);
-int      read_interval          (FILE* f, char* buffer, int bufferLen, int valCol,
-                                 char** chrom, u32* start, u32* end, valtype* val);
-void     report_intervals       (FILE* f, int precision, int noOutputValues, int collapseRuns,
-                                 int showUncovered, int originOne);
-valtype* get_scratch_vector     (void);          /* DEVICE scratch, longest-chromosome sized */
-void     release_scratch_vector (valtype* v);
-void     set_named_global       (char* name, valtype val);
-valtype  get_named_global       (char* name, valtype defaultVal);
-int      named_global_exists    (char* name, valtype* val);
-void     report_named_globals   (FILE* f, char* indent);
-void     tracking_report        (const char* format, ...);
+#define dspinforecord(name,X) { name, X##_short, X##_usage, X##_parse, X##_free, X##_apply }
+#define dspinfoalias(name)    { name, 0, 0, 0, 0, 0 }
 
 /* ---- device-side additions (no counterpart in the reference) ---- */
 void*    op_stream              (void);          /* hipStream_t of the chromosome being processed  */
