@@ -104,11 +104,39 @@ void window_sum_tile_kernel (double* __restrict__ v, uint32_t n, uint32_t W, uin
 	const uint64_t base  = (uint64_t) tile * K * W;
 	const uint32_t span  = (uint32_t) ((base + (uint64_t) K*W <= n)? K*W : n - base);   // bases in this tile
 
-	// stage: thread handles bases p, p+256, ...; (row, col) advance without divisions.  Four
-	// loads are issued (index clamped, never predicated) before the four LDS stores.
+	// a full tile that starts on a 16-byte boundary moves as 16-byte words, eight loads per lane in flight:
+	// thread handles the pairs of bases (2t, 2t+1), +512, ...; (row, col) advance without divisions
+	const bool wide = (span == K*W) && ((span & 1) == 0) && ((base & 1) == 0) && (W >= 2);
+	if (wide)
+		{
+		uint32_t row = (2*threadIdx.x) / W, col = (2*threadIdx.x) % W;
+		const uint32_t dRow = (2*SU_THREADS) / W, dCol = (2*SU_THREADS) % W;
+		const double2* src = reinterpret_cast<const double2*> (v + base);
+		const uint32_t np  = span / 2;
+		for (uint32_t q0=threadIdx.x ; q0<np ; q0+=8*SU_THREADS)
+			{
+			double2 x[8];
+#pragma unroll
+			for (int u=0 ; u<8 ; u++)
+				{ const uint32_t q = q0 + u*SU_THREADS;  x[u] = src[(q < np)? q : np-1]; }
+#pragma unroll
+			for (int u=0 ; u<8 ; u++)
+				{
+				const uint32_t q = q0 + u*SU_THREADS;
+				if (q < np)
+					{
+					suLds[(size_t) row * pitch + col] = x[u].x;
+					if (col + 1 < W) suLds[(size_t) row * pitch + col + 1] = x[u].y;
+					else             suLds[(size_t) (row + 1) * pitch]     = x[u].y;
+					}
+				row += dRow;  col += dCol;
+				if (col >= W) { col -= W;  row++; }
+				}
+			}
+		}
 	uint32_t row = threadIdx.x / W, col = threadIdx.x % W;
 	const uint32_t dRow = SU_THREADS / W, dCol = SU_THREADS % W;
-	for (uint32_t p0=threadIdx.x ; p0<span ; p0+=4*SU_THREADS)
+	for (uint32_t p0=threadIdx.x ; !wide && (p0<span) ; p0+=4*SU_THREADS)
 		{
 		double x[4];
 #pragma unroll
@@ -131,12 +159,34 @@ void window_sum_tile_kernel (double* __restrict__ v, uint32_t n, uint32_t W, uin
 		if (s >= span) break;
 		const uint32_t len = (uint32_t) ((s + W <= span)? W : span - s);
 		const double*  x   = suLds + (size_t) w * pitch;
+		// (eight LDS reads in flight, the adds still one after the other in the reference's order)
 		double acc = x[0];
-		for (uint32_t k=1 ; k<len ; k++) acc += x[k];
+		uint32_t k = 1;
+		for ( ; k+8<=len ; k+=8)
+			{
+			const double a0 = x[k], a1 = x[k+1], a2 = x[k+2], a3 = x[k+3], a4 = x[k+4], a5 = x[k+5], a6 = x[k+6], a7 = x[k+7];
+			acc += a0;  acc += a1;  acc += a2;  acc += a3;  acc += a4;  acc += a5;  acc += a6;  acc += a7;
+			}
+		for ( ; k<len ; k++) acc += x[k];
 		res[w] = useActual? acc / (double) len : acc / denom;
 		}
 	__syncthreads ();
 
+	if (wide)
+		{
+		uint32_t r2 = (2*threadIdx.x) / W, c2 = (2*threadIdx.x) % W;
+		const uint32_t dR2 = (2*SU_THREADS) / W, dC2 = (2*SU_THREADS) % W;
+		double2* dst = reinterpret_cast<double2*> (v + base);
+		for (uint32_t q=threadIdx.x ; q<span/2 ; q+=SU_THREADS)
+			{
+			const double a = (c2 == 0)? res[r2] : zeroVal;
+			const double b = (c2 + 1 == W)? res[r2 + 1] : zeroVal;   // (the next window starts on the odd base)
+			dst[q] = make_double2 (a, b);
+			r2 += dR2;  c2 += dC2;
+			if (c2 >= W) { c2 -= W;  r2++; }
+			}
+		return;
+		}
 	row = threadIdx.x / W;  col = threadIdx.x % W;
 	for (uint32_t p=threadIdx.x ; p<span ; p+=SU_THREADS)
 		{
@@ -314,7 +364,8 @@ int gdsp_window_sum (double* d_v, uint32_t n, uint32_t W, double denom, int useA
 	const uint32_t nwin = (uint32_t) (((uint64_t) n + W - 1) / W);
 	if (W <= WS_TILE_MAX_W)
 		{
-		const uint32_t K      = WS_TILE_BASES / W;                         // >= 4 whole windows per tile
+		uint32_t       K      = WS_TILE_BASES / W;                         // >= 4 whole windows per tile
+		if ((K * W) & 1) K--;                                              // tiles start on 16-byte boundaries
 		const uint32_t ntiles = (uint32_t) (((uint64_t) n + (uint64_t) K*W - 1) / ((uint64_t) K*W));
 		const size_t   bytes  = ((size_t) K * (W | 1) + K + 2) * sizeof(double);
 		if (bytes > 64*1024)

@@ -65,6 +65,8 @@ timeit("clip", lambda: gd.clip(a, 1.0, 20.0, stream=S), prep=lambda: copy_into(a
 timeit("addconst", lambda: gd.add_constant(a, 1.5, stream=S), prep=lambda: copy_into(a, src))
 timeit("slidingsum W=101", lambda: gd.sliding_sum(src, 101, out=b, stream=S))
 timeit("sum W=100", lambda: gd.window_sum(a, 100, stream=S), prep=lambda: copy_into(a, src))
+timeit("sum W=101", lambda: gd.window_sum(a, 101, stream=S), prep=lambda: copy_into(a, src))
+timeit("sum W=1000", lambda: gd.window_sum(a, 1000, stream=S), prep=lambda: copy_into(a, src))
 work = gd.DeviceBuffer(gd.lib().gdsp_cumulative_sum_work(n))
 timeit("cumulativesum", lambda: gd.call("gdsp_cumulative_sum", a.ptr, n, gd.C.c_void_p(work.ptr), gd._sp(S)),
        prep=lambda: copy_into(a, src))
