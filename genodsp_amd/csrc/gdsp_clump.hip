@@ -42,17 +42,28 @@ __device__ __forceinline__ double sc_block_reduce (double x, double* part)
 	return sc_op<OP> (sc_op<OP> (part[0], part[1]), sc_op<OP> (part[2], part[3]));
 	}
 
+// Both passes read and write lane-consecutive elements (a chunk of a reversed scan simply runs down in
+// memory), sixteen accesses per lane in flight; the apply pass turns the chunk in LDS (pitch 17 per 16) so
+// that a thread scans sixteen consecutive elements.
 template <int OP, bool REVERSE>
 __global__ __launch_bounds__(SC_THREADS)
 void scan_totals_kernel (const double* __restrict__ v, size_t n, double* __restrict__ totals)
 	{
 	__shared__ double part[SC_THREADS/64];
 	const size_t k0 = (size_t) blockIdx.x * SC_CHUNK;
-	double acc = sc_identity<OP> ();
+	double x[SC_PER];
+#pragma unroll
 	for (int i=0 ; i<SC_PER ; i++)
 		{
 		const size_t k = k0 + (size_t) i * SC_THREADS + threadIdx.x;
-		if (k < n) acc = sc_op<OP> (acc, v[sc_at<REVERSE> (k, n)]);
+		x[i] = v[sc_at<REVERSE> ((k < n)? k : n-1, n)];
+		}
+	double acc = sc_identity<OP> ();
+#pragma unroll
+	for (int i=0 ; i<SC_PER ; i++)
+		{
+		const size_t k = k0 + (size_t) i * SC_THREADS + threadIdx.x;
+		if (k < n) acc = sc_op<OP> (acc, x[i]);
 		}
 	acc = sc_block_reduce<OP> (acc, part);
 	if (threadIdx.x == 0) totals[blockIdx.x] = acc;
@@ -84,19 +95,30 @@ template <int OP, bool REVERSE>
 __global__ __launch_bounds__(SC_THREADS)
 void scan_apply_kernel (double* __restrict__ v, size_t n, const double* __restrict__ offsets)
 	{
+	__shared__ double turn[SC_THREADS * (SC_PER + 1)];
 	__shared__ double waveTot[SC_THREADS/64];
-	const size_t k0   = (size_t) blockIdx.x * SC_CHUNK + (size_t) threadIdx.x * SC_PER;
+	const size_t k0   = (size_t) blockIdx.x * SC_CHUNK;
 	const int    lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	double x[SC_PER];
-	double run = sc_identity<OP> ();
 #pragma unroll
 	for (int i=0 ; i<SC_PER ; i++)
 		{
-		const size_t k = k0 + i;
-		x[i] = (k < n)? v[sc_at<REVERSE> (k, n)] : sc_identity<OP> ();
-		run  = sc_op<OP> (run, x[i]);
-		x[i] = run;
+		const size_t k = k0 + (size_t) i * SC_THREADS + threadIdx.x;
+		x[i] = v[sc_at<REVERSE> ((k < n)? k : n-1, n)];
 		}
+#pragma unroll
+	for (int i=0 ; i<SC_PER ; i++)
+		{
+		const int    kk = i * SC_THREADS + (int) threadIdx.x;         // place in the chunk, scan order
+		const size_t k  = k0 + kk;
+		turn[kk + (kk >> 4)] = (k < n)? x[i] : sc_identity<OP> ();
+		}
+	__syncthreads ();
+
+	double* mine = turn + threadIdx.x * (SC_PER + 1);
+	double  run  = sc_identity<OP> ();
+#pragma unroll
+	for (int i=0 ; i<SC_PER ; i++) { run = sc_op<OP> (run, mine[i]);  x[i] = run; }
 	double incl = run;
 	for (int d=1 ; d<64 ; d*=2)
 		{
@@ -111,10 +133,14 @@ void scan_apply_kernel (double* __restrict__ v, size_t n, const double* __restri
 	for (int w=0 ; w<wave ; w++) before = sc_op<OP> (before, waveTot[w]);
 	before = sc_op<OP> (before, excl);
 #pragma unroll
+	for (int i=0 ; i<SC_PER ; i++) mine[i] = sc_op<OP> (before, x[i]);
+	__syncthreads ();
+#pragma unroll
 	for (int i=0 ; i<SC_PER ; i++)
 		{
-		const size_t k = k0 + i;
-		if (k < n) v[sc_at<REVERSE> (k, n)] = sc_op<OP> (before, x[i]);
+		const int    kk = i * SC_THREADS + (int) threadIdx.x;
+		const size_t k  = k0 + kk;
+		if (k < n) v[sc_at<REVERSE> (k, n)] = turn[kk + (kk >> 4)];
 		}
 	}
 
