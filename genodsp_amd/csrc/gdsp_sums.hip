@@ -85,6 +85,126 @@ void sliding_sum_kernel (const double* __restrict__ in, double* __restrict__ out
 		}
 	}
 
+// ---------------------------------------------------- sliding sum, block form ----
+// Windows of 17 .. SLB_MAX_W bases.  The staged tile is cut into blocks of 16: a window [a,b] is the tail
+// of a's block + the whole blocks between + the head of b's block.  One thread owns a block as the right
+// end b of 16 windows: prefix sums of its own block in registers, block totals through LDS, then one
+// backward walk over the 16+dr elements that hold the 16 left ends, finishing one output per step.  The
+// blocks between are added one by one (up to 8 of them) or taken as the difference of two entries of a
+// running sum over the tile's 256 block totals.  Same LDS image (pitch 17) as the extrema block form;
+// about a third of the LDS traffic of the in-place prefix form above.
+#define SLB_THREADS 256
+#define SLB_G       16
+#define SLB_PITCH   17
+#define SLB_ELEMS   (SLB_THREADS * SLB_G)
+#define SLB_MIN_W   17
+#define SLB_MAX_W   2048
+
+__global__ __launch_bounds__(SLB_THREADS)
+void sliding_blocks_kernel (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t ntiles,
+                            int rgt, int dq, int dr, int sh, double denom)
+	{
+	__shared__ __attribute__((aligned(16))) double lds[SLB_THREADS * SLB_PITCH];
+	__shared__ double blockTot[SLB_THREADS + 1];              // [k+1] = total of blocks 0..k once scanned
+	__shared__ double waveTot[SLB_THREADS/64];
+	const int    haloL = dq + 1;
+	const int    outs  = (SLB_THREADS - haloL) * SLB_G - 2*sh;
+	const int    nt    = dq - 1;                              // whole blocks always between
+	const int    lead  = haloL * SLB_G - rgt + sh;
+	const uint32_t tile = gdsp_xcd_tile (blockIdx.x, ntiles);
+	const int64_t  out0 = (int64_t) tile * outs;
+	const int64_t  e0   = out0 - lead;
+	const int      p    = threadIdx.x, lane = p & 63, wave = p >> 6;
+
+	if ((e0 >= 0) && (e0 + SLB_ELEMS <= (int64_t) n))
+		{
+		const double2* src = reinterpret_cast<const double2*> (in + e0);
+		double2 r[SLB_G/2];
+#pragma unroll
+		for (int u=0 ; u<SLB_G/2 ; u++) r[u] = src[u*SLB_THREADS + p];
+#pragma unroll
+		for (int u=0 ; u<SLB_G/2 ; u++)
+			{
+			const int e = 2 * (u*SLB_THREADS + p);
+			double* dst = lds + e + (e >> 4);
+			dst[0] = r[u].x;  dst[1] = r[u].y;
+			}
+		}
+	else
+		{
+		for (int e=p ; e<SLB_ELEMS ; e+=SLB_THREADS)
+			{
+			const int64_t g = e0 + e;
+			lds[e + (e >> 4)] = ((g >= 0) && (g < (int64_t) n))? in[g] : 0.0;
+			}
+		}
+	__syncthreads ();
+
+	double P[SLB_G];
+	double run = 0.0;
+		{
+		const double* xb = lds + p * SLB_PITCH;
+#pragma unroll
+		for (int u=0 ; u<SLB_G ; u++) { run += xb[u];  P[u] = run; }
+		}
+	// running sum over the block totals (only consulted when more than 8 blocks lie between)
+	double incl = run;
+	for (int d=1 ; d<64 ; d*=2) { const double up = __shfl_up (incl, d, 64);  if (lane >= d) incl += up; }
+	if (lane == 63) waveTot[wave] = incl;
+	if (p == 0) blockTot[0] = 0.0;
+	__syncthreads ();
+		{
+		double before = 0.0;
+		for (int w=0 ; w<wave ; w++) before += waveTot[w];
+		blockTot[p + 1] = (nt > 8)? before + incl : run;        // short stretches: the plain totals, added one by one
+		}
+	__syncthreads ();
+
+	if (p >= haloL)
+		{
+		double T = 0.0;                                           // whole blocks p-nt .. p-1
+		if (nt > 8) T = blockTot[p] - blockTot[p - nt];
+		else        { for (int d=nt ; d>=1 ; d--) T += blockTot[p - d + 1]; }
+		const double* lb = lds + (p - dq) * SLB_PITCH;
+		const double* la = lb - SLB_PITCH + SLB_G;
+		double s = 0.0;
+#pragma unroll
+		for (int u=2*SLB_G-2 ; u>=0 ; u--)
+			{
+			if (u >= SLB_G + dr) continue;
+			if (u == dr - 1) { T += s;  s = 0.0; }
+			const int rel = u - dr;
+			s += (rel >= 0)? lb[rel] : la[rel];
+			if (u < SLB_G) P[u] = ((s + T) + P[u]) / denom;
+			}
+		}
+	__syncthreads ();
+	if (p >= haloL)
+		{
+		double* mine = lds + (p - haloL) * SLB_PITCH;
+#pragma unroll
+		for (int u=0 ; u<SLB_G ; u++) mine[u] = P[u];
+		}
+	__syncthreads ();
+	if (out0 + outs <= (int64_t) n)
+		{
+		double2* dst = reinterpret_cast<double2*> (out + out0);
+		for (int q=p ; q<outs/2 ; q+=SLB_THREADS)
+			{
+			const int o = 2*q + sh, o1 = o + 1;
+			dst[q] = make_double2 (lds[o + (o >> 4)], lds[o1 + (o1 >> 4)]);
+			}
+		}
+	else
+		{
+		for (int q=p ; q<outs ; q+=SLB_THREADS)
+			{
+			const int o = q + sh;
+			if (out0 + q < (int64_t) n) out[out0 + q] = lds[o + (o >> 4)];
+			}
+		}
+	}
+
 // -------------------------------------------------------------- window sum ----
 #define WS_TILE_MAX_W 2048               // windows up to this long go through the tiled kernel
 #define WS_TILE_BASES 8192               // bases staged per workgroup (whole windows only)
@@ -333,6 +453,17 @@ int gdsp_sliding_sum (const double* d_in, double* d_out, uint32_t n, uint32_t W,
 
 	// a window longer than the vector plus its own reach sees everything anyway
 	uint64_t Weff = W, hOff = (W - 1) / 2, lft = W - 1 - hOff;
+	if ((W >= SLB_MIN_W) && (W <= SLB_MAX_W))
+		{
+		const int d  = (int) W - 1, dq = d / SLB_G, dr = d % SLB_G;
+		const int sh = ((dq + 1) * SLB_G - (int) hOff) & 1;
+		const int outs = (SLB_THREADS - (dq + 1)) * SLB_G - 2*sh;
+		const uint32_t ntiles = (uint32_t) (((uint64_t) n + outs - 1) / outs);
+		hipLaunchKernelGGL (sliding_blocks_kernel, dim3(ntiles), dim3(SLB_THREADS), 0, gdsp_stream (stream),
+		                    d_in, d_out, n, ntiles, (int) hOff, dq, dr, sh, denom);
+		GDSP_LAUNCH_CHECK ();
+		return GDSP_OK;
+		}
 	const int tile = 4096;
 	const size_t maxDoubles = 18432;                       // 144 KiB of LDS
 	if (Weff + tile + 4 > maxDoubles)

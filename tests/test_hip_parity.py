@@ -325,6 +325,20 @@ def test_sliding_sum(n, W, gd):
     assert np.abs(got - want).max() <= bound
 
 
+@pytest.mark.parametrize("W", [16, 17, 18, 33, 100, 101, 144, 145, 160, 161, 1000, 2047, 2048, 2049])
+def test_sliding_sum_block_form_seams(W, gd):
+    """Windows of 17..2048 bases run in the block form (sliding_blocks_kernel): (256 - (W-1)//16 - 1) * 16
+    outputs per tile, 2 fewer when the alignment shift is needed; up to 8 whole blocks are added one by one,
+    more come from a running sum over the tile's block totals (W >= 161)."""
+    rng = np.random.default_rng(W)
+    outs = (256 - ((W - 1) // 16 + 1)) * 16 if 17 <= W <= 2048 else 4096
+    for n in sorted({1, W - 1, W, W + 1, outs - 2, outs - 1, outs, outs + 1, 2 * outs - 3, 3 * outs + 5, 40009}):
+        x = _signal("depth", n, rng)
+        got = gd.sliding_sum(gd.DeviceVector.from_numpy(x), W, denom=3.0).numpy()
+        want = cpu.sliding_sum(x, W, 3.0)
+        assert bits_equal(got, want), (n, first_diff(got, want))
+
+
 @pytest.mark.parametrize("n", [1, 5, 100, 2350, 100003])
 @pytest.mark.parametrize("W", [3, 7, 64, 100, 8192, 8193, 50000])
 def test_window_sum(n, W, gd):
