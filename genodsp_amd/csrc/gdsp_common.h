@@ -34,6 +34,11 @@ void gdsp_set_error (const char* fmt, ...);
 bool gdsp_hann_blocks_available (uint32_t W);
 int  gdsp_hann_blocks_apply (const double* d_in, double* d_out, uint32_t n, uint32_t W, void* stream);
 
+// gdsp_extrema.hip: dilate / erode as window-any / window-all in the block form
+bool gdsp_morph_blocks_available (uint32_t left, uint32_t right);
+void gdsp_morph_blocks (const double* d_in, double* d_out, uint32_t n, uint32_t left, uint32_t right, int erode,
+                        double T, double one, double zero, void* stream);
+
 static inline hipStream_t gdsp_stream (void* s) { return (hipStream_t) s; }
 
 static inline bool gdsp_aligned16 (const void* p) { return (((uintptr_t) p) & 15) == 0; }

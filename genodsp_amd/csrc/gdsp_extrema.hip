@@ -199,10 +199,26 @@ void extrema_kernel (const double* __restrict__ in, double* __restrict__ out, ui
 
 // G = elements per block (and per thread): 16 for windows of 17 bases and more, 8 for 9..16, 4 for 5..8 --
 // a window has to reach past its right end's block for the decomposition to apply
-template <bool MAX, bool LOCAL, int G>
+// SET: 0 = values as they are; 1 / 2 = dilate / erode (morphology.c:882-1072, :1331-1454): what is staged is
+// the membership of a base in the set (1.0 / 0.0, nothing outside the vector), the window extreme is then
+// "any" (MAX) or "all" (MIN) over [i-right, i+left], and `one` or `zero` is written
+#define EXB_VALUES 0
+#define EXB_DILATE 1
+#define EXB_ERODE  2
+struct ExbSet { double T, one, zero; };
+
+template <int SET>
+__device__ __forceinline__ double exb_staged (double x, int64_t g, double T)
+	{
+	if (SET == EXB_DILATE) return ((g == 0)? (x > T) : !(x <= T))? 1.0 : 0.0;      // morphology.c:930 vs :935
+	if (SET == EXB_ERODE)  return (x > T)? 1.0 : 0.0;                              // :1384, :1391
+	return x;
+	}
+
+template <bool MAX, bool LOCAL, int G, int SET>
 __global__ __launch_bounds__(EXB_THREADS)
 void extrema_blocks_kernel (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t ntiles,
-                            int rgt, int dq, int dr, int level, int sh, double fill)
+                            int rgt, int dq, int dr, int level, int sh, double fill, ExbSet set)
 	{
 	constexpr int PITCH = G + 1;
 	constexpr int ELEMS = EXB_THREADS * G;
@@ -210,6 +226,7 @@ void extrema_blocks_kernel (const double* __restrict__ in, double* __restrict__ 
 	__shared__ __attribute__((aligned(16))) double lds[EXB_THREADS * PITCH];
 	__shared__ double blockExt[2][EXB_THREADS];
 	const double pad   = MAX? -INFINITY : INFINITY;           // never beats anything, like "outside the vector"
+	const double away  = (SET == EXB_VALUES)? pad : 0.0;      // what is staged for positions outside the vector
 	const int    haloL = dq + 1;                              // leading blocks that only feed
 	const int    outs  = (EXB_THREADS - haloL) * G - 2*sh;    // outputs stored per tile (even)
 	const int    nt    = dq - 1;                              // whole blocks always between
@@ -231,7 +248,7 @@ void extrema_blocks_kernel (const double* __restrict__ in, double* __restrict__ 
 			{
 			const int e = 2 * (u*EXB_THREADS + p);
 			double* dst = lds + e + (e >> LOG_G);
-			dst[0] = r[u].x;  dst[1] = r[u].y;
+			dst[0] = exb_staged<SET> (r[u].x, e0 + e, set.T);  dst[1] = exb_staged<SET> (r[u].y, e0 + e + 1, set.T);
 			}
 		}
 	else
@@ -239,7 +256,7 @@ void extrema_blocks_kernel (const double* __restrict__ in, double* __restrict__ 
 		for (int e=p ; e<ELEMS ; e+=EXB_THREADS)
 			{
 			const int64_t g = e0 + e;
-			lds[e + (e >> LOG_G)] = ((g >= 0) && (g < (int64_t) n))? in[g] : pad;
+			lds[e + (e >> LOG_G)] = ((g >= 0) && (g < (int64_t) n))? exb_staged<SET> (in[g], g, set.T) : away;
 			}
 		}
 	__syncthreads ();
@@ -290,6 +307,7 @@ void extrema_blocks_kernel (const double* __restrict__ in, double* __restrict__ 
 					const double v = lds[c + (c >> LOG_G)];
 					e = ex_beats<MAX> (e, v)? fill : v;
 					}
+				if (SET != EXB_VALUES) e = (e != 0.0)? set.one : set.zero;
 				P[u] = e;
 				}
 			}
@@ -324,9 +342,9 @@ void extrema_blocks_kernel (const double* __restrict__ in, double* __restrict__ 
 		}
 	}
 
-template <bool MAX, bool LOCAL, int G>
+template <bool MAX, bool LOCAL, int G, int SET = EXB_VALUES>
 static void extrema_blocks_launch (const double* d_in, double* d_out, uint32_t n, uint32_t lft, uint32_t rgt, double fill,
-                                   hipStream_t s)
+                                   hipStream_t s, ExbSet set = ExbSet ())
 	{
 	const int d  = (int) (lft + rgt);                             // left end = right end - d
 	const int dq = d / G, dr = d % G;
@@ -336,8 +354,20 @@ static void extrema_blocks_launch (const double* d_in, double* d_out, uint32_t n
 	const int sh   = ((dq + 1) * G - (int) rgt) & 1;              // keeps the first staged element even
 	const int outs = (EXB_THREADS - (dq + 1)) * G - 2*sh;
 	const uint32_t ntiles = (uint32_t) (((uint64_t) n + outs - 1) / outs);
-	hipLaunchKernelGGL ((extrema_blocks_kernel<MAX, LOCAL, G>), dim3(ntiles), dim3(EXB_THREADS), 0, s,
-	                    d_in, d_out, n, ntiles, (int) rgt, dq, dr, level, sh, fill);
+	hipLaunchKernelGGL ((extrema_blocks_kernel<MAX, LOCAL, G, SET>), dim3(ntiles), dim3(EXB_THREADS), 0, s,
+	                    d_in, d_out, n, ntiles, (int) rgt, dq, dr, level, sh, fill, set);
+	}
+
+// dilate / erode with a reach the block form covers: the window of base i is [i-right, i+left]
+bool gdsp_morph_blocks_available (uint32_t left, uint32_t right)
+	{ const uint64_t span = (uint64_t) left + right + 1;  return (span >= 17) && (span <= EXB_MAX_SPAN); }
+
+void gdsp_morph_blocks (const double* d_in, double* d_out, uint32_t n, uint32_t left, uint32_t right, int erode,
+                        double T, double one, double zero, void* stream)
+	{
+	ExbSet set = { T, one, zero };
+	if (erode) extrema_blocks_launch<false, false, 16, EXB_ERODE>  (d_in, d_out, n, right, left, 0.0, gdsp_stream (stream), set);
+	else       extrema_blocks_launch<true,  false, 16, EXB_DILATE> (d_in, d_out, n, right, left, 0.0, gdsp_stream (stream), set);
 	}
 
 template <bool MAX, bool LOCAL>
