@@ -495,7 +495,8 @@ int gdsp_window_sum (double* d_v, uint32_t n, uint32_t W, double denom, int useA
 	const uint32_t nwin = (uint32_t) (((uint64_t) n + W - 1) / W);
 	if (W <= WS_TILE_MAX_W)
 		{
-		uint32_t       K      = WS_TILE_BASES / W;                         // >= 4 whole windows per tile
+		// long windows keep few lanes busy in the summing phase: smaller tiles, more workgroups per CU to overlap it
+		uint32_t       K      = (W > 256)? ((4096 / W > 2)? 4096 / W : 2) : WS_TILE_BASES / W;
 		if ((K * W) & 1) K--;                                              // tiles start on 16-byte boundaries
 		const uint32_t ntiles = (uint32_t) (((uint64_t) n + (uint64_t) K*W - 1) / ((uint64_t) K*W));
 		const size_t   bytes  = ((size_t) K * (W | 1) + K + 2) * sizeof(double);
