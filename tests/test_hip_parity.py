@@ -248,6 +248,21 @@ def test_morphology_bit_exact(n, L, gd):
     assert bits_equal(gd.erode(d, L, 0, 0.0, 7.0, -1.0).numpy(), cpu.erode(x, L, 0, 0.0, 7.0, -1.0))
 
 
+def test_morphology_nan_membership_follows_the_reference_spelling(gd):
+    """dilate asks `v > T` at position 0 and `!(v <= T)` elsewhere, erode asks `v > T`: they differ for NaN only
+    (morphology.c:930 vs :935, :1384).  Both the block form (reach 17..3584) and the bit-mask tile must agree
+    with the oracle's restatement."""
+    rng = np.random.default_rng(77)
+    n = 20000
+    x = _islands(n, rng, max_gap=300, max_run=200)
+    x[0] = np.nan
+    x[rng.integers(1, n, 40)] = np.nan
+    d = gd.DeviceVector.from_numpy(x)
+    for left, right in ((5, 5), (50, 50), (0, 300), (700, 1), (2000, 2000)):
+        assert bits_equal(gd.dilate(d, left, right, 0.0).numpy(), cpu.dilate(x, left, right, 0.0)), ("dilate", left, right)
+        assert bits_equal(gd.erode(d, left, right, 0.0).numpy(), cpu.erode(x, left, right, 0.0)), ("erode", left, right)
+
+
 def test_morphology_all_set_and_all_clear(gd):
     for n in (1, 500, 40000):
         ones, zeros = np.ones(n), np.zeros(n)
