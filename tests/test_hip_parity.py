@@ -162,6 +162,22 @@ def test_smooth_hann_any_window_within_one_rounding_per_op(W, gd):
                                                                    float(np.max(np.abs(got - want) / np.maximum(W * 2 * EPS * scale, 1e-300))))
 
 
+@pytest.mark.parametrize("factor", [1e-300, 1e-150, 1e150, 1e290])
+def test_smooth_hann_bound_is_relative_to_the_signal(factor, gd):
+    """The same bar at very small and very large magnitudes (the block sums add up to 85 unweighted inputs:
+    the documented range ends at DBL_MAX/128)."""
+    rng = np.random.default_rng(5)
+    for W in (101, 301):
+        taps = cpu.hann_window(W)
+        for kind in ("real", "noise"):
+            x = _signal(kind, 30011, rng) * factor
+            got = gd.smooth(gd.DeviceVector.from_numpy(x), W, mode=gd.FIR_HANN).numpy()
+            want = cpu.smooth(x, W)
+            scale = cpu.fir(np.abs(x), taps)
+            assert np.all(np.isfinite(got))
+            assert np.all(np.abs(got - want) <= W * 2 * EPS * scale), (W, kind, first_diff(got, want))
+
+
 def test_smooth_hann_mode_other_windows_fall_back_to_fma(gd):
     x = _signal("real", 30000, np.random.default_rng(3))
     for W in (21, 79, 2003):
