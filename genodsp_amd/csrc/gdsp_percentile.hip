@@ -33,10 +33,8 @@
 #include "gdsp_common.h"
 
 #define PC_THREADS     256
-#define PC_PER         8
 #define PC_MAX_BLOCKS  2048
 #define PC_MAX_PIVOTS  32
-#define PC_MAX_BINS    (2*PC_MAX_PIVOTS + 1)
 #define PC_WAVE_BUF    512
 #define PC_SAMPLE_TARGET (1u << 24)
 
