@@ -479,6 +479,16 @@ static void allocate_vectors (void)
 /* Pending intervals per chromosome, in file order, flushed to the device in
  * batches: pinned staging -> hipMemcpyAsync -> gdsp_apply_intervals. */
 #define BATCH_INTERVALS (8*1024*1024)
+u64 ib_batch_limit (void)                     /* GDSP_BATCH_INTERVALS=<n>: a test hook that forces many small batches */
+	{
+	static u64 limit = 0;
+	if (limit == 0)
+		{
+		const char* e = getenv ("GDSP_BATCH_INTERVALS");
+		limit = ((e != NULL) && (atoll (e) > 0))? (u64) atoll (e) : BATCH_INTERVALS;
+		}
+	return limit;
+	}
 
 typedef struct pending { u32* start;  u32* end;  valtype* val;  u32 count, cap; } pending;
 static pending* pend = NULL;          /* indexed like chromsSorted */
@@ -697,7 +707,7 @@ void read_intervals (FILE* f, int valCol, int origin1, int overlapOp, int clear,
 			if (adjEnd   >= s->length) adjEnd = s->length;
 			}
 		ib_add (s, adjStart, adjEnd, val);
-		if (ib_pending () >= BATCH_INTERVALS)
+		if (ib_pending () >= ib_batch_limit ())
 			{
 			ib_flush_apply (overlapOp, clearFlags, missingVal, (clearFlags & GDSP_CLEAR_FILL) != 0);
 			clearFlags &= ~GDSP_CLEAR_FILL;            /* later batches keep only the first-touch rule */

@@ -18,6 +18,7 @@ void ib_flush_mask  (int inside, valtype outsideVal, int binarizeFirst);
 void ib_flush_over  (int wantMax, valtype fillVal);
 
 void sync_all_devices    (void);
+u64   ib_batch_limit (void);                   /* intervals buffered before they are applied (8 M; GDSP_BATCH_INTERVALS) */
 void* device_workspace (size_t bytes);         /* per-device, grows on demand, kept for the run */
 void* long_window_workspace (size_t* bytes);   /* lazily allocated, for windows beyond one LDS tile */
 int  device_count_in_use (void);

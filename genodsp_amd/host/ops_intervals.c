@@ -166,7 +166,7 @@ static void fileop_apply (dspop* _op)
 		else if (op->kind == K_MASK)     val = op->maskVal;
 		else if (op->kind == K_OR)       val = 1.0;
 		ib_add (s, adjStart, adjEnd, val);
-		if ((op->kind <= K_SUBTRACT) && (ib_pending () >= 8*1024*1024)) ib_flush_apply (ri_overlapSum, 0, 0.0, false);
+		if ((op->kind <= K_SUBTRACT) && (ib_pending () >= ib_batch_limit ())) ib_flush_apply (ri_overlapSum, 0, 0.0, false);
 		}
 	fclose (f);
 

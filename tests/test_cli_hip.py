@@ -260,3 +260,15 @@ def test_threaded_ingest_reads_what_the_line_reader_reads(with_values, tmp_path,
     lines[20000] = "chr1 zz 4"
     rc, out, err = both(lines)
     assert rc != 0 and "zz" in err
+
+
+@pytest.mark.parametrize("case", DIGEST_CASES[::6], ids=[c["name"] for c in DIGEST_CASES[::6]])
+def test_many_small_interval_batches_give_the_same_output(case, tmp_path, monkeypatch):
+    """Ingest and the interval-file operators buffer 8 M intervals before they go to the device; GDSP_BATCH_INTERVALS
+    forces a batch every 7 intervals, so that the batch seams (first-touch rule of `input`, file order of
+    overlapping `add`) sit all over these inputs.  The reference binary's digest must still be met."""
+    import hashlib
+    monkeypatch.setenv("GDSP_BATCH_INTERVALS", "7")
+    rc, out, err = run(case["args"], case["stdin"], case["chroms_text"], tmp_path, case.get("files"))
+    assert rc == 0, err
+    assert hashlib.sha256(out.encode()).hexdigest() == case["sha256"], case["args"]
