@@ -99,6 +99,16 @@ def test_smooth_w101_full_chromosome(gd, real):
     stencil_check(peaks, lambda x: cpu.local_extrema(cpu.smooth(x, 101), 11, 1, 0.0), 1, 55, rng)
 
 
+def test_block_form_windows_full_chromosome(gd, real, depth):
+    """The block-form kernels at full size: both chromosome ends and 160+ random stretches, bit for bit."""
+    rng = np.random.default_rng(6)
+    stencil_check(gd.best_extrema(real, 1001, True), lambda x: cpu.best_extrema(x, 1001, 1), 1, 1001, rng)
+    stencil_check(gd.best_extrema(real, 100, False), lambda x: cpu.best_extrema(x, 100, 0), 1, 100, rng)
+    stencil_check(gd.local_extrema(real, 101, True, 0.0), lambda x: cpu.local_extrema(x, 101, 1, 0.0), 1, 101, rng)
+    stencil_check(gd.local_extrema(depth, 11, False, 99.0), lambda x: cpu.local_extrema(x, 11, 0, 99.0), 0, 11, rng)
+    stencil_check(gd.sliding_sum(depth, 1000, 7.0), lambda x: cpu.sliding_sum(x, 1000, 7.0), 0, 1000, rng)
+
+
 def test_dilate_erode_binarize_full_chromosome(gd, depth):
     rng = np.random.default_rng(2)
     left, right = gd.split_length(1001)
