@@ -58,7 +58,12 @@ class Stream:
 
 
 def sync(stream=None):
-    call("gdsp_stream_sync", _sp(stream))
+    """Wait for `stream`; with no stream, for EVERY stream of the current device (the library's streams are
+    non-blocking, so the NULL stream alone would not order a copy behind a kernel launched on one of them)."""
+    if stream:
+        call("gdsp_stream_sync", _sp(stream))
+    else:
+        call("gdsp_device_sync")
 
 
 class Event:
@@ -99,12 +104,14 @@ class DeviceBuffer:
     def upload(self, arr, offset=0, stream=None):
         arr = np.ascontiguousarray(arr)
         assert offset + arr.nbytes <= self.nbytes
+        sync(stream)                     # nothing launched earlier, on whatever stream, may still be using the bytes
         call("gdsp_memcpy_h2d", C.c_void_p(self.ptr + offset), arr.ctypes.data_as(C.c_void_p), arr.nbytes, _sp(stream))
         sync(stream)
 
     def download(self, dtype, count, offset=0, stream=None):
         out = np.empty(count, dtype)
         assert offset + out.nbytes <= self.nbytes
+        sync(stream)                     # producers on other (non-blocking) streams included when stream is None
         call("gdsp_memcpy_d2h", out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr + offset), out.nbytes, _sp(stream))
         sync(stream)
         return out
@@ -140,6 +147,7 @@ class DeviceVector:
     def copy(self, stream=None):
         out = self.like()
         if self.n:
+            sync(stream)
             call("gdsp_memcpy_d2d", out.ptr, self.ptr, self.n * 8, _sp(stream))
         return out
 

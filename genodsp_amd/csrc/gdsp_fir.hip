@@ -36,6 +36,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <mutex>
+#include <vector>
 #include "gdsp_common.h"
 
 #define FIR_THREADS 256
@@ -405,9 +406,10 @@ extern "C" {
 
 // Hann plans cached per (device, W): `smooth` rebuilds its window for every
 // chromosome in the reference (sum.c:632-645); here it is built once.
-#define SMOOTH_CACHE 32
-static struct { int device; uint32_t W; gdsp_fir_plan* plan; } smoothCache[SMOOTH_CACHE];
-static int        smoothCacheLen = 0;
+// Plans are never evicted (an entry is W taps; a caller or a kernel in flight on another
+// device may still hold a plan's taps), so a pointer handed out stays valid for the process.
+struct smooth_cache_entry { int device; uint32_t W; gdsp_fir_plan* plan; };
+static std::vector<smooth_cache_entry> smoothCache;
 static std::mutex smoothCacheLock;
 
 static int smooth_plan (uint32_t W, gdsp_fir_plan** out);
@@ -466,8 +468,8 @@ static int smooth_plan (uint32_t W, gdsp_fir_plan** out)
 
 	gdsp_fir_plan* plan = NULL;
 	std::lock_guard<std::mutex> hold (smoothCacheLock);
-	for (int i=0 ; i<smoothCacheLen ; i++)
-		{ if ((smoothCache[i].device == device) && (smoothCache[i].W == W)) { plan = smoothCache[i].plan;  break; } }
+	for (const smooth_cache_entry& e : smoothCache)
+		{ if ((e.device == device) && (e.W == W)) { plan = e.plan;  break; } }
 	if (plan == NULL)
 		{
 		double* taps = (double*) malloc ((size_t) W * sizeof(double));
@@ -476,12 +478,7 @@ static int smooth_plan (uint32_t W, gdsp_fir_plan** out)
 		int rc = gdsp_fir_plan_create (&plan, taps, W);
 		free (taps);
 		if (rc != GDSP_OK) return rc;
-		if (smoothCacheLen == SMOOTH_CACHE)
-			{ gdsp_fir_plan_destroy (smoothCache[0].plan);  smoothCache[0] = smoothCache[--smoothCacheLen]; }
-		smoothCache[smoothCacheLen].device = device;
-		smoothCache[smoothCacheLen].W      = W;
-		smoothCache[smoothCacheLen].plan   = plan;
-		smoothCacheLen++;
+		smoothCache.push_back (smooth_cache_entry { device, W, plan });
 		}
 	*out = plan;
 	return GDSP_OK;

@@ -20,7 +20,12 @@ void gdsp_set_error (const char* fmt, ...)
 extern "C" {
 
 const char* gdsp_last_error (void) { return gdsp_error_text; }
-const char* gdsp_version    (void) { return "genodsp_hip 0.1 (gfx950)"; }
+// "<library version> (gfx950) <git hash of the tree the library was built from>[-dirty]"; the hash comes from
+// the Makefile (GDSP_BUILD_ID), "unknown" where the sources were not under git when it was built
+#ifndef GDSP_BUILD_ID
+#define GDSP_BUILD_ID "unknown"
+#endif
+const char* gdsp_version    (void) { return "genodsp_hip 0.2 (gfx950) " GDSP_BUILD_ID; }
 
 int gdsp_device_count (int* count)
 	{
@@ -88,6 +93,12 @@ int gdsp_memcpy_d2d (void* d_dst, const void* d_src, size_t bytes, void* stream)
 	return GDSP_OK;
 	}
 
+int gdsp_memset (void* d_dst, int byte, size_t bytes, void* stream)
+	{
+	GDSP_HIP_TRY (hipMemsetAsync (d_dst, byte, bytes, gdsp_stream (stream)));
+	return GDSP_OK;
+	}
+
 int gdsp_stream_create (void** stream)
 	{
 	GDSP_REQUIRE (stream != NULL, "stream is NULL");
@@ -106,6 +117,12 @@ int gdsp_stream_destroy (void* stream)
 int gdsp_stream_sync (void* stream)
 	{
 	GDSP_HIP_TRY (hipStreamSynchronize (gdsp_stream (stream)));
+	return GDSP_OK;
+	}
+
+int gdsp_device_sync (void)
+	{
+	GDSP_HIP_TRY (hipDeviceSynchronize ());
 	return GDSP_OK;
 	}
 

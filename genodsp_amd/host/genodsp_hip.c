@@ -33,9 +33,12 @@
 #define specialPipeChar        '='
 
 /* ------------------------------------------------------------ operator table */
-/* same names, aliases and order as the reference's dspTable (genodsp.c:117-174);
- * operators outside the hot-path scope (clump, anticlump) are not in
- * this build and are reported as such */
+/* same names, aliases and order as the reference's dspTable (genodsp.c:117-174): all 37
+ * operators.  As in the reference a "plugin" is a link-time function group: a further group
+ * is added by compiling the driver with -DGDSP_EXTRA_OPERATORS='"my_ops.h"', a header that
+ * declares the groups (dspprototypes) and defines GDSP_EXTRA_DSPTABLE_ROWS as the rows to append
+ * (dspinforecord("name", op_x), ...), and by linking the group's object file (INTEGRATION.md;
+ * tests/test_plugin_boundary.py builds and runs such a driver). */
 dspprototypes(op_window_sum)     dspprototypes(op_sliding_sum)   dspprototypes(op_smooth)
 dspprototypes(op_cumulative_sum) dspprototypes(op_percentile)    dspprototypes(op_add)
 dspprototypes(op_subtract)       dspprototypes(op_add_constant)  dspprototypes(op_invert)
@@ -49,6 +52,9 @@ dspprototypes(op_mask)           dspprototypes(op_mask_not)      dspprototypes(o
 dspprototypes(op_and)            dspprototypes(op_min_with)      dspprototypes(op_max_with)
 dspprototypes(op_map)            dspprototypes(op_min_in_interval) dspprototypes(op_max_in_interval)
 dspprototypes(op_clump)          dspprototypes(op_skimp)
+#ifdef GDSP_EXTRA_OPERATORS
+#include GDSP_EXTRA_OPERATORS
+#endif
 
 static dspinfo dspTable[] =
 	{dspinforecord("sum"           , op_window_sum)     , dspinfoalias ("window_sum")     ,
@@ -89,7 +95,11 @@ static dspinfo dspTable[] =
 	 dspinforecord("map"           , op_map)            ,
 	 dspinforecord("input"         , op_input)          ,
 	 dspinforecord("output"        , op_output)         ,
-	 dspinforecord("variables"     , op_show_variables) };
+	 dspinforecord("variables"     , op_show_variables)
+#ifdef GDSP_EXTRA_DSPTABLE_ROWS
+	 , GDSP_EXTRA_DSPTABLE_ROWS
+#endif
+	};
 #define dspTableLen (sizeof(dspTable)/sizeof(dspinfo))
 
 static const char* notInThisBuild[] = { NULL };    /* every operator of the reference's table is built */
@@ -128,6 +138,8 @@ typedef struct devstate
 	void*    stream;
 	valtype* scratch[4];  /* lazily allocated, longest-local-chromosome sized */
 	int      scratchInUse[4];
+	s32*     scratchInts[4];
+	int      scratchIntsInUse[4];
 	u32      maxLength;   /* longest chromosome on this device */
 	} devstate;
 
@@ -426,6 +438,38 @@ void release_scratch_vector (valtype* v)
 	for (int i=0 ; i<4 ; i++) { if (d->scratch[i] == v) { d->scratchInUse[i] = false;  return; } }
 	}
 
+s32* get_scratch_ints (void)                              /* genodsp.c:1943-1979, on the current device */
+	{
+	devstate* d = &devs[currentDevice];
+	for (int i=0 ; i<4 ; i++)
+		{
+		if (d->scratchIntsInUse[i]) continue;
+		if (d->scratchInts[i] == NULL)
+			{
+			size_t n = (d->maxLength > 16384)? d->maxLength : 16384;
+			check_gdsp (gdsp_malloc ((void**) &d->scratchInts[i], (n + 4) * sizeof(s32)), "allocate scratch ints");
+			/* the reference callocs: a fresh vector reads as zeros */
+			check_gdsp (gdsp_memset (d->scratchInts[i], 0, (n + 4) * sizeof(s32), d->stream), "clear scratch ints");
+			}
+		d->scratchIntsInUse[i] = true;
+		return d->scratchInts[i];
+		}
+	fprintf (stderr, "[%s] internal error: out of scratch int vectors\n", programName);
+	exit (EXIT_FAILURE);
+	}
+
+void release_scratch_ints (s32* v)
+	{
+	devstate* d = &devs[currentDevice];
+	for (int i=0 ; i<4 ; i++) { if (d->scratchInts[i] == v) { d->scratchIntsInUse[i] = false;  return; } }
+	}
+
+int valtype_ascending (const void* v1, const void* v2)   /* genodsp.c:2262-2270; host arrays only */
+	{
+	const valtype a = *(const valtype*) v1, b = *(const valtype*) v2;
+	return (a > b) - (a < b);
+	}
+
 void sync_all_devices (void)
 	{
 	for (int d=0 ; d<numDevices ; d++)
@@ -435,6 +479,8 @@ void sync_all_devices (void)
 		}
 	check_gdsp (use_device (currentDevice), "select device");
 	}
+
+gdsp_reduce_fn reduce_over_devices (void** ctx) { *ctx = NULL;  return NULL; }
 
 int device_count_in_use (void) { return numDevices; }
 int device_index_of (spec* s)  { return ((xspec*) s)->device; }
@@ -851,6 +897,33 @@ void report_intervals (FILE* f, int precision, int noValues, int collapse, int u
 		free (runStart);  free (runEnd);  free (runVal);
 		}
 	if (trackOperations) tracking_report ("output(--done--)\n");
+	}
+
+/* read_all_chromosomes / write_all_chromosomes, genodsp.c:1718-1792: the signal as text, ten decimals, runs
+ * collapsed, zero stretches left out; read back over a cleared genome.  (percentile --preserve: values come
+ * back rounded to ten decimals, exactly as they do in the reference.) */
+void write_all_chromosomes (char* filename)
+	{
+	FILE* f = fopen (filename, "wt");
+	if (f == NULL) { fprintf (stderr, "can't open \"%s\" for writing\n", filename);  exit (EXIT_FAILURE); }
+	if (trackOperations) fprintf (stderr, "write_all(%s)\n", filename);
+	int saveTrack = trackOperations;
+	trackOperations = false;
+	report_intervals (f, /*precision*/ 10, /*no values*/ false, /*collapse*/ true, uncovered_hide, /*origin one*/ false);
+	trackOperations = saveTrack;
+	fclose (f);
+	}
+
+void read_all_chromosomes (char* filename)
+	{
+	FILE* f = fopen (filename, "rt");
+	if (f == NULL) { fprintf (stderr, "can't open \"%s\" for reading\n", filename);  exit (EXIT_FAILURE); }
+	if (trackOperations) fprintf (stderr, "read_all(%s)\n", filename);
+	int saveTrack = trackOperations;
+	trackOperations = false;
+	read_intervals (f, /*value column*/ 4-1, /*origin one*/ false, ri_overlapSum, /*clear*/ true, 0.0);
+	trackOperations = saveTrack;
+	fclose (f);
 	}
 
 /* ------------------------------------------------------------- option parsing */

@@ -4,6 +4,7 @@
 #define host_services_H
 
 #include "genodsp_interface.h"
+#include "genodsp_hip.h"
 
 extern int selectStrategy;                  /* GDSP_SELECT_* (--percentile=) */
 extern int firMode;                         /* GDSP_FIR_EXACT or GDSP_FIR_FMA (--smooth=) */
@@ -18,6 +19,9 @@ void ib_flush_mask  (int inside, valtype outsideVal, int binarizeFirst);
 void ib_flush_over  (int wantMax, valtype fillVal);
 
 void sync_all_devices    (void);
+/* how whole-genome operators (percentile, invert) combine what the devices of this process found: the
+ * reduction hook for gdsp_percentiles (NULL: the library adds its devices' counts on the host) */
+gdsp_reduce_fn reduce_over_devices (void** ctx);
 u64   ib_batch_limit (void);                   /* intervals buffered before they are applied (8 M; GDSP_BATCH_INTERVALS) */
 void* device_workspace (size_t bytes);         /* per-device, grows on demand, kept for the run */
 void* long_window_workspace (size_t* bytes);   /* lazily allocated, for windows beyond one LDS tile */

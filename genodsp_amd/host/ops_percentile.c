@@ -3,12 +3,14 @@
  *
  * Argument rules, rank formula, variable names and messages follow percentile.c:131-375,
  * :587-589, :657-710, :756-780 in the reference.  The reference sorts the genome in place
- * (destroying it, percentile.c:34-36, hence its --preserve option); here the k-th smallest
- * is found by radix select on the device (gdsp_select_histogram) and the signal is left
- * untouched, so --preserve is accepted and does nothing.  With several GPUs every device
- * histograms its own chromosomes; the histograms are summed (here on the host, one process
- * drives all devices; bench.py and the Python binding do the same sum with an RCCL
- * all-reduce when every GPU has its own process). */
+ * (destroying it, percentile.c:34-36, hence its --preserve option); here the order statistics
+ * are found on the device (gdsp_percentiles) and the signal is left untouched.  --preserve=<file>
+ * still does what it does in the reference -- the signal goes to the file as text with ten decimals
+ * and is read back afterwards (percentile.c:532-535, :716-724), so values come back rounded to ten
+ * decimals and the (emptied) file is left behind -- because a pipeline's output must not depend on
+ * which of the two programs ran it.  With several GPUs every device counts its own chromosomes and
+ * the counts are summed by the library's reduction hook (reduce_over_devices below: RCCL
+ * all-reduce over the devices of this process, or a host sum with --reduce=host). */
 #include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
@@ -48,7 +50,9 @@ void op_percentile_usage (char* name, FILE* f, char* indent)
 	fprintf (f, "%s  --map=<filename>         write \"value percentile\" lines to a file\n", indent);
 	fprintf (f, "%s  --report:bash            print results as shell assignments on stdout\n", indent);
 	fprintf (f, "%s  --quiet                  do not report results on stderr\n", indent);
-	fprintf (f, "%s  --preserve=<filename>    accepted for compatibility; nothing needs preserving\n", indent);
+	fprintf (f, "%s  --preserve=<filename>    write the signal to this file first and read it back afterwards, as\n", indent);
+	fprintf (f, "%s                           genodsp does (values return rounded to ten decimals); without it\n", indent);
+	fprintf (f, "%s                           the signal is simply left as it is\n", indent);
 	}
 
 static u32 to_thousandths (valtype pct)           /* percentile.c:296-302 */
@@ -65,7 +69,8 @@ dspop* op_percentile_parse (char* name, int argc, char** argv)
 	op->percentileStep = percentileStepUnits;
 	op->minAllowed     = -valtypeMax;
 	op->maxAllowed     =  valtypeMax;
-	op->windowSize     = 1;
+	op->windowSize     = (u32) get_named_global ("windowSize", 1);      /* percentile.c:153: the global --window= */
+	if (op->windowSize == 0) op->windowSize = 1;
 	op->valPrecision   = (int) get_named_global ("valPrecision", 0);
 
 	for ( ; argc > 0 ; argv++, argc--)
@@ -168,14 +173,27 @@ void op_percentile_apply (dspop* _op, arg_dont_complain(char* vName), arg_dont_c
 	{
 	dspop_percentile* op = (dspop_percentile*) _op;
 	char  varName[100];
+
+	/* percentile.c:432-530: `0`, `100` and any range from 0 to 100 are answered from the minimum and maximum of
+	 * the sample alone -- only percentile0 / percentile100 are set, nothing is reported, nothing is preserved */
+	int onlyMin = (op->percentileLo == 0) && (op->percentileHi == 0);
+	int onlyMax = (op->percentileLo == 100*percentileStepUnits) && (op->percentileHi == 100*percentileStepUnits);
+	int minAndMax = (op->percentileLo == 0) && (op->percentileHi == 100*percentileStepUnits);
+	int extremesOnly = (op->mapFilename == NULL) && (onlyMin || onlyMax || minAndMax);
+
+	if ((op->preserveFilename != NULL) && !extremesOnly) write_all_chromosomes (op->preserveFilename);
 	FILE* mapF = (op->mapFilename != NULL)? fopen (op->mapFilename, "wt") : NULL;
 
-	/* every chromosome on every GPU is one source of the population; the library adds the
-	 * devices' counts itself, so there is nothing to reduce across processes here */
+	/* every chromosome on every GPU is one source of the population; the counts of the devices of this
+	 * process are added through the driver's reduction (RCCL over the devices in use, see genodsp_hip.c) */
 	int nsrc = 0, npct = 0;
 	for (int i=0 ; chromsSorted[i]!=NULL ; i++) nsrc++;
-	for (u32 pt=op->percentileLo ; pt<=op->percentileHi ; pt+=op->percentileStep)
-		{ npct++;  if (op->percentileStep == 0) break; }
+	if (extremesOnly) npct = minAndMax? 2 : 1;
+	else
+		{
+		for (u32 pt=op->percentileLo ; pt<=op->percentileHi ; pt+=op->percentileStep)
+			{ npct++;  if (op->percentileStep == 0) break; }
+		}
 	gdsp_select_source* src = (gdsp_select_source*) calloc (nsrc? nsrc : 1, sizeof(gdsp_select_source));
 	u32*     pts  = (u32*)     calloc (npct, sizeof(u32));
 	valtype* vals = (valtype*) calloc (npct, sizeof(valtype));
@@ -190,11 +208,21 @@ void op_percentile_apply (dspop* _op, arg_dont_complain(char* vName), arg_dont_c
 		src[i].device = physical_device_of (s);  src[i].stream = op_stream ();
 		}
 	npct = 0;
-	for (u32 pt=op->percentileLo ; pt<=op->percentileHi ; pt+=op->percentileStep)
-		{ pts[npct++] = pt;  if (op->percentileStep == 0) break; }
+	if (extremesOnly)
+		{
+		if (onlyMax || minAndMax) pts[npct++] = 100*percentileStepUnits;      /* percentile100 is set first (:524-527) */
+		if (onlyMin || minAndMax) pts[npct++] = 0;
+		}
+	else
+		{
+		for (u32 pt=op->percentileLo ; pt<=op->percentileHi ; pt+=op->percentileStep)
+			{ pts[npct++] = pt;  if (op->percentileStep == 0) break; }
+		}
 	u64 numValues = 0;
+	void* reduceCtx = NULL;
+	gdsp_reduce_fn reduce = reduce_over_devices (&reduceCtx);
 	check_gdsp (gdsp_percentiles (src, nsrc, op->windowSize, op->minAllowed, op->maxAllowed, pts, npct,
-	                              selectStrategy, 0, NULL, NULL, vals, &numValues), "percentile");
+	                              selectStrategy, 0, reduce, reduceCtx, vals, &numValues), "percentile");
 	if (nsrc > 0) select_device_of (chromsSorted[0]);
 	free (src);
 	if (numValues == 0)
@@ -213,6 +241,7 @@ void op_percentile_apply (dspop* _op, arg_dont_complain(char* vName), arg_dont_c
 		float pPct = pt / ((float) percentileStepUnits);
 		percentile_name (varName, pt);
 		set_named_global (varName, pVal);
+		if (extremesOnly) continue;
 		if (op->reportForBash)
 			fprintf (stdout, "%s=" valtypeFmtPrec " # bash command\n", varName, op->valPrecision, pVal);
 		else if (!op->quiet)
@@ -221,4 +250,11 @@ void op_percentile_apply (dspop* _op, arg_dont_complain(char* vName), arg_dont_c
 		}
 	if (mapF != NULL) fclose (mapF);
 	free (pts);  free (vals);
+
+	if ((op->preserveFilename != NULL) && !extremesOnly)     /* percentile.c:716-724: restore, then empty the file */
+		{
+		read_all_chromosomes (op->preserveFilename);
+		FILE* f = fopen (op->preserveFilename, "wb");
+		if (f != NULL) fclose (f);
+		}
 	}

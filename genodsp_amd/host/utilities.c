@@ -12,6 +12,9 @@
 #include <float.h>
 #include "utilities.h"
 
+#define true  1
+#define false 0
+
 static void die (const char* what, const char* s)
 	{
 	fprintf (stderr, "\"%s\" %s\n", s, what);
@@ -36,6 +39,14 @@ int strcmp_suffix (const char* str, const char* suffix)
 	size_t n = strlen (str), m = strlen (suffix);
 	if (m > n) return -1;
 	return strcmp (str + n - m, suffix);
+	}
+
+int strncmp_suffix (const char* str, const char* suffix, size_t n)   /* utilities.c:104-116 in the reference */
+	{
+	size_t len = strlen (str), m = strlen (suffix);
+	if (len > n) len = n;
+	if (m > len) return strcmp (str, suffix);
+	return strcmp (str + len - m, suffix);
 	}
 
 int string_to_int (const char* s)
@@ -171,6 +182,17 @@ char* ucommatize (const u64 v)
 		}
 	out[o] = 0;
 	return out;
+	}
+
+char* duration_to_string (float seconds)                           /* utilities.c:449-473 in the reference */
+	{
+	static char text[64];
+	int whole = (int) (seconds / 60);
+	if (seconds < 60)   { snprintf (text, sizeof(text), "%.3fs", seconds);  return text; }
+	seconds -= 60 * whole;
+	if (whole < 60) snprintf (text, sizeof(text), "%dm%06.3fs", whole, seconds);
+	else            snprintf (text, sizeof(text), "%dh%02dm%06.3fs", whole / 60, whole % 60, seconds);
+	return text;
 	}
 
 void safe_strncpy (char* dest, const char* src, size_t n)

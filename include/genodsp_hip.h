@@ -60,9 +60,11 @@ int gdsp_host_free      (void* h_ptr);
 int gdsp_memcpy_h2d     (void* d_dst, const void* h_src, size_t bytes, void* stream);
 int gdsp_memcpy_d2h     (void* h_dst, const void* d_src, size_t bytes, void* stream);
 int gdsp_memcpy_d2d     (void* d_dst, const void* d_src, size_t bytes, void* stream);
+int gdsp_memset         (void* d_dst, int byte, size_t bytes, void* stream);
 int gdsp_stream_create  (void** stream);
 int gdsp_stream_destroy (void* stream);
 int gdsp_stream_sync    (void* stream);
+int gdsp_device_sync    (void);                                /* every stream of the current device */
 int gdsp_event_create   (void** event);
 int gdsp_event_destroy  (void* event);
 int gdsp_event_record   (void* event, void* stream);

@@ -2,10 +2,14 @@
  *
  * This is an independent, ABI-compatible re-declaration of the reference's
  * operator interface (rsharris/genodsp genodsp_interface.h:20-190): the same type
- * names, struct layouts, macro names and host-service prototypes, so that an
- * operator group written against the reference's header (five functions
- * X_short / X_usage / X_parse / X_free / X_apply registered with
- * dspinforecord(name, X)) compiles against this one unchanged.
+ * names, struct layouts, macro names and ALL sixteen host-service prototypes
+ * (:167-190), so that an operator group written against the reference's header
+ * (five functions X_short / X_usage / X_parse / X_free / X_apply registered with
+ * dspinforecord(name, X)) compiles against this one unchanged.  Held by
+ * tests/test_plugin_boundary.py: every operator file of the reference passes
+ * `gcc -fsyntax-only -Wall -Wextra -Werror` against include/ (where /root/reference
+ * exists), and a group written in the reference's style is linked into the driver's
+ * table (GDSP_EXTRA_OPERATORS) and run on the GPU.
  *
  * The one semantic difference is where the values live: `valVector` and the `v`
  * handed to X_apply are DEVICE pointers (f64 arrays in HBM).  An operator body
@@ -19,20 +23,11 @@
 
 #include <stdio.h>
 #include <inttypes.h>
+#include "utilities.h"                  /* s32/u32/s64/u64, arg_dont_complain and the string helpers; the reference's
+                                           operator files include it themselves, before this header */
 
 #ifdef __cplusplus
 extern "C" {
-#endif
-
-typedef int32_t  s32;                   /* utilities.h:4-8 in the reference */
-typedef uint32_t u32;
-typedef int64_t  s64;
-typedef uint64_t u64;
-
-#ifdef __GNUC__
-#define arg_dont_complain(arg) arg __attribute__ ((unused))
-#else
-#define arg_dont_complain(arg) arg
 #endif
 
 #ifndef true
@@ -50,8 +45,17 @@ void chastise (const char* format, ...);           /* message, the operator's us
 void tracking_report (const char* format, ...);    /* --progress=operations                    */
 struct spec* find_chromosome_spec (char* chrom);
 
-valtype* get_scratch_vector (void);                /* DEVICE scratch, longest-chromosome sized */
+valtype* get_scratch_vector (void);                /* DEVICE scratch: longest-chromosome many valtype, on the current GPU */
 void release_scratch_vector (valtype* v);
+s32*  get_scratch_ints (void);                     /* DEVICE scratch: longest-chromosome many s32 (:182, genodsp.c:1943-1979) */
+void  release_scratch_ints (s32* v);
+
+/* the whole signal to / from a text file (genodsp.c:1718-1792): what percentile --preserve uses.
+ * Written with 10 decimals, runs collapsed, zero stretches left out; read back over a cleared genome. */
+void read_all_chromosomes  (char* filename);
+void write_all_chromosomes (char* filename);
+
+int  valtype_ascending (const void* v1, const void* v2);      /* qsort comparator for HOST arrays of valtype (:190) */
 
 int named_global_exists (char* name, valtype* val);           /* the percentile -> threshold channel */
 valtype get_named_global (char* name, valtype defaultVal);

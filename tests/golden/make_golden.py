@@ -426,6 +426,31 @@ def random_file_case(k):
 for k in range(40):
     random_file_case(k)
 
+# ---- round 2 (appended; earlier cases keep their random streams) -------------------------------------------
+# percentile: the global --window= is its default window (percentile.c:153); --preserve really writes the signal
+# with ten decimals and reads it back (:532-535, :716-724), so values return rounded; `0`, `100` and any range
+# from 0 to 100 are answered from the extremes alone, silently (:432-530)
+def long_decimals(n, seed, count):
+    r = np.random.default_rng(seed)
+    out = []
+    for _ in range(count):
+        a = int(r.integers(0, n - 80))
+        out.append("chrV %d %d %.15f" % (a, a + int(r.integers(1, 80)), r.random() * 3))
+    return "\n".join(out) + "\n"
+
+
+cli_case("cli_percentile_global_window_preserve", "chrV 4000\nchrW 900\n",
+         ["--window=7", "--precision=14", "=", "percentile", "75", "--preserve=@keep@"],
+         long_decimals(4000, 11, 300) + "chrW 10 500 0.00000000004\nchrW 100 300 1.00000000005\n", {"keep": ""})
+cli_case("cli_percentile_opt_window_beats_global", "chrV 4000\n",
+         ["--window=7", "--precision=3", "=", "percentile", "40..60by10", "--window=3", "--preserve=@keep@", "=", "variables"],
+         long_decimals(4000, 12, 200), {"keep": ""})
+for tag, what in (("0", ["0"]), ("100", ["100"]), ("0_to_100by10", ["0..100by10"]), ("0_100_bash", ["0,100", "--report:bash"]),
+                  ("0_map", ["0", "--map=@m@"])):
+    cli_case("cli_percentile_extremes_" + tag, APPENDIX_C_CH,
+             ["--novalue", "=", "percentile"] + what + ["--min=1/inf", "=", "variables"], APPENDIX_C_IV,
+             {"m": ""} if "--map=@m@" in what else None)
+
 np.savez_compressed(os.path.join(HERE, "golden.npz"), **arrays)
 with open(os.path.join(HERE, "golden.json"), "w") as f:
     json.dump({"seed": SEED, "cases": cases}, f, indent=1)

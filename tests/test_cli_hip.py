@@ -49,12 +49,16 @@ def test_cli_stdout_matches_reference(case, tmp_path):
         pytest.skip("reference itself failed on this input")
     rc, out, err = run(case["args"], case["stdin"], case["chroms_text"], tmp_path, case.get("files"))
     assert rc == 0, err
-    if "percentile" in case["args"] and "input" not in case["args"]:
+    if case["name"] in ("cli_percentile99", "cli_percentile_extremes_0_map"):
         # the reference prints its sort-scrambled signal after percentile (percentile.c:34-36);
         # here the signal is untouched, i.e. the output of the same pipeline without the operator
         assert out == golden().cases["cli_coverage"]["stdout"]
     else:
         assert out == case["stdout"]
+    if case["name"].startswith("cli_percentile_"):
+        # what percentile reports and what it does not (the extremes are answered silently, percentile.c:432-530),
+        # and the variables it leaves behind, in the reference's order
+        assert err == case["stderr"]
     # the percentile report line goes to stderr in both programs
     for line in case["stderr"].splitlines():
         if line.startswith("percentile "):
