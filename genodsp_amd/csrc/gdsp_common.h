@@ -34,6 +34,9 @@ void gdsp_set_error (const char* fmt, ...);
 bool gdsp_hann_blocks_available (uint32_t W);
 int  gdsp_hann_blocks_apply (const double* d_in, double* d_out, uint32_t n, uint32_t W, void* stream);
 
+// gdsp_fir.hip: the device copy of the reference's Hann taps for W (cached per device, never freed)
+int  gdsp_smooth_taps_device (uint32_t W, const double** d_taps);
+
 // gdsp_extrema.hip: dilate / erode as window-any / window-all in the block form
 bool gdsp_morph_blocks_available (uint32_t left, uint32_t right);
 void gdsp_morph_blocks (const double* d_in, double* d_out, uint32_t n, uint32_t left, uint32_t right, int erode,

@@ -390,6 +390,15 @@ int gdsp_fir_apply (const gdsp_fir_plan* plan, const double* d_in, double* d_out
 
 } // extern "C"
 
+static int smooth_plan (uint32_t W, gdsp_fir_plan** out);
+int gdsp_smooth_taps_device (uint32_t W, const double** d_taps)
+	{
+	gdsp_fir_plan* plan = NULL;
+	int rc = smooth_plan (W, &plan);
+	if (rc == GDSP_OK) *d_taps = plan->d_taps;
+	return rc;
+	}
+
 template <bool FMA, bool MAX>
 static void fir_extrema_launch (const double* d_in, double* d_out, uint32_t n, const double* h_taps,
                                 int h, double fill, hipStream_t s)
@@ -411,8 +420,6 @@ extern "C" {
 struct smooth_cache_entry { int device; uint32_t W; gdsp_fir_plan* plan; };
 static std::vector<smooth_cache_entry> smoothCache;
 static std::mutex smoothCacheLock;
-
-static int smooth_plan (uint32_t W, gdsp_fir_plan** out);
 
 // 1 when gdsp_smooth_local_extrema has a fused kernel for this pair of parameters
 int gdsp_smooth_local_extrema_fusable (uint32_t W, uint32_t N)

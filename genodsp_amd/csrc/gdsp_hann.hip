@@ -37,10 +37,14 @@
 // report see such ties; that is why EXACT stays the default of the command line, why the fused
 // smooth+extrema kernel evaluates directly whatever the mode, and why this mode is for the
 // smoothed track as a floating-point result.
-// Range: the block sums add up to 85 unweighted inputs, so inputs beyond DBL_MAX/128 overflow where the
-// weighted sum would not, and a window that holds an infinity yields NaN (inf - inf) where direct
-// evaluation yields the infinity; a NaN input gives NaN for exactly the windows that hold it, as in
-// the reference.
+// Range: the block sums add up to 85 unweighted inputs, which would overflow on inputs beyond DBL_MAX/128
+// where the weighted sum does not, and a window holding an infinity would give inf - inf.  So every thread
+// looks at the exponents of its own block while it builds the prefix sums (one integer max per element), the
+// four waves' verdicts ride the barrier that is there anyway, and a tile that holds a NaN, an infinity or a
+// magnitude of 2^1017 or more is evaluated tap by tap instead (hann_direct_tile: ascending fused multiply-adds,
+// the taps as data -- the very operations of GDSP_FIR_FMA, so such a tile is bit-identical to that mode and
+// inf / NaN / DBL_MAX (what `localmin` leaves behind, minmax.c:901) come out as direct evaluation gives them).
+// With that, the mode differs from the reference by rounding only, on any input.
 
 #include <math.h>
 #include <string.h>
@@ -53,6 +57,43 @@
 #define HN_PITCH   17
 #define HN_ELEMS   (HN_THREADS * HN_G)
 #define HN_E       8                                     // direct taps at either end of the window
+
+// exponent field of 2^1017 = DBL_MAX/128 in the high word of a double (sign stripped): at or above it the
+// unweighted block sums could overflow; infinities and NaNs (exponent 0x7FF) are above it too
+#define HN_HUGE_HI 0x7F800000u
+
+__device__ __forceinline__ uint32_t hann_magnitude_hi (double x)
+	{ return ((uint32_t) (__double_as_longlong (x) >> 32)) & 0x7FFFFFFFu; }
+
+// A tile the block sums must not touch: out[o] = sum_k taps[k] * x[first + o + k], ascending k, one fused
+// multiply-add per tap (what fir_*_kernel<.., FMA> does).  Output o = p + 256*i; results go back into the
+// LDS image like the block-sum results.  Rare (a tile holding inf / NaN / |x| >= 2^1017), so not tuned.
+__device__ __noinline__ void hann_direct_tile (double* lds, const double* __restrict__ taps, int W, int first, int nout)
+	{
+	const int p = threadIdx.x;
+	double acc[HN_G];
+#pragma unroll
+	for (int i=0 ; i<HN_G ; i++) acc[i] = 0.0;
+	for (int k=0 ; k<W ; k++)
+		{
+		const double w = taps[k];
+#pragma unroll
+		for (int i=0 ; i<HN_G ; i++)
+			{
+			int e = first + p + HN_THREADS*i + k;
+			if (e > HN_ELEMS-1) e = HN_ELEMS-1;                    // (outputs past nout are computed and dropped)
+			acc[i] = __builtin_fma (w, lds[e + (e >> 4)], acc[i]);
+			}
+		}
+	__syncthreads ();                                              // every read of the staged inputs is done
+#pragma unroll
+	for (int i=0 ; i<HN_G ; i++)
+		{
+		const int o = p + HN_THREADS*i;
+		if (o < nout) lds[o + (o >> 4)] = acc[i];
+		}
+	__syncthreads ();
+	}
 
 template <int W> struct HannGeom
 	{
@@ -87,11 +128,12 @@ template <int W> struct HannConsts
 template <int W>
 __global__ __launch_bounds__(HN_THREADS)
 void hann_blocks_kernel (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t ntiles,
-                         HannConsts<W> K)
+                         HannConsts<W> K, const double* __restrict__ taps)
 	{
 	typedef HannGeom<W> G;
 	__shared__ __attribute__((aligned(16))) double lds[HN_THREADS * HN_PITCH];
 	__shared__ double tot[3][HN_THREADS];
+	__shared__ __attribute__((aligned(16))) uint32_t huge[HN_THREADS/64];
 
 	const uint32_t tile = gdsp_xcd_tile (blockIdx.x, ntiles);
 	const int64_t  out0 = (int64_t) tile * G::OUT;
@@ -156,21 +198,27 @@ void hann_blocks_kernel (const double* __restrict__ in, double* __restrict__ out
 		{
 		const double* xb = lds + p * HN_PITCH;
 		double a0 = 0.0, ar = 0.0, ai = 0.0;
+		uint32_t big = 0;                                          // largest exponent seen in the own block
 #pragma unroll
 		for (int u=0 ; u<HN_G ; u++)
 			{
 			const double x = xb[u];
+			big = max (big, hann_magnitude_hi (x));
 			a0 += x;
 			ar  = __builtin_fma (x, K.ownC[u], ar);
 			ai  = __builtin_fma (x, K.ownS[u], ai);
 			P0[u] = a0;  Pr[u] = ar;  Pi[u] = ai;
 			}
 		tot[0][p] = a0;  tot[1][p] = ar;  tot[2][p] = ai;
+		const bool any = (__builtin_amdgcn_ballot_w64 (big >= HN_HUGE_HI) != 0);   // the 256 blocks are the whole tile
+		if ((p & 63) == 0) huge[p >> 6] = any? 1u : 0u;
 		}
 	__syncthreads ();
+	const uint4 hg     = *reinterpret_cast<const uint4*> (huge);
+	const bool  direct = ((hg.x | hg.y | hg.z | hg.w) != 0);       // uniform over the workgroup
 
 	// ---- phase 2: the middle stretch of one window per left end
-	if (live)
+	if (live && !direct)
 		{
 		double T0 = 0.0, Tr = 0.0, Ti = 0.0;                       // whole blocks p-NT .. p-1
 #pragma unroll
@@ -216,16 +264,20 @@ void hann_blocks_kernel (const double* __restrict__ in, double* __restrict__ out
 			acc[u] = K.scale * ((z0 - c) + acc[u]);
 			}
 		}
-	__syncthreads ();                                              // every read of the staged inputs is done
-
-	// ---- results back through LDS: output o of the tile belongs to thread HALO_L + o/16
-	if (live)
+	if (direct) hann_direct_tile (lds, taps, W, G::LO, G::OUT);    // (output o sits under taps LO+o .. LO+o+W-1 of the staged elements)
+	else
 		{
-		double* mine = lds + (p - G::HALO_L) * HN_PITCH;
+		__syncthreads ();                                          // every read of the staged inputs is done
+
+		// ---- results back through LDS: output o of the tile belongs to thread HALO_L + o/16
+		if (live)
+			{
+			double* mine = lds + (p - G::HALO_L) * HN_PITCH;
 #pragma unroll
-		for (int u=0 ; u<HN_G ; u++) mine[u] = acc[u];
+			for (int u=0 ; u<HN_G ; u++) mine[u] = acc[u];
+			}
+		__syncthreads ();
 		}
-	__syncthreads ();
 
 	if (out0 + G::OUT <= (int64_t) n)
 		{
@@ -250,7 +302,7 @@ void hann_blocks_kernel (const double* __restrict__ in, double* __restrict__ out
 	}
 
 template <int W>
-static void hann_launch (const double* d_in, double* d_out, uint32_t n, hipStream_t s)
+static void hann_launch (const double* d_in, double* d_out, uint32_t n, const double* d_taps, hipStream_t s)
 	{
 	typedef HannGeom<W> G;
 	HannConsts<W> K;
@@ -275,7 +327,7 @@ static void hann_launch (const double* d_in, double* d_out, uint32_t n, hipStrea
 		}
 	K.scale = 0.5 / total;
 	const uint32_t ntiles = (uint32_t) (((uint64_t) n + G::OUT - 1) / G::OUT);
-	hipLaunchKernelGGL ((hann_blocks_kernel<W>), dim3(ntiles), dim3(HN_THREADS), 0, s, d_in, d_out, n, ntiles, K);
+	hipLaunchKernelGGL ((hann_blocks_kernel<W>), dim3(ntiles), dim3(HN_THREADS), 0, s, d_in, d_out, n, ntiles, K, d_taps);
 	}
 
 // ------------------------------------------------------ any window, 81 .. 2001 ----
@@ -299,11 +351,12 @@ struct HannRT
 template <int E>
 __global__ __launch_bounds__(HN_THREADS)
 void hann_blocks_rt_kernel (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t ntiles,
-                            HannRT K, const double2* __restrict__ rot)
+                            HannRT K, const double2* __restrict__ rot, const double* __restrict__ taps, int W)
 	{
 	constexpr int NEDGE = HN_G + E - 1;
 	__shared__ __attribute__((aligned(16))) double lds[HN_THREADS * HN_PITCH];
 	__shared__ double tot[3][HN_THREADS];
+	__shared__ __attribute__((aligned(16))) uint32_t huge[HN_THREADS/64];
 
 	const uint32_t tile = gdsp_xcd_tile (blockIdx.x, ntiles);
 	const int64_t  out0 = (int64_t) tile * K.OUT;
@@ -367,21 +420,27 @@ void hann_blocks_rt_kernel (const double* __restrict__ in, double* __restrict__ 
 		{
 		const double* xb = lds + p * HN_PITCH;
 		double a0 = 0.0, ar = 0.0, ai = 0.0;
+		uint32_t big = 0;                                          // largest exponent seen in the own block
 #pragma unroll
 		for (int u=0 ; u<HN_G ; u++)
 			{
 			const double x = xb[u];
+			big = max (big, hann_magnitude_hi (x));
 			a0 += x;
 			ar  = __builtin_fma (x, K.ownC[u], ar);
 			ai  = __builtin_fma (x, K.ownS[u], ai);
 			P0[u] = a0;  Pr[u] = ar;  Pi[u] = ai;
 			}
 		tot[0][p] = a0;  tot[1][p] = ar;  tot[2][p] = ai;
+		const bool any = (__builtin_amdgcn_ballot_w64 (big >= HN_HUGE_HI) != 0);   // the 256 blocks are the whole tile
+		if ((p & 63) == 0) huge[p >> 6] = any? 1u : 0u;
 		}
 	__syncthreads ();
+	const uint4 hg     = *reinterpret_cast<const uint4*> (huge);
+	const bool  direct = ((hg.x | hg.y | hg.z | hg.w) != 0);       // uniform over the workgroup
 
 	// ---- phase 2: the middle stretch of one window per left end
-	if (live)
+	if (live && !direct)
 		{
 		double T0 = 0.0, Tr = 0.0, Ti = 0.0;                       // whole blocks p-NT .. p-1
 		for (int d=K.NT ; d>=1 ; d--)
@@ -415,15 +474,19 @@ void hann_blocks_rt_kernel (const double* __restrict__ in, double* __restrict__ 
 				}
 			}
 		}
-	__syncthreads ();
-
-	if (live)
+	if (direct) hann_direct_tile (lds, taps, W, K.LO, K.OUT);
+	else
 		{
-		double* mine = lds + (p - K.HALO_L) * HN_PITCH;
+		__syncthreads ();
+
+		if (live)
+			{
+			double* mine = lds + (p - K.HALO_L) * HN_PITCH;
 #pragma unroll
-		for (int u=0 ; u<HN_G ; u++) mine[u] = acc[u];
+			for (int u=0 ; u<HN_G ; u++) mine[u] = acc[u];
+			}
+		__syncthreads ();
 		}
-	__syncthreads ();
 
 	if (out0 + K.OUT <= (int64_t) n)
 		{
@@ -516,13 +579,16 @@ int gdsp_hann_blocks_apply (const double* d_in, double* d_out, uint32_t n, uint3
 	GDSP_REQUIRE ((d_in != NULL) && (d_out != NULL) && (d_in != d_out), "vectors must be distinct and non-NULL");
 	GDSP_REQUIRE (gdsp_aligned16 (d_in) && gdsp_aligned16 (d_out), "vectors must be 16-byte aligned");
 	hipStream_t s = gdsp_stream (stream);
-	if (W == 101) { hann_launch<101> (d_in, d_out, n, s);  GDSP_LAUNCH_CHECK ();  return GDSP_OK; }
+	const double* d_taps = NULL;                                   // the window as data, for tiles evaluated tap by tap
+	int rc0 = gdsp_smooth_taps_device (W, &d_taps);
+	if (rc0 != GDSP_OK) return rc0;
+	if (W == 101) { hann_launch<101> (d_in, d_out, n, d_taps, s);  GDSP_LAUNCH_CHECK ();  return GDSP_OK; }
 	HannPlanRT* pl = NULL;
 	int rc = hann_plan_rt (W, &pl);
 	if (rc != GDSP_OK) return rc;
 	GDSP_REQUIRE ((pl->K.DQ >= 2) && (pl->K.NT <= HN_RT_MAX_NT) && (pl->K.OUT >= 512) && ((pl->K.LEAD & 1) == 0), "window outside the block-sum kernel's range");
 	const uint32_t ntiles = (uint32_t) (((uint64_t) n + pl->K.OUT - 1) / pl->K.OUT);
-#define HN_RT_LAUNCH(EE) hipLaunchKernelGGL ((hann_blocks_rt_kernel<EE>), dim3(ntiles), dim3(HN_THREADS), 0, s, d_in, d_out, n, ntiles, pl->K, pl->d_rot)
+#define HN_RT_LAUNCH(EE) hipLaunchKernelGGL ((hann_blocks_rt_kernel<EE>), dim3(ntiles), dim3(HN_THREADS), 0, s, d_in, d_out, n, ntiles, pl->K, pl->d_rot, d_taps, (int) W)
 	switch (pl->E)
 		{
 		case 8:  HN_RT_LAUNCH (8);   break;

@@ -183,7 +183,8 @@ static void usage (void)
 	"  --smooth=exact|fma|hann   arithmetic of `smooth`: exact = bit-identical to genodsp\n"
 	"                            (default); fma = fused multiply-add, one rounding per tap;\n"
 	"                            hann = block sums of the window (fastest, same tolerance,\n"
-	"                            not shift invariant: see DESIGN.md)\n"
+	"                            not shift invariant: a smooth feeding localmin/localmax is\n"
+	"                            evaluated as fma instead; see DESIGN.md)\n"
 	"  --percentile=auto|radix|bracket  how `percentile` finds its order statistics (same\n"
 	"                            values either way; auto brackets them from a subsample\n"
 	"                            when the genome is large)\n"

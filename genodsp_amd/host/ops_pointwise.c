@@ -293,4 +293,4 @@ dspop* op_show_variables_parse (char* name, int argc, char** argv)
 void op_show_variables_free (dspop* op) { free (op); }
 
 void op_show_variables_apply (arg_dont_complain(dspop* op), arg_dont_complain(char* vName), arg_dont_complain(u32 vLen), arg_dont_complain(valtype* v))
-	{ report_named_globals (stderr, ""); }
+	{ fprintf (stderr, "variables:\n");  report_named_globals (stderr, "  "); }          /* variables.c:114-122 */

@@ -172,10 +172,19 @@ void op_smooth_free (dspop* op) { free (op); }
 
 u32 op_smooth_window (dspop* op) { return ((dspop_smooth*) op)->windowSize; }
 
+dspprototypes(op_local_minima)  dspprototypes(op_local_maxima)
+
 void op_smooth_apply (dspop* _op, char* vName, u32 vLen, valtype* v)
 	{
 	dspop_smooth* op = (dspop_smooth*) _op;
-	check_gdsp (gdsp_smooth (v, partner_vector (vName), vLen, op->windowSize, firMode, op_stream ()), _op->name);
+	int mode = firMode;
+	/* --smooth=hann is not shift invariant (a flat stretch comes out with last-bit differences), and
+	 * localmin / localmax compare neighbours strictly: a smooth that feeds one of them is evaluated with
+	 * direct taps (fma), fused or not, so the peaks do not depend on --nofuse (ops_fused.c does the same) */
+	if ((mode == GDSP_FIR_HANN) && (_op->next != NULL)
+	 && ((_op->next->funcApply == op_local_maxima_apply) || (_op->next->funcApply == op_local_minima_apply)))
+		mode = GDSP_FIR_FMA;
+	check_gdsp (gdsp_smooth (v, partner_vector (vName), vLen, op->windowSize, mode, op_stream ()), _op->name);
 	flip_vector (vName);                              /* no copy-back pass (sum.c:672-673) */
 	}
 

@@ -33,7 +33,7 @@ extern "C" {
 #define GDSP_FIR_EXACT 0
 #define GDSP_FIR_FMA   1
 /* HANN (gdsp_smooth only) uses what the window is -- tap k = c*(1 - cos(w(k+1))) -- and builds
- * each output from block sums of x and of x*exp(jwe): ~25 operations per base for any tap
+ * each output from block sums of x and of x*exp(jwe): ~45 operations per base for any tap
  * count, additions only (no differences of running sums).  Within W * 2^-52 * sum|w_k v_k| of
  * the reference, like FMA, and no further from the exact value than the reference is.
  * Unlike EXACT and FMA it is not shift invariant (a flat input gives outputs that differ in
