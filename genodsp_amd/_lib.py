@@ -94,6 +94,15 @@ SIGNATURES = {
     "gdsp_percentile_rank": (_u32, [_u32, _u32]),
     "gdsp_percentiles": (_int, [_vp, _int, _u32, _f64, _f64, _vp, _int, _int, _u32, _vp, _vp, _vp, _vp]),
     "gdsp_percentiles_stats": (None, [_vp]),
+    "gdsp_comm_create": (_int, [C.POINTER(_vp), C.POINTER(_int), _int]),
+    "gdsp_comm_destroy": (_int, [_vp]),
+    "gdsp_comm_size": (_int, [_vp]),
+    "gdsp_comm_device": (_int, [_vp, _int]),
+    "gdsp_comm_rccl_version": (_int, [C.POINTER(_int)]),
+    "gdsp_comm_allreduce_u64": (_int, [_vp, C.POINTER(_vp), _sz, _int, C.POINTER(_vp)]),
+    "gdsp_comm_allreduce_f64": (_int, [_vp, C.POINTER(_vp), _sz, _int, C.POINTER(_vp)]),
+    "gdsp_percentiles_use_comm": (_int, [_vp]),
+    "gdsp_percentiles_use_device_reduce": (_int, [_vp, _vp]),
     "gdsp_interval_tile": (_u32, []),
     "gdsp_bin_intervals": (_int, [_u32, _vp, _vp, _u32, _vp, _vp, C.POINTER(_u64)]),
     "gdsp_apply_intervals": (_int, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _int, _int, _f64, _vp]),
@@ -107,7 +116,8 @@ SIGNATURES = {
 }
 
 # functions whose int return is a status code
-_STATUS = {k for k, (r, _) in SIGNATURES.items() if r is _int} - {"gdsp_smooth_local_extrema_fusable"}
+_STATUS = {k for k, (r, _) in SIGNATURES.items() if r is _int} - {"gdsp_smooth_local_extrema_fusable", "gdsp_comm_size",
+                                                                  "gdsp_comm_device"}
 
 
 def lib():

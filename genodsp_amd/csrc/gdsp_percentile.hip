@@ -19,8 +19,16 @@
 // rank that falls outside every bracket (or a candidate list that overflows) sends that
 // percentile through the full radix select, so the result never depends on the sampling.
 // Across GPUs the same decisions are taken everywhere because every count, histogram and flag
-// goes through the caller's reduction (RCCL all-reduce in bench.py; the host adds the devices
-// of one process itself) -- a few KiB per step, the path's only collective.
+// is reduced over all of them -- a few KiB per step, the path's only collective.  Three ways,
+// by who owns the GPUs:
+//   * one process, several devices, a communicator given (gdsp_percentiles_use_comm): the
+//     histograms and counters are all-reduced in place in HBM by RCCL (gdsp_comm.hip) and the
+//     host reads one device's copy -- what `genodsp_hip --gpus=N` does;
+//   * one process per GPU with a device hook (gdsp_percentiles_use_device_reduce): the same
+//     buffers are handed to the caller's collective as device pointers on the stream
+//     (bench.py: torch.distributed over RCCL, no host copy);
+//   * neither: the host adds the copies of this process's devices, then the caller's host hook
+//     (`reduce`) adds across processes (tests over gloo; `--reduce=host`).
 // Traffic: 8 B per sampled base once, against 40 B with five select passes.
 
 #include <math.h>
@@ -281,10 +289,15 @@ struct PcDevice                                               // scratch of one 
 	int       device;
 	uint64_t* hist;       // PC_HIST_WORDS
 	uint64_t* ctr;        // PC_CTR_ALL counters of the counting pass
+	uint64_t* tmp;        // PC_TMP_WORDS: host scalars on their way through a device-side reduction
 	uint64_t* sample;  size_t sampleCap;
 	uint64_t* cand;    size_t candCap;
 	};
+#define PC_TMP_WORDS 64
 static uint64_t   pcStats[6];
+static gdsp_comm*            pcComm    = NULL;                // see gdsp_percentiles_use_comm
+static gdsp_device_reduce_fn pcDReduce = NULL;                // see gdsp_percentiles_use_device_reduce
+static void*                 pcDReduceCtx = NULL;
 static PcDevice   pcDev[64];
 static int        pcDevLen = 0;
 static std::mutex pcLock;
@@ -301,6 +314,7 @@ static int pc_device (int device, size_t sampleCap, size_t candCap, PcDevice** o
 		d->device = device;
 		GDSP_HIP_TRY (hipMalloc ((void**) &d->hist, PC_HIST_WORDS * sizeof(uint64_t)));
 		GDSP_HIP_TRY (hipMalloc ((void**) &d->ctr,  PC_CTR_ALL * sizeof(uint64_t)));
+		GDSP_HIP_TRY (hipMalloc ((void**) &d->tmp,  PC_TMP_WORDS * sizeof(uint64_t)));
 		}
 	if (d->sampleCap < sampleCap)
 		{
@@ -325,7 +339,9 @@ struct PcJob                                                  // one call of gds
 	const gdsp_select_source* src;  int nsrc;
 	uint32_t window;  double lo, hi;
 	gdsp_reduce_fn reduce;  void* ctx;
-	std::vector<int>       devices;                           // distinct devices, in order of first use
+	gdsp_comm* comm;                                          // devices of this process all-reduce in HBM
+	gdsp_device_reduce_fn dreduce;  void* dctx;               // or: the caller's collective on device words
+	std::vector<int>       devices;                           // distinct devices, in order of first use (the communicator's ranks when there is one)
 	std::vector<PcDevice*> scratch;                           // same order
 	std::vector<void*>     stream;                            // a stream of that device (its first source's)
 	std::vector<uint64_t>  sampleCount, candCount;            // per device
@@ -337,6 +353,34 @@ static int pc_reduce (PcJob& J, uint64_t* words, size_t count, int op)
 	{
 	if (J.reduce == NULL) return GDSP_OK;
 	if (J.reduce (J.ctx, words, count, op) != 0) { gdsp_set_error ("gdsp_percentiles: the caller's reduction failed");  return GDSP_EHIP; }
+	return GDSP_OK;
+	}
+
+static bool pc_on_device (const PcJob& J) { return (J.comm != NULL) || (J.dreduce != NULL); }
+
+// all-reduce `count` words in place, in HBM: bufs[d] is device d's copy (J.devices order = communicator ranks)
+static int pc_device_allreduce (PcJob& J, const std::vector<uint64_t*>& bufs, size_t count, int op)
+	{
+	if (J.comm != NULL)
+		return gdsp_comm_allreduce_u64 (J.comm, bufs.data (), count, op, J.stream.data ());
+	GDSP_HIP_TRY (hipSetDevice (J.devices[0]));
+	if (J.dreduce (J.dctx, bufs[0], count, op, J.stream[0]) != 0)
+		{ gdsp_set_error ("gdsp_percentiles: the caller's device reduction failed");  return GDSP_EHIP; }
+	return GDSP_OK;
+	}
+
+// a few host words (already summed over the devices of this process) reduced over ranks
+static int pc_reduce_scalars (PcJob& J, uint64_t* words, size_t count, int op)
+	{
+	if (J.dreduce == NULL) return pc_reduce (J, words, count, op);     // (with a communicator the host sum is already global)
+	GDSP_REQUIRE (count <= PC_TMP_WORDS, "too many scalars");
+	GDSP_HIP_TRY (hipSetDevice (J.devices[0]));
+	hipStream_t s = gdsp_stream (J.stream[0]);
+	GDSP_HIP_TRY (hipMemcpyAsync (J.scratch[0]->tmp, words, count * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+	std::vector<uint64_t*> one (1, J.scratch[0]->tmp);
+	PC_TRY (pc_device_allreduce (J, one, count, op));
+	GDSP_HIP_TRY (hipMemcpyAsync (words, J.scratch[0]->tmp, count * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+	GDSP_HIP_TRY (hipStreamSynchronize (s));
 	return GDSP_OK;
 	}
 
@@ -376,6 +420,24 @@ static int pc_pass (PcJob& J, const PcScope& S, int digit, uint64_t prefix, uint
 				GDSP_LAUNCH_CHECK ();
 				}
 			}
+		}
+	if (pc_on_device (J))
+		{
+		// sum of the bins, then the smallest / largest matching key, all-reduced where they lie; one copy comes back
+		std::vector<uint64_t*> bins (J.devices.size ()), lo (J.devices.size ()), hi (J.devices.size ());
+		for (size_t d=0 ; d<J.devices.size () ; d++)
+			{ bins[d] = J.scratch[d]->hist;  lo[d] = bins[d] + nbins;  hi[d] = bins[d] + nbins + 1; }
+		PC_TRY (pc_device_allreduce (J, bins, nbins, 0));
+		PC_TRY (pc_device_allreduce (J, lo, 1, 1));
+		PC_TRY (pc_device_allreduce (J, hi, 1, 2));
+		GDSP_HIP_TRY (hipSetDevice (J.devices[0]));
+		GDSP_HIP_TRY (hipMemcpyAsync (h, J.scratch[0]->hist, (size_t) (nbins + 2) * sizeof(uint64_t),
+		                              hipMemcpyDeviceToHost, gdsp_stream (J.stream[0])));
+		GDSP_HIP_TRY (hipStreamSynchronize (gdsp_stream (J.stream[0])));
+		if (J.comm != NULL)                                     // the other devices' streams have work queued too
+			for (size_t d=1 ; d<J.devices.size () ; d++)
+				{ GDSP_HIP_TRY (hipSetDevice (J.devices[d]));  GDSP_HIP_TRY (hipStreamSynchronize (gdsp_stream (J.stream[d]))); }
+		return GDSP_OK;
 		}
 	std::vector<uint64_t> part (nbins + 2);
 	for (int b=0 ; b<nbins+2 ; b++) h[b] = 0;
@@ -465,17 +527,37 @@ int gdsp_percentiles (const gdsp_select_source* sources, int nsources, uint32_t 
 
 	PcJob J;
 	J.src = sources;  J.nsrc = nsources;  J.window = window;  J.lo = lo;  J.hi = hi;  J.reduce = reduce;  J.ctx = reduceCtx;
+	J.comm = pcComm;  J.dreduce = pcDReduce;  J.dctx = pcDReduceCtx;
+	GDSP_REQUIRE (!((J.comm != NULL) && (J.dreduce != NULL)), "a communicator and a device reduction hook are both set");
+	GDSP_REQUIRE (!(pc_on_device (J) && (reduce != NULL)), "a host reduction hook next to a device-side reduction");
+	if (J.comm != NULL)                                           // every rank of the communicator takes part, with or without data
+		for (int r=0 ; r<gdsp_comm_size (J.comm) ; r++) { J.devices.push_back (gdsp_comm_device (J.comm, r));  J.stream.push_back (NULL); }
 	uint64_t localPop = 0;
 	for (int i=0 ; i<nsources ; i++)
 		{
 		GDSP_REQUIRE ((sources[i].n == 0) || (sources[i].d_v != NULL), "NULL vector");
 		localPop += ((uint64_t) sources[i].n + window - 1) / window;
-		if (std::find (J.devices.begin (), J.devices.end (), sources[i].device) == J.devices.end ())
-			{ J.devices.push_back (sources[i].device);  J.stream.push_back (sources[i].stream); }
+		auto at = std::find (J.devices.begin (), J.devices.end (), sources[i].device);
+		if (at == J.devices.end ())
+			{
+			GDSP_REQUIRE (J.comm == NULL, "a source lives on a device outside the communicator");
+			J.devices.push_back (sources[i].device);  J.stream.push_back (sources[i].stream);
+			}
+		else if (J.stream[at - J.devices.begin ()] == NULL) J.stream[at - J.devices.begin ()] = sources[i].stream;
 		}
+	GDSP_REQUIRE ((J.dreduce == NULL) || (J.devices.size () <= 1), "the device reduction hook serves one device per process");
 	if (J.devices.empty ()) { J.devices.push_back (homeDevice);  J.stream.push_back (NULL); }   // a rank without data still reduces
 	uint64_t pop = localPop;
-	PC_TRY (pc_reduce (J, &pop, 1, 0));
+	if (J.dreduce != NULL)                                         // its scratch (the staging words) is needed before the first reduction
+		{
+		GDSP_HIP_TRY (hipSetDevice (J.devices[0]));
+		PcDevice* sc = NULL;
+		PC_TRY (pc_device (J.devices[0], 0, 0, &sc));
+		J.scratch.push_back (sc);
+		PC_TRY (pc_reduce_scalars (J, &pop, 1, 0));
+		J.scratch.clear ();
+		}
+	else PC_TRY (pc_reduce (J, &pop, 1, 0));
 
 	// ---- how: brackets need a population worth sampling and pivots that fit the counting kernel
 	const bool bracket = (strategy == GDSP_SELECT_BRACKET)
@@ -628,20 +710,48 @@ int gdsp_percentiles (const gdsp_select_source* sources, int nsources, uint32_t 
 		}
 	const int nb = 2*P.m + 1;
 	std::vector<uint64_t> raw (PC_CTR_WORDS + 2, 0), part (PC_CTR_ALL);   // + padded count, + an overflowed candidate list anywhere
-	for (size_t d=0 ; d<J.devices.size () ; d++)
+	const size_t replicated = (size_t) PC_REPL * PC_CTR_WORDS;    // the candidate count behind them stays per device
+	if (pc_on_device (J))
 		{
-		GDSP_HIP_TRY (hipSetDevice (J.devices[d]));
-		GDSP_HIP_TRY (hipMemcpyAsync (part.data (), J.scratch[d]->ctr, PC_CTR_ALL * sizeof(uint64_t), hipMemcpyDeviceToHost,
-		                              gdsp_stream (J.stream[d])));
-		GDSP_HIP_TRY (hipStreamSynchronize (gdsp_stream (J.stream[d])));
+		std::vector<uint64_t*> ctrs (J.devices.size ());
+		for (size_t d=0 ; d<J.devices.size () ; d++)
+			{
+			GDSP_HIP_TRY (hipSetDevice (J.devices[d]));
+			GDSP_HIP_TRY (hipMemcpyAsync (&J.candCount[d], J.scratch[d]->ctr + replicated, sizeof(uint64_t), hipMemcpyDeviceToHost,
+			                              gdsp_stream (J.stream[d])));
+			ctrs[d] = J.scratch[d]->ctr;
+			}
+		PC_TRY (pc_device_allreduce (J, ctrs, replicated, 0));
+		GDSP_HIP_TRY (hipSetDevice (J.devices[0]));
+		GDSP_HIP_TRY (hipMemcpyAsync (part.data (), J.scratch[0]->ctr, replicated * sizeof(uint64_t), hipMemcpyDeviceToHost,
+		                              gdsp_stream (J.stream[0])));
+		for (size_t d=0 ; d<J.devices.size () ; d++)
+			{ GDSP_HIP_TRY (hipSetDevice (J.devices[d]));  GDSP_HIP_TRY (hipStreamSynchronize (gdsp_stream (J.stream[d]))); }
 		for (int r=0 ; r<PC_REPL ; r++)
 			for (int b=0 ; b<PC_CTR_WORDS ; b++) raw[b] += part[(size_t) r * PC_CTR_WORDS + b];
-		J.candCount[d] = part[(size_t) PC_REPL * PC_CTR_WORDS];
-		if (J.candCount[d] > J.scratch[d]->candCap) { raw[PC_CTR_WORDS + 1] = 1;  J.candCount[d] = J.scratch[d]->candCap; }
+		for (size_t d=0 ; d<J.devices.size () ; d++)
+			{ if (J.candCount[d] > J.scratch[d]->candCap) { raw[PC_CTR_WORDS + 1] = 1;  J.candCount[d] = J.scratch[d]->candCap; } }
+		raw[PC_CTR_WORDS] = padded;
+		PC_TRY (pc_reduce_scalars (J, raw.data () + PC_CTR_WORDS, 1, 0));
+		PC_TRY (pc_reduce_scalars (J, raw.data () + PC_CTR_WORDS + 1, 1, 2));
 		}
-	raw[PC_CTR_WORDS] = padded;
-	PC_TRY (pc_reduce (J, raw.data (), PC_CTR_WORDS + 1, 0));
-	PC_TRY (pc_reduce (J, raw.data () + PC_CTR_WORDS + 1, 1, 2));
+	else
+		{
+		for (size_t d=0 ; d<J.devices.size () ; d++)
+			{
+			GDSP_HIP_TRY (hipSetDevice (J.devices[d]));
+			GDSP_HIP_TRY (hipMemcpyAsync (part.data (), J.scratch[d]->ctr, PC_CTR_ALL * sizeof(uint64_t), hipMemcpyDeviceToHost,
+			                              gdsp_stream (J.stream[d])));
+			GDSP_HIP_TRY (hipStreamSynchronize (gdsp_stream (J.stream[d])));
+			for (int r=0 ; r<PC_REPL ; r++)
+				for (int b=0 ; b<PC_CTR_WORDS ; b++) raw[b] += part[(size_t) r * PC_CTR_WORDS + b];
+			J.candCount[d] = part[replicated];
+			if (J.candCount[d] > J.scratch[d]->candCap) { raw[PC_CTR_WORDS + 1] = 1;  J.candCount[d] = J.scratch[d]->candCap; }
+			}
+		raw[PC_CTR_WORDS] = padded;
+		PC_TRY (pc_reduce (J, raw.data (), PC_CTR_WORDS + 1, 0));
+		PC_TRY (pc_reduce (J, raw.data () + PC_CTR_WORDS + 1, 1, 2));
+		}
 	const bool overflow = (raw[PC_CTR_WORDS + 1] != 0);
 	// counts within the population (see the kernel's header): every "above" loses what lies above hi
 	const uint64_t nans  = raw[PC_CTR_NANPOS] + raw[PC_CTR_NANNEG];
@@ -705,6 +815,21 @@ int gdsp_percentiles (const gdsp_select_source* sources, int nsources, uint32_t 
 		rc = pc_radix (J, pThousandths, fallback, values, &again);
 		}
 	return finish (rc);
+	}
+
+// how the devices' counts are combined from now on (see the head of this file); NULL = on the host
+int gdsp_percentiles_use_comm (gdsp_comm* comm)
+	{
+	std::lock_guard<std::mutex> hold (pcLock);
+	pcComm = comm;
+	return GDSP_OK;
+	}
+
+int gdsp_percentiles_use_device_reduce (gdsp_device_reduce_fn fn, void* ctx)
+	{
+	std::lock_guard<std::mutex> hold (pcLock);
+	pcDReduce = fn;  pcDReduceCtx = ctx;
+	return GDSP_OK;
 	}
 
 void gdsp_percentiles_stats (uint64_t out[6])

@@ -124,6 +124,9 @@ static int numDevices     = 1;
 int        firMode        = GDSP_FIR_EXACT;      /* --smooth=exact|fma|hann (see ops_sum.c) */
 int        selectStrategy = GDSP_SELECT_AUTO;    /* --percentile=auto|radix|bracket (see ops_percentile.c) */
 static int fuseChains     = true;                /* --nofuse: one kernel per operator          */
+enum { reduce_auto, reduce_rccl, reduce_host };
+static int reduceHow      = reduce_auto;         /* --reduce=rccl|host: how whole-genome operators combine the devices */
+static gdsp_comm* deviceComm = NULL;             /* RCCL communicator over the devices in use (NULL: host sums)        */
 
 /* a chromosome as the driver sees it: the public spec first, device state after */
 typedef struct xspec
@@ -178,6 +181,8 @@ static void usage (void)
 	"  --nooutput                do not write the resulting signal\n"
 	"  --window=<length>         (W=) default window size for windowed operators\n"
 	"  --gpus=<n>                shard whole chromosomes over n GPUs (default 1)\n"
+	"  --reduce=rccl|host        how percentile / invert combine the GPUs' counts: an RCCL all-reduce in\n"
+	"                            HBM (default with --gpus > 1) or sums on the host\n"
 	"  --nofuse                  run every operator as its own kernel (default: the chains\n"
 	"                            smooth=localmax|localmin and dilate=erode[=binarize] are fused)\n"
 	"  --smooth=exact|fma|hann   arithmetic of `smooth`: exact = bit-identical to genodsp\n"
@@ -481,7 +486,77 @@ void sync_all_devices (void)
 	check_gdsp (use_device (currentDevice), "select device");
 	}
 
-gdsp_reduce_fn reduce_over_devices (void** ctx) { *ctx = NULL;  return NULL; }
+/* ---- the one collective: percentile's counts and invert's extremes over the devices in use.
+ * One process drives all GPUs, so the communicator is RCCL's single-process clique (ncclCommInitAll inside
+ * gdsp_comm_create) and the all-reduces run in HBM on each device's stream.  --reduce=host keeps the sums on the
+ * host instead; that is also what happens when shards share a GPU (GDSP_OVERSUBSCRIBE_GPUS: RCCL wants one
+ * rank per GPU) and, by default, with a single device (nothing to reduce; --reduce=rccl still goes through a
+ * one-rank communicator, which is how the one-GPU test box exercises this path). */
+static void create_device_comm (void)
+	{
+	int wantRccl = (reduceHow == reduce_rccl) || ((reduceHow == reduce_auto) && (numDevices > 1));
+	if (!wantRccl) return;
+	if (numDevices > physicalDevices)
+		{
+		if (reduceHow == reduce_rccl)
+			{ fprintf (stderr, "[%s] --reduce=rccl needs one GPU per shard (%d shards, %d GPUs)\n", programName, numDevices, physicalDevices);  exit (EXIT_FAILURE); }
+		return;
+		}
+	int devices[64];
+	for (int d=0 ; d<numDevices ; d++) devices[d] = d % physicalDevices;
+	check_gdsp (gdsp_comm_create (&deviceComm, devices, numDevices), "create the RCCL communicator");
+	check_gdsp (gdsp_percentiles_use_comm (deviceComm), "hand the communicator to percentile");
+	if (trackOperations)
+		{
+		int version = 0;
+		check_gdsp (gdsp_comm_rccl_version (&version), "RCCL version");
+		fprintf (stderr, "reduce(rccl %d over %d device%s)\n", version, numDevices, (numDevices == 1)? "" : "s");
+		}
+	}
+
+gdsp_reduce_fn reduce_over_devices (void** ctx) { *ctx = NULL;  return NULL; }   /* (the communicator, when there is one, is inside the library) */
+
+/* smallest and largest value of the whole genome (invert, add.c:909-923): every device folds its chromosomes into
+ * three doubles of its own, the devices' results meet in an RCCL all-reduce (min / max) or on the host */
+void genome_extremes (valtype* lo, valtype* hi)
+	{
+	static valtype* acc[64];
+	valtype*        accs[64];
+	void*           streams[64];
+	for (int d=0 ; d<numDevices ; d++)
+		{
+		check_gdsp (use_device (d), "select device");
+		if (acc[d] == NULL) check_gdsp (gdsp_malloc ((void**) &acc[d], 4 * sizeof(valtype)), "allocate accumulators");
+		check_gdsp (gdsp_minmax_init (acc[d], devs[d].stream), "genome extremes");
+		accs[d] = acc[d];  streams[d] = devs[d].stream;
+		}
+	for (int i=0 ; chromsSorted[i]!=NULL ; i++)
+		{
+		spec* s = chromsSorted[i];
+		int   d = ((xspec*) s)->device;
+		check_gdsp (use_device (d), "select device");
+		check_gdsp (gdsp_minmax_update (s->valVector, s->length, 1, -DBL_MAX, DBL_MAX, acc[d], devs[d].stream), "genome extremes");
+		}
+	*lo = DBL_MAX;  *hi = -DBL_MAX;
+	if (deviceComm != NULL)
+		{
+		valtype* his[64];
+		for (int d=0 ; d<numDevices ; d++) his[d] = accs[d] + 1;
+		check_gdsp (gdsp_comm_allreduce_f64 (deviceComm, accs, 1, /*min*/ 1, streams), "all-reduce the minimum");
+		check_gdsp (gdsp_comm_allreduce_f64 (deviceComm, his,  1, /*max*/ 2, streams), "all-reduce the maximum");
+		}
+	for (int d=0 ; d<numDevices ; d++)
+		{
+		valtype r[3];
+		check_gdsp (use_device (d), "select device");
+		check_gdsp (gdsp_memcpy_d2h (r, acc[d], sizeof(r), devs[d].stream), "fetch extremes");
+		check_gdsp (gdsp_stream_sync (devs[d].stream), "synchronise");
+		if ((deviceComm != NULL) && (d > 0)) continue;                 /* device 0 holds the reduced pair already */
+		if (r[0] < *lo) *lo = r[0];
+		if (r[1] > *hi) *hi = r[1];
+		}
+	check_gdsp (use_device (currentDevice), "select device");
+	}
 
 int device_count_in_use (void) { return numDevices; }
 int device_index_of (spec* s)  { return ((xspec*) s)->device; }
@@ -1052,6 +1127,8 @@ static void parse_options (int _argc, char** _argv)            /* genodsp.c:284-
 			continue;
 			}
 		if (strcmp (arg, "--nofuse") == 0) { fuseChains = false;  continue; }
+		if (strcmp (arg, "--reduce=rccl") == 0) { reduceHow = reduce_rccl;  continue; }
+		if (strcmp (arg, "--reduce=host") == 0) { reduceHow = reduce_host;  continue; }
 		if (strcmp (arg, "--smooth=exact") == 0) { firMode = GDSP_FIR_EXACT;  continue; }
 		if (strcmp (arg, "--smooth=fma")   == 0) { firMode = GDSP_FIR_FMA;    continue; }
 		if (strcmp (arg, "--smooth=hann")  == 0) { firMode = GDSP_FIR_HANN;   continue; }
@@ -1133,6 +1210,7 @@ int main (int argc, char** argv)
 
 	sort_chromosomes_by_length ();
 	allocate_vectors ();
+	create_device_comm ();
 
 	/* stdin is the signal unless the first operator is `input` (genodsp.c:891-893) */
 	if ((pipeline == NULL) || (strcmp (pipeline->name, "input") != 0))
@@ -1181,5 +1259,6 @@ int main (int argc, char** argv)
 
 	for (dspop* op=pipeline, *next ; op!=NULL ; op=next)
 		{ next = op->next;  free (op->name);  (*op->funcFree) (op); }
+	if (deviceComm != NULL) { gdsp_percentiles_use_comm (NULL);  gdsp_comm_destroy (deviceComm); }
 	return EXIT_SUCCESS;
 	}

@@ -22,6 +22,7 @@ void sync_all_devices    (void);
 /* how whole-genome operators (percentile, invert) combine what the devices of this process found: the
  * reduction hook for gdsp_percentiles (NULL: the library adds its devices' counts on the host) */
 gdsp_reduce_fn reduce_over_devices (void** ctx);
+void genome_extremes (valtype* lo, valtype* hi);     /* min / max of the whole genome over all devices (invert) */
 u64   ib_batch_limit (void);                   /* intervals buffered before they are applied (8 M; GDSP_BATCH_INTERVALS) */
 void* device_workspace (size_t bytes);         /* per-device, grows on demand, kept for the run */
 void* long_window_workspace (size_t* bytes);   /* lazily allocated, for windows beyond one LDS tile */

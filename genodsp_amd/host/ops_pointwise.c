@@ -250,20 +250,8 @@ void op_invert_apply (dspop* _op, arg_dont_complain(char* vName), arg_dont_compl
 	valtype mid = op->midVal;
 	if (!op->haveMidVal)
 		{
-		valtype  lo = DBL_MAX, hi = -DBL_MAX;
-		for (int i=0 ; chromsSorted[i]!=NULL ; i++)
-			{
-			spec* s = chromsSorted[i];
-			select_device_of (s);
-			valtype* a = get_scratch_vector ();          /* 3 doubles used */
-			check_gdsp (gdsp_minmax_init (a, op_stream ()), _op->name);
-			check_gdsp (gdsp_minmax_update (s->valVector, s->length, 1, -DBL_MAX, DBL_MAX, a, op_stream ()), _op->name);
-			valtype r[3];
-			check_gdsp (gdsp_memcpy_d2h (r, a, sizeof(r), op_stream ()), _op->name);
-			check_gdsp (gdsp_stream_sync (op_stream ()), _op->name);
-			release_scratch_vector (a);
-			if (r[2] > 0) { if (r[0] < lo) lo = r[0];  if (r[1] > hi) hi = r[1]; }
-			}
+		valtype lo, hi;
+		genome_extremes (&lo, &hi);                          /* add.c:909-923, over every device */
 		mid = (lo + hi) / 2.0;                               /* add.c:925 */
 		}
 	for (int i=0 ; chromsSorted[i]!=NULL ; i++)

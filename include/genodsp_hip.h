@@ -221,6 +221,29 @@ typedef int (*gdsp_reduce_fn) (void* ctx, uint64_t* words, size_t count, int op)
 int gdsp_percentiles (const gdsp_select_source* sources, int nsources, uint32_t window, double lo, double hi,
                       const uint32_t* pThousandths, int npercentiles, int strategy, uint32_t sampleTarget,
                       gdsp_reduce_fn reduce, void* reduceCtx, double* values, uint64_t* count);
+/* The path's only collective (gdsp_comm.hip): all-reduce of the counters across the GPUs of one node, RCCL over
+ * xGMI.  One process drives several devices: gdsp_comm_create makes one RCCL communicator per device
+ * (ncclCommInitAll; RCCL is dlopen'ed on first use, a one-GPU run never loads it) and the all-reduces run in place
+ * on d_bufs[rank] -- rank r is devices[r] -- on streams[rank] (NULL: that device's default stream).  op: 0 sum,
+ * 1 min, 2 max.  Replaces, for chromosomes dealt over GPUs, what the reference's single thread sees at once:
+ * percentile.c:547-683 (the sort of the sampled genome), add.c:909-923 (invert's global min / max). */
+typedef struct gdsp_comm gdsp_comm;
+int gdsp_comm_create        (gdsp_comm** comm, const int* devices, int ndevices);
+int gdsp_comm_destroy       (gdsp_comm* comm);
+int gdsp_comm_size          (const gdsp_comm* comm);
+int gdsp_comm_device        (const gdsp_comm* comm, int rank);
+int gdsp_comm_rccl_version  (int* version);
+int gdsp_comm_allreduce_u64 (gdsp_comm* comm, uint64_t* const* d_bufs, size_t count, int op, void* const* streams);
+int gdsp_comm_allreduce_f64 (gdsp_comm* comm, double* const* d_bufs, size_t count, int op, void* const* streams);
+/* gdsp_percentiles over the devices of THIS process: all-reduce its histograms and counters in HBM through `comm`
+ * (whose devices must be the sources' devices) instead of adding host copies; NULL switches back. */
+int gdsp_percentiles_use_comm (gdsp_comm* comm);
+/* gdsp_percentiles with one process per GPU: hand every buffer to be reduced to the caller as DEVICE words on the
+ * stream the counts were produced on (the caller runs its collective there, e.g. torch.distributed over RCCL, and
+ * returns 0); NULL switches back to the host hook of gdsp_percentiles.  op as above. */
+typedef int (*gdsp_device_reduce_fn) (void* ctx, uint64_t* d_words, size_t count, int op, void* stream);
+int gdsp_percentiles_use_device_reduce (gdsp_device_reduce_fn fn, void* ctx);
+
 /* what the last gdsp_percentiles call of this process did: [0] route taken (GDSP_SELECT_RADIX or
  * _BRACKET), [1] population, [2] subsample size, [3] candidates kept on this rank, [4] percentiles
  * that fell back to the radix route, [5] histogram passes over the population */

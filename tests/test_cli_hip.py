@@ -181,6 +181,35 @@ def test_sharded_driver_gives_the_same_output(tmp_path, monkeypatch):
     assert outs[0] == outs[1]
 
 
+def test_rccl_communicator_reduces_percentile_and_invert(tmp_path):
+    """--reduce=rccl: percentile's histograms / counters and invert's extremes go through ncclCommInitAll +
+    ncclAllReduce (gdsp_comm.hip) even with one device, so communicator creation and the u64 sum / min / max and
+    f64 min / max all-reduces run on the one-GPU test box; values and output equal the host-sum path's."""
+    chroms = "".join("chr%d %d\n" % (i, 30000 + 7000 * i) for i in range(5))
+    import numpy as np
+    rng = np.random.default_rng(14)
+    lines = []
+    for i in range(5):
+        n = 30000 + 7000 * i
+        for _ in range(1500):
+            a = int(rng.integers(0, n - 90))
+            lines.append("chr%d %d %d %.3f" % (i, a, a + int(rng.integers(1, 90)), rng.random() * 7 - 2))
+    iv = "\n".join(lines) + "\n"
+    got = {}
+    for how in ("host", "rccl"):
+        for route in ("radix", "bracket"):
+            rc, out, err = run(["--precision=12", "--reduce=" + how, "--percentile=" + route, "--progress=operations",
+                                "=", "percentile", "5..95by15", "--min=-1", "=", "clip", "--max=percentile80", "=", "invert",
+                                "=", "percentile", "0,100", "=", "variables"], iv, chroms, tmp_path)
+            assert rc == 0, err
+            assert ("reduce(rccl" in err) == (how == "rccl"), err
+            got[how, route] = (out, [l for l in err.splitlines() if "percentile" in l and "(" not in l])
+    assert len(got["host", "radix"][1]) >= 9
+    assert got["host", "radix"] == got["rccl", "radix"] == got["host", "bracket"] == got["rccl", "bracket"]
+    rc, out, err = run(["--gpus=2", "--reduce=rccl"], "", "chr1 100\n", tmp_path)
+    assert rc != 0                                   # one GPU here: two shards need two GPUs (or GDSP_OVERSUBSCRIBE_GPUS + host sums)
+
+
 def test_smooth_arithmetic_modes_on_the_command_line(tmp_path):
     """--smooth=exact (default) prints the reference's digits; fma and hann are within one rounding per
     operation, far below what --precision=9 shows on this signal."""
