@@ -4,6 +4,7 @@
 across ranks (LPT, no data-path collective).
 
     python bench.py                                  # 1 GPU
+    python bench.py --gpus N                         # starts N ranks itself (torch.distributed.run), relays rank 0's line
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -33,10 +34,20 @@ GENOME = [("chr1", 248956422), ("chr2", 242193529), ("chr3", 198295559), ("chr4"
           ("chr17", 83257441), ("chr18", 80373285), ("chr19", 58617616), ("chr20", 64444167),
           ("chr21", 46709983), ("chr22", 50818468), ("chrX", 156040895), ("chrY", 57227415)]
 SEED = 20240611
+SAMPLE_ONE_CORE = ["chr17", "chr18", "chr19", "chr20", "chr21", "chr22", "chrY"]      # 441 Mbp: ~12 s of one core
 WINDOW = 101
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_VALU_PEAK_TFLOPS = 78.6     # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 BYTES_PER_BASE = 16              # 8 B read + 8 B write per base for smooth
+ARITHMETIC = {"hann": "hann (block sums of the window's constant and cosine parts; within one rounding per floating-point "
+                      "operation of the reference, not bit-identical; opt-in --smooth=hann of the driver)",
+              "fma": "fma (direct taps, one fused multiply-add each; within one rounding per operation; --smooth=fma)",
+              "exact": "exact (direct taps, multiply then add: bit-identical to the reference; the driver's default)"}
+WORKLOAD_KERNELS = {
+    "peaks": {"fused": ["fir_fixed_extrema_kernel<101,9,FMA,true>"],
+              "nofuse": ["fir_fixed_kernel<101,9,FMA>", "extrema_blocks_kernel"]},
+    "morph": {"fused": ["morph_dilate_erode_kernel"], "nofuse": ["extrema_blocks_kernel", "pointwise_kernel"]},
+    "percentile": {"fused": ["pc_partition_kernel", "pointwise_kernel"], "nofuse": ["pc_partition_kernel", "pointwise_kernel"]}}
 KERNELS = {"hann": "hann_blocks_kernel<101>", "fma": "fir_fixed_kernel<101,9,true>",
            "exact": "fir_fixed_kernel<101,9,false>"}
 
@@ -56,6 +67,9 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="debugging: every rank uses GPU 0 and the gloo backend, to exercise the N>1 code path "
                          "where only one GPU exists (numbers from such a run mean nothing)")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="initialise torch.distributed (nccl = RCCL) even with one rank, so that the reductions of the "
+                         "percentile workload run as RCCL all-reduces on device words at world size 1 (tests)")
     ap.add_argument("--nofuse", action="store_true", help="peaks/morph workloads: one kernel per operator")
     ap.add_argument("--sharding", choices=["chromosomes", "bases"], default="chromosomes",
                     help="chromosomes = whole chromosomes dealt longest-first over the ranks (BASELINE's sharding, the "
@@ -66,6 +80,10 @@ def main():
                          "reported in the same shape for DESIGN.md, never the driver's number")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # invoked plainly: start one fresh rank per GPU and relay rank 0's JSON line.  Nothing in THIS process has
+        # touched HIP or torch (a process that has must never exec or be re-used as a rank), and it never does.
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -80,7 +98,7 @@ def main():
     gd.set_device(device_index)
     dist = None
     reduce_device = "cuda"
-    if world > 1:
+    if world > 1 or args.force_collectives:
         import torch.distributed as dist
         if args.rehearse_on_one_gpu:
             dist.init_process_group(backend="gloo")
@@ -169,6 +187,7 @@ def main():
         r = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(achieved / HBM_PEAK_GBS, 4),
              "traffic": measured_traffic(kernel, BYTES_PER_BASE * bases_rank / launches),
+             "traffic_measured": traffic_source(kernel),
              "kernel": kernel, "avg_launch_ms": round(avg_launch_ms, 4),
              "launches_per_step": launches,
              "algorithmic_bytes_per_launch": int(BYTES_PER_BASE * bases_rank / launches)}
@@ -189,9 +208,10 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": "smooth W=101 on 24-chrom 3.1 Gbp synthetic signal (BASELINE configs[1])",
+        "config": {"workload": "smooth W=101 on 24-chrom 3.1 Gbp synthetic signal (BASELINE configs[1]); arithmetic of `value`: "
+                               + ARITHMETIC[args.mode] + "; the other two arithmetics are in other_modes",
                    "window": WINDOW, "chromosomes": len(GENOME), "bases": total_bases,
-                   "fir_mode": args.mode,
+                   "fir_mode": args.mode, "library": gd.lib().gdsp_version().decode(),
                    "sharding": "whole chromosomes, LPT over ranks" if args.sharding == "chromosomes"
                                else "equal stretches of the concatenated genome, pieces with a half-window halo",
                    "signal": "read-depth-like x U(0.5,1.5), seed %d" % SEED},
@@ -208,6 +228,23 @@ def main():
         print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def self_launch(n):
+    """python bench.py --gpus N outside a launcher: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a child and exit with its code; the
+    ranks' stdout (rank 0's JSON line) and stderr are inherited."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def shard_pieces(lengths, world, sharding, lpt_shards):
@@ -266,19 +303,34 @@ def other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_base
         name, bytes_per_base = "percentile 99 = binarize --threshold=percentile99", 24
         for i in mine:
             gd.call("gdsp_memcpy_d2d", tmp[i].ptr, vin[i].ptr, lengths[i] * 8, gd._sp(S))
-        allreduce = None
+        device_allreduce = None
         if dist is not None:
-            def allreduce(arr, op):       # RCCL: the path's only collective (<= 64 KiB per select pass)
-                if op == "sum":
-                    t = torch.from_numpy(arr.view(np.int64).copy()).to(reduce_device)
-                    dist.all_reduce(t)
-                    return t.cpu().numpy().view(np.uint64)
-                t = torch.from_numpy((arr ^ np.uint64(1 << 63)).view(np.int64).copy()).to(reduce_device)
-                dist.all_reduce(t, op=dist.ReduceOp.MIN if op == "min" else dist.ReduceOp.MAX)
-                return t.cpu().numpy().view(np.uint64) ^ np.uint64(1 << 63)
+            # the path's only collective, on the words where the library left them in HBM: the device address is
+            # wrapped as a torch tensor (no copy) and all-reduced by RCCL on the library's own stream
+            class _Words:
+                def __init__(self, ptr, count):
+                    self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
+
+            TOP = -(1 << 63)                 # u64 order as i64 order: flip the top bit around a min / max
+
+            def device_allreduce(ptr, count, op, stream_handle):
+                ext = torch.cuda.ExternalStream(int(stream_handle)) if stream_handle else torch.cuda.current_stream()
+                with torch.cuda.stream(ext):
+                    t = torch.as_tensor(_Words(ptr, count), device="cuda")
+                    if op != "sum":
+                        t.bitwise_xor_(TOP)
+                    how = {"sum": dist.ReduceOp.SUM, "min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX}[op]
+                    if reduce_device == "cpu":           # one-GPU rehearsal over gloo: the only case with a host hop
+                        h = t.cpu()
+                        dist.all_reduce(h, op=how)
+                        t.copy_(h)
+                    else:
+                        dist.all_reduce(t, op=how)
+                    if op != "sum":
+                        t.bitwise_xor_(TOP)
 
         def step(_):
-            cnt, vals = gd.percentile([vin[i] for i in mine], [99000], allreduce=allreduce, stream=S)
+            cnt, vals = gd.percentile([vin[i] for i in mine], [99000], device_allreduce=device_allreduce, stream=S)
             extra["percentile99"], extra["sampled"] = vals[0], cnt
             st = gd.percentile_stats()
             extra["percentile_route"] = {gd.SELECT_RADIX: "radix", gd.SELECT_BRACKET: "bracket"}.get(st["route"])
@@ -287,22 +339,33 @@ def other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_base
                 gd.binarize(tmp[i], vals[0], stream=S)
     wall_ms, dev_ms = timed_fn(None, args.steps, args.warmup, step=step)
     bases_rank = max(sum(lengths[i] for i in sh) for sh in gd.lpt_shards(lengths, world))
-    achieved = bytes_per_base * bases_rank / (dev_ms * 1e-3) / 1e9
+    moved_per_base = 16 if (args.workload in ("peaks", "morph") and not args.nofuse) else bytes_per_base
+    achieved = moved_per_base * bases_rank / (dev_ms * 1e-3) / 1e9            # bytes that actually cross HBM
+    credited = bytes_per_base * bases_rank / (dev_ms * 1e-3) / 1e9            # 16 B per operator executed
+    kernels = WORKLOAD_KERNELS[args.workload]["nofuse" if args.nofuse else "fused"]
+    if args.workload == "peaks":
+        kernels = [k.replace("FMA", "false" if args.mode == "exact" else "true") for k in kernels]
     result = {"metric": "Gbases/sec on %s over 3.1 Gbp" % name, "value": round(total_bases / (wall_ms * 1e-3) / 1e9, 2),
               "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
               "ms_per_step": round(wall_ms, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
               "dtype": "f64", "data": "synthetic",
               "config": {"workload": name + " on 24-chrom 3.1 Gbp synthetic signal", "bases": total_bases,
                          "fir_mode": "exact" if args.mode == "exact" else "fma", "fused": not args.nofuse,
+                         "library": gd.lib().gdsp_version().decode(),
+                         "collectives": (None if dist is None else "gloo, host copy (one-GPU rehearsal)" if reduce_device == "cpu"
+                                         else "rccl (torch.distributed nccl backend), device words"),
                          "sharding": "whole chromosomes, LPT over ranks"},
               "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                           "algorithmic_bytes_per_base": bytes_per_base,
-                           "hbm_bytes_per_base_moved": (16 if (args.workload in ("peaks", "morph") and not args.nofuse)
-                                                        else bytes_per_base),
-                           "note": "credited as SURVEY 8(d) credits it: 16 B per operator executed (8 B for the percentile "
-                                   "pass), whether or not the chain is fused; a fused chain moves 16 B/base in all, so its "
-                                   "achieved figure can exceed what HBM delivers"}}
+                           "frac": round(achieved / HBM_PEAK_GBS, 4),
+                           "traffic": measured_traffic(kernels[0], moved_per_base * bases_rank / max(1, len(mine))),
+                           "traffic_measured": traffic_source(kernels[0]),
+                           "kernels": kernels,
+                           "hbm_bytes_per_base_moved": moved_per_base,
+                           "credited_by_survey_8d": {"bytes_per_base": bytes_per_base, "achieved": round(credited, 1),
+                                                     "frac": round(credited / HBM_PEAK_GBS, 4)},
+                           "note": "achieved / frac count the bytes that cross HBM (a fused chain moves 16 B/base in all); "
+                                   "credited_by_survey_8d counts 16 B per operator executed (8 B for the percentile pass), "
+                                   "fused or not, and may therefore exceed what HBM delivers"}}
     result.update(extra)
     if rank == 0:
         print(json.dumps(result))
@@ -318,6 +381,16 @@ def measured_traffic(kernel, algorithmic_bytes_per_launch):
     with open(path) as f:
         ratio = json.load(f).get("kernels", {}).get(kernel, {}).get("hbm_bytes_over_algorithmic")
     return None if ratio is None else int(ratio * algorithmic_bytes_per_launch)
+
+
+def traffic_source(kernel):
+    """which rocprofv3 PMC run (and library build) the traffic ratio of `kernel` comes from: a stale ratio shows here"""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        k = json.load(f).get("kernels", {}).get(kernel)
+    return None if k is None else {"source": k.get("source"), "library": k.get("library")}
 
 
 def spot_check(gd, vin, vout, pieces, held, lengths, stream):
@@ -360,10 +433,10 @@ def spot_check(gd, vin, vout, pieces, held, lengths, stream):
 
 
 def cpu_baseline(gd, lengths, names, stream):
-    """Time the CPU path on a bounded sample: smooth W=101 over chr21 + chr22 (97.5 Mbp at
-    full scale), one thread, the same synthetic signal copied back from HBM."""
+    """Time the CPU path on a bounded sample: smooth W=101 over chr17..chr22 + chrY (441 Mbp at full scale,
+    about 12 s of one core), one thread, the same synthetic signal copied back from HBM."""
     from oracle import cpu, ref
-    sample = [names.index("chr21"), names.index("chr22")]
+    sample = [names.index(c) for c in SAMPLE_ONE_CORE]
     vecs = {}
     for i in sample:
         d = gd.synth_coverage(SEED, i, 0, lengths[i], mode=1, stream=stream.handle)
@@ -392,8 +465,8 @@ def cpu_baseline(gd, lengths, names, stream):
         got = gd.smooth(d, WINDOW, mode=gd.FIR_EXACT, stream=stream.handle).numpy()
         same = same and (got.tobytes() == outs[i].tobytes())
     return {"value": round(bases / dt / 1e9, 5), "unit": "Gbases/s", "cores": 1, "kind": kind,
-            "sample": "smooth W=101 on chr21+chr22 (%d bases) of the same synthetic signal, %.1f s"
-                      % (bases, dt),
+            "sample": "smooth W=101 on %s..%s+%s (%d bases) of the same synthetic signal, %.1f s"
+                      % (SAMPLE_ONE_CORE[0], SAMPLE_ONE_CORE[-2], SAMPLE_ONE_CORE[-1], bases, dt),
             "hip_exact_bit_identical_on_sample": bool(same)}
 
 
@@ -403,9 +476,11 @@ def cpu_baseline_all_cores(gd, lengths, names, stream):
     beside the single-threaded reference, never instead of it."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import cpu
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = min(cores, int(os.environ.get("GDSP_HOST_CORES", "16")))     # a one-GPU share of the node's host cores
-    sample = [names.index(c) for c in ("chr19", "chr20", "chr21", "chr22", "chrY")]
+    nproc = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else nproc     # what `nproc` prints
+    if os.environ.get("GDSP_HOST_CORES"):
+        cores = min(cores, int(os.environ["GDSP_HOST_CORES"]))
+    sample = [names.index(c) for c in ("chr13", "chr14", "chr15", "chr16", "chr17", "chr18", "chr19", "chr20", "chr21", "chr22", "chrY")]
     half = (WINDOW - 1) // 2
     jobs = []
     for i in sample:
@@ -419,10 +494,13 @@ def cpu_baseline_all_cores(gd, lengths, names, stream):
     bases = sum(lengths[i] for i in sample)
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=cores) as pool:
-        list(pool.map(lambda x: cpu.smooth(x, WINDOW), jobs))
+        list(pool.map(lambda x: cpu.smooth(x, WINDOW).size, jobs))          # (results are dropped as they come)
     dt = time.perf_counter() - t0
     return {"value": round(bases / dt / 1e9, 5), "unit": "Gbases/s", "cores": cores, "kind": "port",
-            "sample": "smooth W=101 on chr19-22+chrY (%d bases) cut into %d stretches, %.1f s" % (bases, len(jobs), dt)}
+            "host_logical_cpus": nproc, "usable_by_this_process": cores,
+            "sample": "smooth W=101 on chr13..chr22+chrY (%d bases) cut into %d stretches over %d threads (every core this "
+                      "process may use; kind \"port\" = the CPU restatement, the reference itself is single-threaded), %.1f s"
+                      % (bases, len(jobs), cores, dt)}
 
 
 if __name__ == "__main__":

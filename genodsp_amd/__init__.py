@@ -430,14 +430,18 @@ class SelectSource(C.Structure):
 
 
 REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, C.c_int)
+DEVICE_REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
 SELECT_AUTO, SELECT_RADIX, SELECT_BRACKET = 0, 1, 2
 
 
 def percentile(vecs, p_thousandths, window=1, lo=-DBL_MAX, hi=DBL_MAX, allreduce=None, stream=None,
-               strategy=SELECT_AUTO, sample_target=0):
+               strategy=SELECT_AUTO, sample_target=0, device_allreduce=None):
     """Exact percentiles of the sampled genome (percentile.c:392-751), non-destructive: gdsp_percentiles.
-    vecs: this rank's chromosome vectors (current device); allreduce(np.uint64 array, "sum"|"min"|"max")
-    -> the reduction over ranks (None: one rank).  Returns (count, [values])."""
+    vecs: this rank's chromosome vectors (current device).  Across ranks, one of
+      device_allreduce(ptr, count, "sum"|"min"|"max", stream): all-reduce `count` u64 words at DEVICE address `ptr`
+        in place, ordered on `stream` (RCCL through torch.distributed in bench.py: nothing leaves HBM);
+      allreduce(np.uint64 array, op) -> the reduced array (host words; the gloo tests).
+    Returns (count, [values])."""
     device = current_device()
     src = (SelectSource * max(1, len(vecs)))()
     for i, v in enumerate(vecs):
@@ -456,17 +460,60 @@ def percentile(vecs, p_thousandths, window=1, lo=-DBL_MAX, hi=DBL_MAX, allreduce
             failure.append(e)
             return 1
 
+    def device_reduce(_ctx, d_words, n, op, s):
+        try:
+            device_allreduce(d_words, n, ("sum", "min", "max")[op], s)
+            return 0
+        except Exception as e:
+            failure.append(e)
+            return 1
+
+    assert allreduce is None or device_allreduce is None
     cb = REDUCE_FN(reduce) if allreduce is not None else C.cast(None, REDUCE_FN)
+    dcb = DEVICE_REDUCE_FN(device_reduce) if device_allreduce is not None else None
     try:
+        if dcb is not None:
+            call("gdsp_percentiles_use_device_reduce", dcb, None)
         call("gdsp_percentiles", src, len(vecs), int(window), float(lo), float(hi), pts, len(p_thousandths),
              int(strategy), int(sample_target), cb, None, vals, C.byref(count))
     except GdspError:
         if failure:
             raise failure[0]
         raise
+    finally:
+        if dcb is not None:
+            call("gdsp_percentiles_use_device_reduce", None, None)
     if count.value == 0:
         return 0, []
     return int(count.value), [float(x) for x in vals]
+
+
+class Comm:
+    """RCCL communicator over devices of this process (gdsp_comm_create: ncclCommInitAll)."""
+
+    def __init__(self, devices):
+        h = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices)
+        call("gdsp_comm_create", C.byref(h), arr, len(devices))
+        self.handle = h.value
+        self.devices = list(devices)
+
+    def allreduce(self, bufs, count, op, dtype="u64", streams=None):
+        """bufs: one device address per rank, reduced in place; op 'sum' | 'min' | 'max'."""
+        ptrs = (C.c_void_p * len(bufs))(*bufs)
+        st = (C.c_void_p * len(bufs))(*(streams or [None] * len(bufs)))
+        call("gdsp_comm_allreduce_" + dtype, C.c_void_p(self.handle), ptrs, int(count), ("sum", "min", "max").index(op), st)
+
+    def close(self):
+        if self.handle:
+            call("gdsp_comm_destroy", C.c_void_p(self.handle))
+            self.handle = None
+
+
+def rccl_version():
+    v = C.c_int(0)
+    call("gdsp_comm_rccl_version", C.byref(v))
+    return v.value
 
 
 def percentile_stats():

@@ -36,6 +36,35 @@ def _bench(ranks, workload, scale, extra=()):
     return json.loads(lines[0])
 
 
+def test_plain_invocation_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (what the driver's scaling run may do): bench.py starts
+    the two ranks itself, before anything touches HIP, and relays rank 0's one JSON line."""
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--workload", "percentile", "--scale", "0.08", "--steps", "1",
+           "--warmup", "0", "--no-cpu-baseline", "--rehearse-on-one-gpu"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    two = json.loads(lines[0])
+    one = _bench(1, "percentile", 0.08)
+    assert two["n_gpus"] == 2 and two["percentile99"] == one["percentile99"] and two["sampled"] == one["sampled"]
+
+
+def test_device_reduction_hook_through_rccl_at_world_size_one():
+    """One rank, backend nccl (= RCCL): the percentile workload's reductions run as torch.distributed all-reduces on
+    the library's device words (no host copy) -- the code path of the N-GPU run, exercised on the one-GPU box."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "1", "--workload", "percentile", "--scale", "0.08",
+           "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--force-collectives"]
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    got = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    one = _bench(1, "percentile", 0.08)
+    assert got["percentile99"] == one["percentile99"] and got["sampled"] == one["sampled"]
+    assert got["config"]["collectives"] == "rccl (torch.distributed nccl backend), device words"
+
+
 def test_percentile_over_two_ranks_equals_one_rank():
     # 0.08 of the genome = 247 Mbp: above the 2^24 values where the bracketing route starts
     one = _bench(1, "percentile", 0.08)
