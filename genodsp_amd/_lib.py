@@ -42,6 +42,7 @@ SIGNATURES = {
     "gdsp_memcpy_h2d": (_int, [_vp, _vp, _sz, _vp]),
     "gdsp_memcpy_d2h": (_int, [_vp, _vp, _sz, _vp]),
     "gdsp_memcpy_d2d": (_int, [_vp, _vp, _sz, _vp]),
+    "gdsp_memcpy_peer": (_int, [_vp, _int, _vp, _int, _sz, _vp]),
     "gdsp_memset": (_int, [_vp, _int, _sz, _vp]),
     "gdsp_stream_create": (_int, [C.POINTER(_vp)]),
     "gdsp_stream_destroy": (_int, [_vp]),

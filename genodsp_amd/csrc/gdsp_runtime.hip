@@ -93,6 +93,13 @@ int gdsp_memcpy_d2d (void* d_dst, const void* d_src, size_t bytes, void* stream)
 	return GDSP_OK;
 	}
 
+int gdsp_memcpy_peer (void* d_dst, int dstDevice, const void* d_src, int srcDevice, size_t bytes, void* stream)
+	{
+	if (dstDevice == srcDevice) GDSP_HIP_TRY (hipMemcpyAsync (d_dst, d_src, bytes, hipMemcpyDeviceToDevice, gdsp_stream (stream)));
+	else                        GDSP_HIP_TRY (hipMemcpyPeerAsync (d_dst, dstDevice, d_src, srcDevice, bytes, gdsp_stream (stream)));
+	return GDSP_OK;
+	}
+
 int gdsp_memset (void* d_dst, int byte, size_t bytes, void* stream)
 	{
 	GDSP_HIP_TRY (hipMemsetAsync (d_dst, byte, bytes, gdsp_stream (stream)));

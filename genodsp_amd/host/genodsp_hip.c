@@ -146,6 +146,26 @@ typedef struct devstate
 	u32      maxLength;   /* longest chromosome on this device */
 	} devstate;
 
+/* --sharding=bases: between ingest and report the signal may live as STRETCHES of chromosomes, equal
+ * shares of the genome's bases per device, each stretch with haloCap bases of its neighbours either side.  A stretch
+ * is a spec like any other -- name of its chromosome, `start` = where its vector begins, the vector in HBM -- so the
+ * operators are applied to it unchanged. */
+typedef struct piece
+	{
+	xspec x;                /* what an operator is handed: x.pub.valVector[0] is base extStart of the chromosome */
+	spec* whole;            /* the chromosome this is a stretch of */
+	u32   extStart;         /* first base held (halo included) */
+	u32   ownStart, ownEnd; /* the bases this stretch answers for: [ownStart, ownEnd) */
+	} piece;
+static int    shardBases     = false;            /* --sharding=bases */
+static int    showShards     = false;            /* --shards=show: print the plan and stop */
+static piece* pieces         = NULL;
+static int    numPieces      = 0;
+static int    signalInPieces = false;            /* where the signal is current: the stretches, or the whole chromosomes */
+static int    halosFresh     = false;            /* every stretch's halo equals its neighbours' bases */
+static u32    haloCap        = 0;                /* halo bases per side: the longest reach of a sharded run */
+static spec*  activeSpec     = NULL;             /* the stretch an operator is being applied to */
+
 static devstate devs[64];
 static int      currentDevice = 0;
 static int      physicalDevices = 1;   /* logical device d runs on GPU d % physicalDevices (see --gpus) */
@@ -181,6 +201,10 @@ static void usage (void)
 	"  --nooutput                do not write the resulting signal\n"
 	"  --window=<length>         (W=) default window size for windowed operators\n"
 	"  --gpus=<n>                shard whole chromosomes over n GPUs (default 1)\n"
+	"  --sharding=chromosomes|bases  with --gpus=n: whole chromosomes dealt longest-first (default), or equal\n"
+	"                            shares of the genome's bases, chromosomes cut where needed (stretches carry\n"
+	"                            the halo their operators reach into; same output either way)\n"
+	"  --shards=show             print which device gets what (and the makespan efficiency) and stop\n"
 	"  --reduce=rccl|host        how percentile / invert combine the GPUs' counts: an RCCL all-reduce in\n"
 	"                            HBM (default with --gpus > 1) or sums on the host\n"
 	"  --nofuse                  run every operator as its own kernel (default: the chains\n"
@@ -378,15 +402,21 @@ void select_device_of (spec* s)
 
 void* op_stream (void) { return devs[currentDevice].stream; }
 
+static spec* vector_spec (char* vName)           /* the stretch being processed, else the chromosome of that name */
+	{
+	if ((activeSpec != NULL) && (strcmp (activeSpec->chrom, vName) == 0)) return activeSpec;
+	return find_chromosome_spec (vName);
+	}
+
 valtype* partner_vector (char* vName)
 	{
-	spec* s = find_chromosome_spec (vName);
+	spec* s = vector_spec (vName);
 	return (s == NULL)? NULL : ((xspec*) s)->partner;
 	}
 
 void flip_vector (char* vName)
 	{
-	spec* s = find_chromosome_spec (vName);
+	spec* s = vector_spec (vName);
 	if (s == NULL) return;
 	valtype* t = s->valVector;  s->valVector = ((xspec*) s)->partner;  ((xspec*) s)->partner = t;
 	}
@@ -530,12 +560,13 @@ void genome_extremes (valtype* lo, valtype* hi)
 		check_gdsp (gdsp_minmax_init (acc[d], devs[d].stream), "genome extremes");
 		accs[d] = acc[d];  streams[d] = devs[d].stream;
 		}
-	for (int i=0 ; chromsSorted[i]!=NULL ; i++)
+	sigpart* parts;
+	int nparts = signal_parts (&parts);
+	for (int i=0 ; i<nparts ; i++)
 		{
-		spec* s = chromsSorted[i];
-		int   d = ((xspec*) s)->device;
+		int d = ((xspec*) parts[i].s)->device;
 		check_gdsp (use_device (d), "select device");
-		check_gdsp (gdsp_minmax_update (s->valVector, s->length, 1, -DBL_MAX, DBL_MAX, acc[d], devs[d].stream), "genome extremes");
+		check_gdsp (gdsp_minmax_update (parts[i].v, parts[i].n, 1, -DBL_MAX, DBL_MAX, acc[d], devs[d].stream), "genome extremes");
 		}
 	*lo = DBL_MAX;  *hi = -DBL_MAX;
 	if (deviceComm != NULL)
@@ -563,7 +594,7 @@ int device_index_of (spec* s)  { return ((xspec*) s)->device; }
 int physical_device_of (spec* s) { return ((xspec*) s)->device % physicalDevices; }   /* the GPU a logical shard runs on */
 
 /* deal chromosomes to devices longest-first onto the least loaded (LPT), then allocate */
-static void allocate_vectors (void)
+static void deal_chromosomes (void)
 	{
 	u64 load[64] = { 0 };
 	for (int i=0 ; chromsSorted[i]!=NULL ; i++)
@@ -574,6 +605,10 @@ static void allocate_vectors (void)
 		load[best] += chromsSorted[i]->length;
 		if (chromsSorted[i]->length > devs[best].maxLength) devs[best].maxLength = chromsSorted[i]->length;
 		}
+	}
+
+static void allocate_vectors (void)
+	{
 	for (int d=0 ; d<numDevices ; d++)
 		{
 		check_gdsp (use_device (d), "select device");
@@ -593,6 +628,226 @@ static void allocate_vectors (void)
 		check_gdsp (gdsp_fill (s->valVector, s->length, 0.0, devs[x->device].stream), "clear chromosome vector");
 		}
 	if (trackOperations) tracking_report ("allocate(--done--)\n");
+	}
+
+/* ------------------------------------------------- --sharding=bases: stretches ---- */
+#define HALO_LIMIT (1u << 20)       /* a run reaching further than this is given whole chromosomes */
+
+/* reach of the maximal run [firstOp, stopOp) when every operator in it can work on a stretch: the reaches add up
+ * along the chain, plus one base per operator (dilate treats position 0 of its vector specially, morphology.c:925) */
+static int run_reach (dspop* firstOp, dspop* stopOp, u32* left, u32* right)
+	{
+	u64 L = 0, R = 0;
+	for (dspop* op=firstOp ; op!=stopOp ; op=op->next)
+		{
+		u32 l, r;
+		if (!op_reach (op, &l, &r)) return false;
+		L += (u64) l + 1;  R += (u64) r + 1;
+		}
+	if ((L > HALO_LIMIT) || (R > HALO_LIMIT)) return false;
+	*left = (u32) L;  *right = (u32) R;
+	return true;
+	}
+
+/* equal shares of the genome's bases per device: the chromosomes, longest first, laid end to end and cut at
+ * total*d/N; a cut that would leave a stub is moved to the chromosome's end */
+static void plan_pieces (void)
+	{
+	u64 total = 0;
+	int nchrom = 0;
+	for (dspop* firstOp=pipeline ; firstOp!=NULL ; )
+		{
+		dspop* stopOp;
+		u32 l, r;
+		for (stopOp=firstOp ; stopOp!=NULL ; stopOp=stopOp->next) { if (stopOp->atRandom) break; }
+		if ((stopOp != firstOp) && run_reach (firstOp, stopOp, &l, &r))
+			{ if (l > haloCap) haloCap = l;  if (r > haloCap) haloCap = r; }
+		firstOp = (stopOp == NULL)? NULL : stopOp->next;
+		}
+	for (int i=0 ; chromsSorted[i]!=NULL ; i++) { total += chromsSorted[i]->length;  nchrom++; }
+	const u64 stub = 4 * (u64) haloCap + 64;
+	pieces = (piece*) calloc (nchrom + numDevices, sizeof(piece));
+	if (pieces == NULL) { fprintf (stderr, "out of memory\n");  exit (EXIT_FAILURE); }
+	u64 at = 0;                                   /* bases before the current chromosome */
+	int d  = 0;
+	for (int i=0 ; chromsSorted[i]!=NULL ; i++)
+		{
+		spec* s = chromsSorted[i];
+		u32   a = 0;
+		while (a < s->length)
+			{
+			u64 cut = (d+1 < numDevices)? total * (u64) (d+1) / (u64) numDevices : total;    /* end of device d's share */
+			u32 b;
+			if (cut >= at + s->length) b = s->length;                  /* the share runs past this chromosome */
+			else if (cut <= at + a)    { d++;  continue; }             /* the share is full */
+			else
+				{
+				b = (u32) (cut - at);
+				if (b - a < stub)         { d++;  continue; }          /* only a stub left of this share: next device */
+				if (s->length - b < stub) b = s->length;               /* only a stub left of the chromosome: take it too */
+				}
+			piece* p = &pieces[numPieces++];
+			p->whole = s;  p->ownStart = a;  p->ownEnd = b;
+			p->extStart = (a > haloCap)? a - haloCap : 0;
+			u32 extEnd  = (s->length - b > haloCap)? b + haloCap : s->length;
+			p->x.pub.chrom  = s->chrom;
+			p->x.pub.start  = s->start + p->extStart;
+			p->x.pub.length = extEnd - p->extStart;
+			p->x.device     = d;
+			if (p->x.pub.length > devs[d].maxLength) devs[d].maxLength = p->x.pub.length;
+			a = b;
+			if ((at + b >= cut) && (d+1 < numDevices)) d++;
+			}
+		at += s->length;
+		}
+	}
+
+/* --shards=show: who gets what, and how even that is (no GPU needed: printed before any device is touched) */
+static void show_shards (void)
+	{
+	u64 load[64] = { 0 }, total = 0, most = 0;
+	for (int d=0 ; d<numDevices ; d++)
+		{
+		fprintf (stderr, "device %d:", d);
+		if (shardBases)
+			{
+			for (int i=0 ; i<numPieces ; i++)
+				{
+				if (pieces[i].x.device != d) continue;
+				fprintf (stderr, " %s:%u-%u", pieces[i].whole->chrom, pieces[i].ownStart, pieces[i].ownEnd);
+				load[d] += pieces[i].x.pub.length;                 /* what it computes: halos included */
+				total   += pieces[i].ownEnd - pieces[i].ownStart;
+				}
+			}
+		else
+			{
+			for (int i=0 ; chromsSorted[i]!=NULL ; i++)
+				{
+				if (((xspec*) chromsSorted[i])->device != d) continue;
+				fprintf (stderr, " %s", chromsSorted[i]->chrom);
+				load[d] += chromsSorted[i]->length;  total += chromsSorted[i]->length;
+				}
+			}
+		fprintf (stderr, " = %s bases\n", ucommatize (load[d]));
+		if (load[d] > most) most = load[d];
+		}
+	fprintf (stderr, "sharding=%s halo=%u makespan efficiency %.4f\n", shardBases? "bases" : "chromosomes", haloCap,
+	         (most == 0)? 1.0 : (double) total / ((double) most * numDevices));
+	}
+
+static void allocate_pieces (void)
+	{
+	for (int i=0 ; i<numPieces ; i++)
+		{
+		piece* p = &pieces[i];
+		check_gdsp (use_device (p->x.device), "select device");
+		size_t bytes = ((size_t) p->x.pub.length + 2) * sizeof(valtype);
+		check_gdsp (gdsp_malloc ((void**) &p->x.pub.valVector, bytes), "allocate stretch");
+		check_gdsp (gdsp_malloc ((void**) &p->x.partner,       bytes), "allocate stretch");
+		}
+	check_gdsp (use_device (currentDevice), "select device");
+	}
+
+static void copy_bases (valtype* dst, int dstDev, const valtype* src, int srcDev, u32 count)
+	{
+	if (count == 0) return;
+	check_gdsp (use_device (dstDev), "select device");
+	check_gdsp (gdsp_memcpy_peer (dst, dstDev % physicalDevices, src, srcDev % physicalDevices, (size_t) count * sizeof(valtype),
+	                              devs[dstDev].stream), "copy between devices");
+	}
+
+/* whole chromosomes -> stretches (halos included, so they are fresh) */
+static void to_pieces (void)
+	{
+	if (signalInPieces) return;
+	sync_all_devices ();
+	for (int i=0 ; i<numPieces ; i++)
+		{
+		piece* p = &pieces[i];
+		copy_bases (p->x.pub.valVector, p->x.device, p->whole->valVector + p->extStart, ((xspec*) p->whole)->device, p->x.pub.length);
+		}
+	sync_all_devices ();
+	signalInPieces = true;  halosFresh = true;
+	}
+
+/* stretches -> whole chromosomes: every stretch returns the bases it answers for */
+void to_whole (void)
+	{
+	if (!signalInPieces) return;
+	sync_all_devices ();
+	for (int i=0 ; i<numPieces ; i++)
+		{
+		piece* p = &pieces[i];
+		copy_bases (p->whole->valVector + p->ownStart, ((xspec*) p->whole)->device,
+		            p->x.pub.valVector + (p->ownStart - p->extStart), p->x.device, p->ownEnd - p->ownStart);
+		}
+	sync_all_devices ();
+	signalInPieces = false;
+	}
+
+/* every halo base is fetched from the stretch that answers for it (the only GPU-to-GPU traffic of a sharded run) */
+static void refresh_halos (void)
+	{
+	if (halosFresh) return;
+	sync_all_devices ();
+	for (int i=0 ; i<numPieces ; i++)
+		{
+		piece* p = &pieces[i];
+		u32 extEnd = p->extStart + p->x.pub.length;
+		for (int j=0 ; j<numPieces ; j++)
+			{
+			piece* q = &pieces[j];
+			if ((q == p) || (q->whole != p->whole)) continue;
+			for (int side=0 ; side<2 ; side++)
+				{
+				u32 lo = side? p->ownEnd : p->extStart, hi = side? extEnd : p->ownStart;
+				if (q->ownStart > lo) lo = q->ownStart;
+				if (q->ownEnd   < hi) hi = q->ownEnd;
+				if (lo >= hi) continue;
+				copy_bases (p->x.pub.valVector + (lo - p->extStart), p->x.device,
+				            q->x.pub.valVector + (lo - q->extStart), q->x.device, hi - lo);
+				}
+			}
+		}
+	sync_all_devices ();
+	halosFresh = true;
+	}
+
+/* the signal as the stretches of it that someone answers for, wherever it lives now (percentile, invert) */
+int signal_parts (sigpart** out)
+	{
+	static sigpart* parts = NULL;
+	int n = 0;
+	if (parts == NULL)
+		{
+		int cap = numPieces;
+		for (int i=0 ; chromsSorted[i]!=NULL ; i++) cap++;
+		parts = (sigpart*) calloc (cap + 1, sizeof(sigpart));
+		if (parts == NULL) { fprintf (stderr, "out of memory\n");  exit (EXIT_FAILURE); }
+		}
+	if (signalInPieces)
+		{
+		for (int i=0 ; i<numPieces ; i++)
+			{
+			piece* p = &pieces[i];
+			parts[n].s = &p->x.pub;  parts[n].v = p->x.pub.valVector + (p->ownStart - p->extStart);
+			parts[n].n = p->ownEnd - p->ownStart;  parts[n].first = p->ownStart;
+			parts[n].base = p->x.pub.valVector;  parts[n].baseLen = p->x.pub.length;
+			n++;
+			}
+		}
+	else
+		{
+		for (int i=0 ; chromsSorted[i]!=NULL ; i++)
+			{
+			spec* s = chromsSorted[i];
+			parts[n].s = s;  parts[n].v = s->valVector;  parts[n].n = s->length;  parts[n].first = 0;
+			parts[n].base = s->valVector;  parts[n].baseLen = s->length;
+			n++;
+			}
+		}
+	*out = parts;
+	return n;
 	}
 
 /* ---------------------------------------------------------------- text ingest */
@@ -795,6 +1050,7 @@ void read_intervals (FILE* f, int valCol, int origin1, int overlapOp, int clear,
 	valtype  val;
 	int      clearFlags = clear? GDSP_CLEAR_BOTH : 0;
 
+	to_whole ();                                               /* intervals are applied to whole chromosomes */
 	if (trackOperations) { for (int i=0 ; chromsSorted[i]!=NULL ; i++) chromsSorted[i]->flag = false; }
 	ib_begin ();
 	prevChrom[0] = 0;
@@ -925,6 +1181,7 @@ static void out_line (FILE* f, const char* chrom, int start, int end, int withVa
 void report_intervals (FILE* f, int precision, int noValues, int collapse, int uncovered, int origin1)
 	{
 	u32 o = origin1? 1 : 0;
+	to_whole ();                                               /* runs are found chromosome by chromosome */
 	for (spec* s=chromsOfInterest ; s!=NULL ; s=s->next)
 		{
 		if (trackOperations) tracking_report ("output(%s)\n", s->chrom);
@@ -1127,6 +1384,9 @@ static void parse_options (int _argc, char** _argv)            /* genodsp.c:284-
 			continue;
 			}
 		if (strcmp (arg, "--nofuse") == 0) { fuseChains = false;  continue; }
+		if (strcmp (arg, "--shards=show") == 0)          { showShards = true;   continue; }
+		if (strcmp (arg, "--sharding=bases") == 0)       { shardBases = true;   continue; }
+		if (strcmp (arg, "--sharding=chromosomes") == 0) { shardBases = false;  continue; }
 		if (strcmp (arg, "--reduce=rccl") == 0) { reduceHow = reduce_rccl;  continue; }
 		if (strcmp (arg, "--reduce=host") == 0) { reduceHow = reduce_host;  continue; }
 		if (strcmp (arg, "--smooth=exact") == 0) { firMode = GDSP_FIR_EXACT;  continue; }
@@ -1197,6 +1457,15 @@ int main (int argc, char** argv)
 	set_named_global ("originOne",     (valtype) originOne);
 	parse_options (argc, argv);
 
+	if (showShards)
+		{
+		sort_chromosomes_by_length ();
+		deal_chromosomes ();
+		if (shardBases) plan_pieces ();
+		show_shards ();
+		return EXIT_SUCCESS;
+		}
+
 	int available = 0;
 	check_gdsp (gdsp_device_count (&available), "count GPUs");
 	if (available < 1) { fprintf (stderr, "[%s] no GPU visible\n", programName);  return EXIT_FAILURE; }
@@ -1209,7 +1478,10 @@ int main (int argc, char** argv)
 		}
 
 	sort_chromosomes_by_length ();
+	deal_chromosomes ();
+	if (shardBases) plan_pieces ();                            /* (before allocation: stretches count towards scratch sizes) */
 	allocate_vectors ();
+	if (shardBases) allocate_pieces ();
 	create_device_comm ();
 
 	/* stdin is the signal unless the first operator is `input` (genodsp.c:891-893) */
@@ -1227,27 +1499,41 @@ int main (int argc, char** argv)
 		for (stopOp=firstOp ; stopOp!=NULL ; stopOp=stopOp->next) { if (stopOp->atRandom) break; }
 		if (stopOp != firstOp)
 			{
-			for (int i=0 ; chromsSorted[i]!=NULL ; i++)
+			u32 reachL = 0, reachR = 0;
+			int sharded = shardBases && run_reach (firstOp, stopOp, &reachL, &reachR);
+			int nunits = 0;
+			if (sharded) { to_pieces ();  if ((reachL | reachR) != 0) refresh_halos ();  nunits = numPieces; }
+			else         { to_whole ();  while (chromsSorted[nunits] != NULL) nunits++; }
+			for (int i=0 ; i<nunits ; i++)
 				{
-				spec* s = chromsSorted[i];
+				spec* s = sharded? &pieces[i].x.pub : chromsSorted[i];
+				char  where[200];
+				if (sharded) snprintf (where, sizeof(where), "%.100s:%u-%u", s->chrom, pieces[i].ownStart, pieces[i].ownEnd);
+				else         snprintf (where, sizeof(where), "%.100s", s->chrom);
 				select_device_of (s);
+				activeSpec = sharded? s : NULL;
 				for (dspop* op=firstOp ; op!=stopOp ; op=op->next)
 					{
-					if (trackOperations) fprintf (stderr, "%s(%s)\n", op->name, s->chrom);
+					if (trackOperations) fprintf (stderr, "%s(%s)\n", op->name, where);
 					int fused = fuseChains? try_fused_apply (op, stopOp, s) : 0;
 					if (fused == 0) { (*op->funcApply) (op, s->chrom, s->length, s->valVector);  continue; }
 					for ( ; fused > 1 ; fused--)           /* the chain ran as one kernel */
 						{
 						op = op->next;
-						if (trackOperations) fprintf (stderr, "%s(%s)\n", op->name, s->chrom);
+						if (trackOperations) fprintf (stderr, "%s(%s)\n", op->name, where);
 						}
 					}
+				activeSpec = NULL;
 				}
+			if (sharded && ((reachL | reachR) != 0)) halosFresh = false;     /* pointwise runs leave the halos right */
 			}
 		if (stopOp == NULL) firstOp = NULL;
 		else
 			{
 			if (trackOperations) tracking_report ("%s(*)\n", stopOp->name);
+			if ((stopOp->funcApply != op_percentile_apply) && (stopOp->funcApply != op_invert_apply)
+			 && (stopOp->funcApply != op_show_variables_apply))
+				to_whole ();                                   /* file-driven operators address whole chromosomes */
 			(*stopOp->funcApply) (stopOp, "*", maxLength, NULL);
 			firstOp = stopOp->next;
 			}

@@ -19,6 +19,12 @@ void ib_flush_mask  (int inside, valtype outsideVal, int binarizeFirst);
 void ib_flush_over  (int wantMax, valtype fillVal);
 
 void sync_all_devices    (void);
+/* the signal as the stretches someone answers for, wherever it lives now: whole chromosomes, or (--sharding=bases,
+ * between ingest and report) stretches of them.  v[0] is base `first` of chromosome s->chrom; base/baseLen is the
+ * 16-byte aligned vector v lies in (an elementwise operator may as well run over all of it) */
+typedef struct sigpart { spec* s;  valtype* v;  u32 n;  u32 first;  valtype* base;  u32 baseLen; } sigpart;
+int  signal_parts (sigpart** parts);
+void to_whole (void);                          /* make the whole chromosomes current (file-driven operators, report) */
 /* how whole-genome operators (percentile, invert) combine what the devices of this process found: the
  * reduction hook for gdsp_percentiles (NULL: the library adds its devices' counts on the host) */
 gdsp_reduce_fn reduce_over_devices (void** ctx);
@@ -41,6 +47,12 @@ void  resolve_variable  (dspop* op, char** varName, valtype* val, const char* ro
  * the chain is one the device library fuses; returns how many operators were consumed (0 = none) */
 int   try_fused_apply   (dspop* op, dspop* stopOp, spec* s);
 u32   op_smooth_window    (dspop* op);
+u32   op_best_window      (dspop* op);
+void  op_morph_reach      (dspop* op, u32* left, u32* right);
+/* --sharding=bases: true when output i of this per-chromosome operator depends on inputs [i-left, i+right] only
+ * and not on where i lies in the vector (so a stretch of a chromosome with that much halo computes what the whole
+ * chromosome would); false for running sums, window grids and clump, which need the chromosome in one piece */
+int   op_reach            (dspop* op, u32* left, u32* right);
 void  op_local_describe   (dspop* op, u32* neighborhood, int* wantMax, valtype* fill);
 void  op_morph_describe   (dspop* op, u32* left, u32* right, valtype* T, valtype* one, valtype* zero);
 void  op_binarize_describe (dspop* op, valtype* T, int* tiesAbove, valtype* one, valtype* zero);

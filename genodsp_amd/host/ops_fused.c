@@ -16,6 +16,27 @@
 dspprototypes(op_smooth)  dspprototypes(op_local_minima)  dspprototypes(op_local_maxima)
 dspprototypes(op_dilate)  dspprototypes(op_erode)         dspprototypes(op_binarize)
 
+dspprototypes(op_best_local_min)  dspprototypes(op_best_local_max)  dspprototypes(op_close)  dspprototypes(op_open)
+dspprototypes(op_clip)  dspprototypes(op_erase)  dspprototypes(op_add_constant)  dspprototypes(op_absolute_value)  dspprototypes(op_map)
+
+int op_reach (dspop* op, u32* left, u32* right)
+	{
+	opfunc_apply f = op->funcApply;
+	*left = *right = 0;
+	if (f == op_smooth_apply)                              /* sum.c:647-663: taps -h..+h */
+		{ *left = *right = (op_smooth_window (op) - 1) / 2;  return true; }
+	if ((f == op_local_maxima_apply) || (f == op_local_minima_apply))      /* minmax.c:1195-1216 */
+		{ u32 N;  int wantMax;  valtype fill;  op_local_describe (op, &N, &wantMax, &fill);  *left = *right = (N - 1) / 2;  return true; }
+	if ((f == op_best_local_max_apply) || (f == op_best_local_min_apply))  /* minmax.c:1636-1640: [i-wLft, i+wRgt] */
+		{ u32 W = op_best_window (op);  *left = (W - 1) / 2;  *right = W - 1 - *left;  return true; }
+	if ((f == op_dilate_apply) || (f == op_erode_apply) || (f == op_close_apply) || (f == op_open_apply))
+		{ op_morph_reach (op, left, right);  return (*left != u32Max); }
+	if ((f == op_binarize_apply) || (f == op_clip_apply) || (f == op_erase_apply) || (f == op_add_constant_apply)
+	 || (f == op_absolute_value_apply) || (f == op_map_apply))
+		return true;
+	return false;                                          /* sum, slidingsum, cumulativesum, clump, anticlump, plugins */
+	}
+
 int try_fused_apply (dspop* op, dspop* stopOp, spec* s)
 	{
 	dspop* next = op->next;

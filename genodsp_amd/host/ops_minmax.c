@@ -95,6 +95,8 @@ static dspop* best_parse (char* name, int argc, char** argv, int wantMax)
 	return (dspop*) op;
 	}
 
+u32 op_best_window (dspop* op) { return ((dspop_best*) op)->windowSize; }
+
 static void best_usage (char* name, FILE* f, char* indent, int wantMax)
 	{
 	if (indent == NULL) indent = "";

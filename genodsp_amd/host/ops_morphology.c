@@ -81,6 +81,21 @@ static void morph_free (dspop* _op)
 	}
 
 /* parameters as morph_apply would use them (resolves a threshold variable, with the usual note) */
+/* how far an output looks: dilate / erode test [i-right, i+left]; close / open decide a run from its length, at most
+ * <length>+1 bases either way (no variable is resolved here: this is asked before the pipeline runs) */
+void op_morph_reach (dspop* _op, u32* left, u32* right)
+	{
+	dspop_morph* op = (dspop_morph*) _op;
+	if ((op->kind == M_DILATE) || (op->kind == M_ERODE))
+		{
+		u32 l = op->left, r = op->right;
+		if ((l == 0) && (r == 0)) { l = (u32) (op->length / 2);  r = (u32) (op->length - l); }
+		*left = r;  *right = l;
+		return;
+		}
+	*left = *right = (op->length < 4.0e9)? (u32) op->length + 1 : u32Max;
+	}
+
 void op_morph_describe (dspop* _op, u32* left, u32* right, valtype* T, valtype* one, valtype* zero)
 	{
 	dspop_morph* op = (dspop_morph*) _op;

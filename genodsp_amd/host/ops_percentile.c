@@ -186,8 +186,9 @@ void op_percentile_apply (dspop* _op, arg_dont_complain(char* vName), arg_dont_c
 
 	/* every chromosome on every GPU is one source of the population; the counts of the devices of this
 	 * process are added through the driver's reduction (RCCL over the devices in use, see genodsp_hip.c) */
-	int nsrc = 0, npct = 0;
-	for (int i=0 ; chromsSorted[i]!=NULL ; i++) nsrc++;
+	int npct = 0;
+	sigpart* parts;
+	int nsrc = signal_parts (&parts);
 	if (extremesOnly) npct = minAndMax? 2 : 1;
 	else
 		{
@@ -202,10 +203,13 @@ void op_percentile_apply (dspop* _op, arg_dont_complain(char* vName), arg_dont_c
 	sync_all_devices ();
 	for (int i=0 ; i<nsrc ; i++)
 		{
-		spec* s = chromsSorted[i];
-		select_device_of (s);
-		src[i].d_v = s->valVector;  src[i].n = s->length;
-		src[i].device = physical_device_of (s);  src[i].stream = op_stream ();
+		/* the sample is every windowSize-th base counted from the chromosome's first (percentile.c:560): a stretch
+		 * that starts at base `first` begins with the next multiple */
+		u32 skip = (op->windowSize - parts[i].first % op->windowSize) % op->windowSize;
+		select_device_of (parts[i].s);
+		src[i].d_v = (skip < parts[i].n)? parts[i].v + skip : NULL;
+		src[i].n   = (skip < parts[i].n)? parts[i].n - skip : 0;
+		src[i].device = physical_device_of (parts[i].s);  src[i].stream = op_stream ();
 		}
 	npct = 0;
 	if (extremesOnly)
@@ -223,7 +227,7 @@ void op_percentile_apply (dspop* _op, arg_dont_complain(char* vName), arg_dont_c
 	gdsp_reduce_fn reduce = reduce_over_devices (&reduceCtx);
 	check_gdsp (gdsp_percentiles (src, nsrc, op->windowSize, op->minAllowed, op->maxAllowed, pts, npct,
 	                              selectStrategy, 0, reduce, reduceCtx, vals, &numValues), "percentile");
-	if (nsrc > 0) select_device_of (chromsSorted[0]);
+	if (nsrc > 0) select_device_of (parts[0].s);
 	free (src);
 	if (numValues == 0)
 		{

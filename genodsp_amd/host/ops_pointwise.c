@@ -254,11 +254,12 @@ void op_invert_apply (dspop* _op, arg_dont_complain(char* vName), arg_dont_compl
 		genome_extremes (&lo, &hi);                          /* add.c:909-923, over every device */
 		mid = (lo + hi) / 2.0;                               /* add.c:925 */
 		}
-	for (int i=0 ; chromsSorted[i]!=NULL ; i++)
+	sigpart* parts;
+	int nparts = signal_parts (&parts);
+	for (int i=0 ; i<nparts ; i++)                           /* (a stretch is inverted halo and all: the halo stays its neighbours' bases) */
 		{
-		spec* s = chromsSorted[i];
-		select_device_of (s);
-		check_gdsp (gdsp_invert (s->valVector, s->length, mid, op_stream ()), _op->name);
+		select_device_of (parts[i].s);
+		check_gdsp (gdsp_invert (parts[i].base, parts[i].baseLen, mid, op_stream ()), _op->name);
 		}
 	}
 

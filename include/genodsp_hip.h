@@ -60,6 +60,7 @@ int gdsp_host_free      (void* h_ptr);
 int gdsp_memcpy_h2d     (void* d_dst, const void* h_src, size_t bytes, void* stream);
 int gdsp_memcpy_d2h     (void* h_dst, const void* d_src, size_t bytes, void* stream);
 int gdsp_memcpy_d2d     (void* d_dst, const void* d_src, size_t bytes, void* stream);
+int gdsp_memcpy_peer    (void* d_dst, int dstDevice, const void* d_src, int srcDevice, size_t bytes, void* stream); /* GPU to GPU (xGMI) */
 int gdsp_memset         (void* d_dst, int byte, size_t bytes, void* stream);
 int gdsp_stream_create  (void** stream);
 int gdsp_stream_destroy (void* stream);

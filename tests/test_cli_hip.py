@@ -181,6 +181,60 @@ def test_sharded_driver_gives_the_same_output(tmp_path, monkeypatch):
     assert outs[0] == outs[1]
 
 
+@pytest.mark.parametrize("case", DIGEST_CASES[::2], ids=[c["name"] for c in DIGEST_CASES[::2]])
+def test_base_sharding_prints_what_the_reference_printed(case, tmp_path, monkeypatch):
+    """--gpus=3 --sharding=bases: the chromosomes are cut into equal shares of the genome's bases; runs of
+    operators with a bounded reach (smooth, extrema, morphology, pointwise) work on the stretches, each carrying the
+    halo the chain reaches into and refreshed from its neighbours between runs; everything else (running sums, clump,
+    file-driven operators, ingest, report) gets whole chromosomes back.  The three shards share the one GPU of the
+    test box.  Same bytes as the reference binary."""
+    import hashlib
+    monkeypatch.setenv("GDSP_OVERSUBSCRIBE_GPUS", "1")
+    rc, out, err = run(["--gpus=3", "--sharding=bases", "--progress=operations"] + case["args"], case["stdin"],
+                       case["chroms_text"], tmp_path, case.get("files"))
+    assert rc == 0, err
+    assert hashlib.sha256(out.encode()).hexdigest() == case["sha256"], (case["args"], out[:300])
+    for line in case["stderr_percentile"]:
+        assert line in err.splitlines()
+
+
+def test_base_sharding_cuts_chromosomes_and_matches_whole_chromosomes(tmp_path, monkeypatch):
+    """Two chromosomes of very different length over 4 shards: the long one must be cut (the progress lines name the
+    stretches), and every pipeline -- fused chains, long reaches, percentile with a window, invert, a running sum in
+    the middle (whole chromosomes again) -- prints exactly what --sharding=chromosomes prints."""
+    import numpy as np
+    monkeypatch.setenv("GDSP_OVERSUBSCRIBE_GPUS", "1")
+    chroms = "chrL 90000\nchrS 7000\n"
+    rng = np.random.default_rng(21)
+    lines = []
+    for c, n in (("chrL", 90000), ("chrS", 7000)):
+        for _ in range(n // 20):
+            a = int(rng.integers(0, n - 300))
+            lines.append("%s %d %d %.2f" % (c, a, a + int(rng.integers(1, 300)), rng.random() * 6 - 1))
+    iv = "\n".join(lines) + "\n"
+    pipelines = [["=", "smooth", "W=101", "=", "localmax", "N=11"],
+                 ["--nofuse", "=", "smooth", "W=101", "=", "localmax", "N=11"],
+                 ["=", "dilate", "1001", "=", "erode", "1001", "=", "binarize"],
+                 ["=", "close", "300", "=", "open", "40", "=", "bestmax", "W=500", "=", "localmin", "N=201", "--infinity=9"],
+                 ["=", "percentile", "90", "--window=7", "--min=0.5", "=", "clip", "--max=percentile90", "=", "invert", "=", "abs"],
+                 ["=", "smooth", "W=21", "=", "cumulativesum", "=", "smooth", "W=51", "=", "slidingsum", "W=30", "=", "bestmin", "W=9"],
+                 ["=", "clip", "--min=0", "=", "addconst", "0.25", "=", "smooth", "W=5001"]]
+    for pl in pipelines:
+        got = {}
+        for how in ("chromosomes", "bases"):
+            rc, out, err = run(["--precision=10", "--gpus=4", "--sharding=" + how, "--progress=operations"] + pl, iv, chroms, tmp_path)
+            assert rc == 0, err
+            got[how] = out
+            if how == "bases" and pl[1] != "percentile":
+                first = pl[2] if pl[0] == "--nofuse" else pl[1]
+                if "cumulativesum" in pl:        # a running sum anywhere in a run of operators: the run gets whole chromosomes
+                    assert ("%s(chrL)" % first) in err and "chrL:0-" not in err
+                else:
+                    assert ("%s(chrL:0-" % first) in err and ("%s(chrS:0-7000)" % first) in err, err[-1500:]
+        assert got["bases"] == got["chromosomes"], pl
+        assert len(got["bases"].splitlines()) >= 2
+
+
 def test_rccl_communicator_reduces_percentile_and_invert(tmp_path):
     """--reduce=rccl: percentile's histograms / counters and invert's extremes go through ncclCommInitAll +
     ncclAllReduce (gdsp_comm.hip) even with one device, so communicator creation and the u64 sum / min / max and

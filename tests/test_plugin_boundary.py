@@ -111,3 +111,35 @@ def test_group_runs_in_the_pipeline_on_the_gpu(tmp_path):
     assert len(open(snap).read().splitlines()) == len(expect)                  # write_all_chromosomes: the same runs, 10 decimals
     q = subprocess.run([binary, "chrA:100", "=", "demolift", "--bogus"], input="", capture_output=True, text=True)
     assert q.returncode != 0 and "Can't understand" in q.stderr and "usage: demolift" in q.stderr   # chastise + usage
+
+
+def test_base_sharding_plan_is_even_at_eight_devices():
+    """--sharding=bases --shards=show (no GPU needed): the hg38-like genome of BASELINE.json over 8 devices.  Whole
+    chromosomes dealt longest-first reach 0.965 of a perfect split; equal shares of the bases,
+    chromosomes cut where needed and halos counted as work, must reach 0.995 or better, every base owned once."""
+    import re
+    genome = [("chr1", 248956422), ("chr2", 242193529), ("chr3", 198295559), ("chr4", 190214555), ("chr5", 181538259),
+              ("chr6", 170805979), ("chr7", 159345973), ("chr8", 145138636), ("chr9", 138394717), ("chr10", 133797422),
+              ("chr11", 135086622), ("chr12", 133275309), ("chr13", 114364328), ("chr14", 107043718), ("chr15", 101991189),
+              ("chr16", 90338345), ("chr17", 83257441), ("chr18", 80373285), ("chr19", 58617616), ("chr20", 64444167),
+              ("chr21", 46709983), ("chr22", 50818468), ("chrX", 156040895), ("chrY", 57227415)]
+    driver = os.path.join(ROOT, "genodsp_amd", "genodsp_hip")
+    eff = {}
+    for how in ("chromosomes", "bases"):
+        for gpus in (2, 4, 8):
+            p = subprocess.run([driver] + ["%s:%d" % c for c in genome] + ["--gpus=%d" % gpus, "--sharding=" + how, "--shards=show",
+                               "=", "dilate", "1001", "=", "erode", "1001", "=", "binarize"], capture_output=True, text=True)
+            assert p.returncode == 0, p.stderr
+            eff[how, gpus] = float(re.search(r"makespan efficiency ([0-9.]+)", p.stderr).group(1))
+            if how == "bases":
+                owned = {}
+                for c, a, b in re.findall(r" (chr\w+):(\d+)-(\d+)", p.stderr):
+                    owned.setdefault(c, []).append((int(a), int(b)))
+                for c, n in genome:                              # the stretches of a chromosome tile it exactly
+                    at = 0
+                    for a, b in sorted(owned[c]):
+                        assert a == at and b > a
+                        at = b
+                    assert at == n
+    assert abs(eff["chromosomes", 8] - 0.965) < 0.001 and abs(eff["chromosomes", 4] - 0.995) < 0.001
+    assert eff["bases", 8] >= 0.995 and eff["bases", 4] >= 0.995 and eff["bases", 2] >= 0.995
