@@ -44,7 +44,7 @@ void gdsp_morph_blocks (const double* d_in, double* d_out, uint32_t n, uint32_t 
 
 static inline hipStream_t gdsp_stream (void* s) { return (hipStream_t) s; }
 
-static inline bool gdsp_aligned16 (const void* p) { return (((uintptr_t) p) & 15) == 0; }
+__host__ __device__ static inline bool gdsp_aligned16 (const void* p) { return (((uintptr_t) p) & 15) == 0; }
 
 // MI355X: 256 CUs in 8 XCDs; workgroups are dealt round-robin over the XCDs
 // (block b and b+8 share an L2).  Remap a linear block id so that each XCD

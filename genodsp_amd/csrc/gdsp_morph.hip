@@ -21,6 +21,7 @@
 // every query above with one or two LDS reads, whatever the window length.
 
 #include <math.h>
+#include <stdlib.h>
 #include "gdsp_common.h"
 
 #define MO_THREADS   256
@@ -197,8 +198,54 @@ void morph_kernel (const double* __restrict__ in, double* __restrict__ out, uint
 	mo_stage<OP> (mask, in, n, g0, nwords, T, (OP == MO_ERODE) || (OP == MO_OPEN));
 	mo_build_tables (mask, nextFrom, prevTo, nwords, scanA, scanB);
 
-	// ---- answer: two adjacent bases per lane, one 16-byte store
 	const MoTables tb = { mask, nextFrom, prevTo };
+
+	if ((OP == MO_CLOSE) || (OP == MO_OPEN))
+		{
+		// ---- answer by WORDS: one lane settles 64 bases at a time by walking the runs that cross its word (a run
+		// is decided once, from its two ends), then the workgroup turns the answer bits into one / zero with
+		// 16-byte stores.  A per-base evaluation spends ~30 instructions a base on table look-ups and 64-bit
+		// shifts, enough to hold this kernel below the HBM rate; per word it is ~5.
+		uint64_t* answer = reinterpret_cast<uint64_t*> (prevTo + nwords + 1);       // tile/64 words behind the tables
+		const int firstWord = haloL >> 6, tileWords = tile >> 6;
+		for (int k = threadIdx.x ; k < tileWords ; k += MO_THREADS)
+			{
+			const int      w    = firstWord + k;
+			const uint64_t m    = mask[w];
+			uint64_t       res  = (OP == MO_CLOSE)? m : 0;     // close: S stays; open: only long runs of S survive
+			uint64_t       todo = ~m;                          // positions to decide: gaps of S (close) / runs of S (open: the mask is the complement)
+			while (todo != 0)
+				{
+				const int b = __builtin_ctzll (todo);
+				const int p = 64*w + b;
+				const int e = mo_next (tb, p);                 // first mask position after the run
+				const int s = mo_prev (tb, p);                 // last one before it
+				bool set;
+				if (OP == MO_CLOSE) set = (e != MO_NONE_HI) && (s != MO_NONE_LO) && !((double) (e - (s+1)) > length);
+				else                set = (e == MO_NONE_HI) || (s == MO_NONE_LO) || ((double) (e - (s+1)) > length);
+				const int      last  = (e - 64*w >= 64)? 64 : e - 64*w;                 // the run covers bits [b, last)
+				const uint64_t below = (last >= 64)? ~0ULL : ((1ULL << last) - 1);
+				const uint64_t run   = below & ~((1ULL << b) - 1);
+				if (set) res |= run;
+				todo &= ~run;
+				}
+			answer[k] = res;
+			}
+		__syncthreads ();
+		for (int q = threadIdx.x ; q < tile/2 ; q += MO_THREADS)
+			{
+			const int64_t g = tileStart + 2*q;
+			if (g >= (int64_t) n) break;
+			const uint64_t word = answer[q >> 5];
+			const int      b    = (2*q) & 63;
+			const double   r0   = ((word >> b) & 1)? one : zero, r1 = ((word >> (b+1)) & 1)? one : zero;
+			if (g + 1 < (int64_t) n) *reinterpret_cast<double2*> (out + g) = make_double2 (r0, r1);
+			else                     out[g] = r0;
+			}
+		return;
+		}
+
+	// ---- answer: two adjacent bases per lane, one 16-byte store
 	for (int o = 2*threadIdx.x ; o < tile ; o += 2*MO_THREADS)
 		{
 		const int64_t g = tileStart + o;
@@ -208,31 +255,8 @@ void morph_kernel (const double* __restrict__ in, double* __restrict__ out, uint
 		for (int u=0 ; u<2 ; u++)
 			{
 			const int p = haloL + o + u;           // staged position of this base
-			bool isOne;
-			if (OP == MO_DILATE)
-				isOne = (mo_next (tb, p - right) <= p + left);
-			else if (OP == MO_ERODE)               // first position outside S at or after p-right
-				isOne = (mo_next (tb, p - right) > p + left);
-			else if (OP == MO_CLOSE)
-				{
-				int e = mo_next (tb, p);
-				if (e == p) isOne = true;          // in S
-				else
-					{
-					int s = mo_prev (tb, p);
-					isOne = (e != MO_NONE_HI) && (s != MO_NONE_LO) && !((double) (e - (s+1)) > length);
-					}
-				}
-			else // MO_OPEN: the tables describe the complement
-				{
-				int e = mo_next (tb, p);
-				if (e == p) isOne = false;         // not in S
-				else
-					{
-					int s = mo_prev (tb, p);
-					isOne = (e == MO_NONE_HI) || (s == MO_NONE_LO) || ((double) (e - (s+1)) > length);
-					}
-				}
+			const bool isOne = (OP == MO_DILATE)? (mo_next (tb, p - right) <= p + left)
+			                                    : (mo_next (tb, p - right) >  p + left);   // erode: first position outside S at or after p-right
 			r[u] = isOne? one : zero;
 			}
 		if (g + 1 < (int64_t) n) *reinterpret_cast<double2*> (out + g) = make_double2 (r[0], r[1]);
@@ -342,11 +366,12 @@ static int morph_launch (const double* d_in, double* d_out, uint32_t n, uint64_t
 		}
 	uint64_t tile = 4 * (haloL + haloR);
 	if (tile < MO_MIN_TILE) tile = MO_MIN_TILE;
+	if (getenv ("GDSP_MORPH_TILE") != NULL) tile = (uint64_t) atoll (getenv ("GDSP_MORPH_TILE"));   // (tuning experiments)
 	if (tile + haloL + haloR > MO_MAX_STAGE) tile = MO_MAX_STAGE - haloL - haloR;
 	tile = (tile / 512) * 512;
 	const int      nwords = (int) ((haloL + tile + haloR) / 64);
 	const uint32_t ntiles = (uint32_t) (((uint64_t) n + tile - 1) / tile);
-	const size_t   bytes  = (size_t) nwords * 8 + ((size_t) 2*nwords + 2) * 4;
+	const size_t   bytes  = (size_t) nwords * 8 + ((size_t) 2*nwords + 2) * 4 + (tile / 64) * 8;     // mask, tables, answer words
 
 	hipLaunchKernelGGL ((morph_kernel<OP>), dim3(ntiles), dim3(MO_THREADS), bytes, gdsp_stream (stream),
 	                    d_in, d_out, n, ntiles, (int) tile, (int) haloL, nwords,

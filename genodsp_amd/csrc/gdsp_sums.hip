@@ -206,7 +206,7 @@ void sliding_blocks_kernel (const double* __restrict__ in, double* __restrict__ 
 	}
 
 // -------------------------------------------------------------- window sum ----
-#define WS_TILE_MAX_W 2048               // windows up to this long go through the tiled kernel
+#define WS_TILE_MAX_W 1024               // windows up to this long go through the tiled kernel, longer ones through the rows kernel
 #define WS_TILE_BASES 8192               // bases staged per workgroup (whole windows only)
 
 // Tiled form: a workgroup stages K whole windows with coalesced 16-byte loads, one thread
@@ -279,13 +279,31 @@ void window_sum_tile_kernel (double* __restrict__ v, uint32_t n, uint32_t W, uin
 		if (s >= span) break;
 		const uint32_t len = (uint32_t) ((s + W <= span)? W : span - s);
 		const double*  x   = suLds + (size_t) w * pitch;
-		// (eight LDS reads in flight, the adds still one after the other in the reference's order)
+		// The adds stay one after the other in the reference's order; what can be hidden is the latency of the LDS
+		// reads: sixteen values are fetched while the sixteen before them are being added (with one short batch in
+		// flight a 1000-base window spent more time waiting for LDS than adding).
 		double acc = x[0];
 		uint32_t k = 1;
-		for ( ; k+8<=len ; k+=8)
+		if (len >= 1 + 16)
 			{
-			const double a0 = x[k], a1 = x[k+1], a2 = x[k+2], a3 = x[k+3], a4 = x[k+4], a5 = x[k+5], a6 = x[k+6], a7 = x[k+7];
-			acc += a0;  acc += a1;  acc += a2;  acc += a3;  acc += a4;  acc += a5;  acc += a6;  acc += a7;
+			double A[16], B[16];
+#pragma unroll
+			for (int u=0 ; u<16 ; u++) A[u] = x[k+u];
+			k += 16;
+			while (k + 32 <= len)
+				{
+#pragma unroll
+				for (int u=0 ; u<16 ; u++) B[u] = x[k+u];
+#pragma unroll
+				for (int u=0 ; u<16 ; u++) acc += A[u];
+#pragma unroll
+				for (int u=0 ; u<16 ; u++) A[u] = x[k+16+u];
+#pragma unroll
+				for (int u=0 ; u<16 ; u++) acc += B[u];
+				k += 32;
+				}
+#pragma unroll
+			for (int u=0 ; u<16 ; u++) acc += A[u];
 			}
 		for ( ; k<len ; k++) acc += x[k];
 		res[w] = useActual? acc / (double) len : acc / denom;
@@ -314,6 +332,109 @@ void window_sum_tile_kernel (double* __restrict__ v, uint32_t n, uint32_t W, uin
 		row += dRow;  col += dCol;
 		if (col >= W) { col -= W;  row++; }
 		}
+	}
+
+// ---- long windows (W > WS_TILE_MAX_W): one LANE per window, one 128-byte line of every window at a time.
+// In the tiled kernel a 1000-base window keeps one lane busy for a thousand dependent adds while the other 252
+// threads of its workgroup wait, and LDS holds only a handful of whole windows per CU.  Here a wave takes 64
+// consecutive windows and walks them in step, line by line: per stage it fetches the next 128-byte aligned line of
+// each window (eight 16-byte loads per line, eight windows per load instruction), turns it through LDS, and every
+// lane adds the bases of its own window in that line in the reference's order (sum.c:230-249: bit-identical; a
+// window's first and last line are partial).  All 64 lanes add, the next stage's loads are in flight meanwhile, and
+// a wave needs 17 KiB of LDS however long the windows are.  A line that has landed in LDS is overwritten with
+// zeroVal in HBM straight away -- whole lines, so the memory side never has to merge a partial one, except at the
+// two ends of a window -- and the sum goes to the window's first slot at the end.
+#define WR_PIECE   16                       // bases per window per stage: one 128-byte line (two lines a stage and half the waves: slower)
+#define WR_PITCH   (WR_PIECE + 1)
+#define WR_THREADS 256                      // four waves: 4 x 2 x 64 x 17 x 8 B = 68 KiB of LDS per workgroup
+#define WR_LPR     (WR_PIECE / 2)           // lanes (16-byte words) per window per load instruction
+#define WR_RPI     (64 / WR_LPR)            // windows per load instruction
+#define WR_LOADS   (64 / WR_RPI)            // load instructions per stage
+
+__global__ __launch_bounds__(WR_THREADS)
+void window_sum_rows_kernel (double* __restrict__ v, uint32_t n, uint32_t W, uint32_t nwin,
+                             double denom, int useActual, double zeroVal)
+	{
+	__shared__ __attribute__((aligned(16))) double stage[WR_THREADS/64][2][64 * WR_PITCH];
+	const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const uint64_t w0   = ((uint64_t) blockIdx.x * (WR_THREADS/64) + wave) * 64;      // first window of this wave
+	if (w0 >= nwin) return;                                        // (whole waves only: no workgroup barrier below)
+	const uint64_t myWin   = w0 + lane;
+	const uint64_t myStart = myWin * W;
+	const uint64_t myEnd   = (myWin >= nwin)? myStart : ((myStart + W <= n)? myStart + W : n);
+	const uint64_t myLine0 = myStart / WR_PIECE;
+	const uint32_t nstages = W / WR_PIECE + 2;                     // pieces a window can touch
+	double2*       base    = reinterpret_cast<double2*> (v);
+	const uint64_t lastPair = ((uint64_t) n - 1) / 2;
+
+	// the window and the 16-byte word of its piece that this lane fetches in load instruction j
+	const int myRowInGroup = lane / WR_LPR, myWord = lane % WR_LPR;
+	double2 fetched[WR_LOADS];
+	auto issue = [&] (uint32_t st)
+		{
+#pragma unroll
+		for (int j=0 ; j<WR_LOADS ; j++)
+			{
+			const uint64_t line0 = ((w0 + (uint64_t) (WR_RPI*j + myRowInGroup)) * W) / WR_PIECE;
+			uint64_t pair = (line0 + st) * (WR_PIECE/2) + myWord;
+			if (pair > lastPair) pair = lastPair;                  // clamped: what lies past the data is never added
+			fetched[j] = base[pair];
+			}
+		};
+	auto land = [&] (int buf, uint32_t st)
+		{
+#pragma unroll
+		for (int j=0 ; j<WR_LOADS ; j++)
+			{
+			double* dst = &stage[wave][buf][(WR_RPI*j + myRowInGroup) * WR_PITCH + 2*myWord];
+			dst[0] = fetched[j].x;  dst[1] = fetched[j].y;
+			// the bases of this piece that belong to the window (all but its first slot) become zeroVal
+			const uint64_t win   = w0 + (uint64_t) (WR_RPI*j + myRowInGroup);
+			const uint64_t start = win * W;
+			const uint64_t end   = (win >= nwin)? start : ((start + W <= n)? start + W : n);
+			const uint64_t e0    = (start / WR_PIECE + st) * WR_PIECE + 2*myWord;
+			const bool in0 = (e0     > start) && (e0     < end);
+			const bool in1 = (e0 + 1 > start) && (e0 + 1 < end);
+			if (in0 && in1) base[e0 / 2] = make_double2 (zeroVal, zeroVal);
+			else if (in0)   v[e0] = zeroVal;
+			else if (in1)   v[e0 + 1] = zeroVal;
+			}
+		};
+
+	double acc = 0.0;
+	issue (0);
+	for (uint32_t st=0 ; st<nstages ; st++)
+		{
+		const int buf = st & 1;
+		land (buf, st);                                            // (waits for the loads of this stage)
+		if (st + 1 < nstages) issue (st + 1);                      // next stage's loads fly while this one is added
+		__builtin_amdgcn_wave_barrier ();
+		const uint64_t lineLo = (myLine0 + st) * WR_PIECE;
+		const double*  x      = &stage[wave][buf][lane * WR_PITCH];
+		if ((lineLo > myStart) && (lineLo + WR_PIECE <= myEnd))    // a whole piece inside the window
+			{
+#pragma unroll
+			for (int h=0 ; h<WR_PIECE ; h+=16)
+				{
+				double t[16];
+#pragma unroll
+				for (int u=0 ; u<16 ; u++) t[u] = x[h+u];
+#pragma unroll
+				for (int u=0 ; u<16 ; u++) acc += t[u];
+				}
+			}
+		else
+			{
+			for (int u=0 ; u<WR_PIECE ; u++)
+				{
+				const uint64_t e = lineLo + u;
+				if (e == myStart) { if (e < myEnd) acc = x[u]; }  // sum.c:231-236: the window's first base starts the sum
+				else if ((e > myStart) && (e < myEnd)) acc += x[u];
+				}
+			}
+		__builtin_amdgcn_wave_barrier ();                          // (the buffer is rewritten two stages on)
+		}
+	if (myEnd > myStart) v[myStart] = useActual? acc / (double) (myEnd - myStart) : acc / denom;
 	}
 
 #define WS_SEQ_MAX 8192
@@ -388,26 +509,48 @@ void cumsum_totals_kernel (const double* __restrict__ v, uint32_t n, uint32_t nc
 	if (threadIdx.x == 0) totals[chunk] = (part[0] + part[1]) + (part[2] + part[3]);
 	}
 
-// exclusive scan of the chunk totals, one workgroup of 1024
-__global__ __launch_bounds__(1024)
+// exclusive scan of the chunk totals, one workgroup of 1024: tiles of 8192 totals, eight consecutive ones per thread
+// (64 contiguous bytes per lane, so the loads coalesce; a thread walking its own far-apart slice of the array, as this
+// kernel first did, spends ~90 us on dependent loads for 35 k chunks), lanes, then waves, then a carry from tile to tile
+#define CO_THREADS 1024
+#define CO_PER     8
+__global__ __launch_bounds__(CO_THREADS)
 void cumsum_offsets_kernel (double* __restrict__ totals, uint32_t nchunks)
 	{
-	__shared__ double sums[1024];
-	const uint32_t per = (nchunks + 1023) / 1024;
-	const uint32_t a = threadIdx.x * per, b = (a + per < nchunks)? a + per : ((a < nchunks)? nchunks : a);
-	double acc = 0.0;
-	for (uint32_t i=a ; i<b ; i++) acc += totals[i];
-	sums[threadIdx.x] = acc;
-	__syncthreads ();
-	for (int d=1 ; d<1024 ; d*=2)
+	__shared__ double part[CO_THREADS/64];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	double carry = 0.0;
+	for (uint32_t t0=0 ; t0<nchunks ; t0+=CO_THREADS*CO_PER)
 		{
-		double up = ((int) threadIdx.x >= d)? sums[threadIdx.x - d] : 0.0;
+		const uint32_t c0 = t0 + threadIdx.x * CO_PER;
+		double T[CO_PER];
+#pragma unroll
+		for (int i=0 ; i<CO_PER ; i++) T[i] = (c0 + i < nchunks)? totals[c0 + i] : 0.0;
+		double sum = 0.0;
+#pragma unroll
+		for (int i=0 ; i<CO_PER ; i++) sum += T[i];
+		double incl = sum;
+		for (int d=1 ; d<64 ; d*=2)
+			{
+			const double up = __shfl_up (incl, d, 64);
+			if (lane >= d) incl = up + incl;
+			}
+		double excl = __shfl_up (incl, 1, 64);
+		if (lane == 0) excl = 0.0;
+		if (lane == 63) part[wave] = incl;
 		__syncthreads ();
-		sums[threadIdx.x] += up;
+		double run = carry, all = carry;
+		for (int w=0 ; w<CO_THREADS/64 ; w++) { if (w < wave) run += part[w];  all += part[w]; }
 		__syncthreads ();
+		carry = all;
+		run += excl;
+#pragma unroll
+		for (int i=0 ; i<CO_PER ; i++)
+			{
+			if (c0 + i < nchunks) totals[c0 + i] = run;
+			run += T[i];
+			}
 		}
-	double run = sums[threadIdx.x] - acc;          // exclusive offset of this thread's slice
-	for (uint32_t i=a ; i<b ; i++) { double t = totals[i];  totals[i] = run;  run += t; }
 	}
 
 __global__ __launch_bounds__(SU_THREADS)
@@ -506,6 +649,11 @@ int gdsp_window_sum (double* d_v, uint32_t n, uint32_t W, double denom, int useA
 		hipLaunchKernelGGL (window_sum_tile_kernel, dim3(ntiles), dim3(SU_THREADS), bytes, gdsp_stream (stream),
 		                    d_v, n, W, K, ntiles, denom, useActual, zeroVal);
 		}
+	else if ((W <= WS_SEQ_MAX) && gdsp_aligned16 (d_v))
+		{
+		hipLaunchKernelGGL (window_sum_rows_kernel, dim3((nwin + WR_THREADS - 1)/WR_THREADS), dim3(WR_THREADS), 0,
+		                    gdsp_stream (stream), d_v, n, W, nwin, denom, useActual, zeroVal);
+		}
 	else if (W <= WS_SEQ_MAX)
 		hipLaunchKernelGGL (window_sum_seq_kernel, dim3((nwin + SU_THREADS - 1)/SU_THREADS), dim3(SU_THREADS), 0,
 		                    gdsp_stream (stream), d_v, n, W, nwin, denom, useActual, zeroVal);
@@ -528,7 +676,7 @@ int gdsp_cumulative_sum (double* d_v, uint32_t n, void* d_work, void* stream)
 	hipStream_t    s       = gdsp_stream (stream);
 	GDSP_REQUIRE (gdsp_aligned16 (d_v), "vector must be 16-byte aligned");
 	hipLaunchKernelGGL (cumsum_totals_kernel,  dim3(nchunks), dim3(SU_THREADS), 0, s, d_v, n, nchunks, totals);
-	hipLaunchKernelGGL (cumsum_offsets_kernel, dim3(1),       dim3(1024),       0, s, totals, nchunks);
+	hipLaunchKernelGGL (cumsum_offsets_kernel, dim3(1),       dim3(CO_THREADS), 0, s, totals, nchunks);
 	hipLaunchKernelGGL (cumsum_apply_kernel,   dim3(nchunks), dim3(SU_THREADS), 0, s, d_v, n, nchunks, totals);
 	GDSP_LAUNCH_CHECK ();
 	return GDSP_OK;
