@@ -270,13 +270,21 @@ def split_length(length):
 
 def dilate(v, left, right, T=0.0, one=1.0, zero=0.0, out=None, stream=None):
     out = out if out is not None else v.like()
-    call("gdsp_dilate", v.ptr, out.ptr, v.n, left, right, float(T), float(one), float(zero), _sp(stream))
+    work, nbytes = _long_work(v) if left + right > 200000 else (None, 0)
+    call("gdsp_dilate_any", v.ptr, out.ptr, v.n, left, right, float(T), float(one), float(zero),
+         C.c_void_p(work.ptr) if work else None, nbytes, _sp(stream))
+    if work:
+        sync(stream)
     return out
 
 
 def erode(v, left, right, T=0.0, one=1.0, zero=0.0, out=None, stream=None):
     out = out if out is not None else v.like()
-    call("gdsp_erode", v.ptr, out.ptr, v.n, left, right, float(T), float(one), float(zero), _sp(stream))
+    work, nbytes = _long_work(v) if left + right > 200000 else (None, 0)
+    call("gdsp_erode_any", v.ptr, out.ptr, v.n, left, right, float(T), float(one), float(zero),
+         C.c_void_p(work.ptr) if work else None, nbytes, _sp(stream))
+    if work:
+        sync(stream)
     return out
 
 
@@ -293,13 +301,32 @@ def dilate_erode(v, d_left, d_right, e_left, e_right, d_T=0.0, d_one=1.0, d_zero
 
 def close(v, length, T=0.0, one=1.0, zero=0.0, out=None, stream=None):
     out = out if out is not None else v.like()
-    call("gdsp_close", v.ptr, out.ptr, v.n, float(length), float(T), float(one), float(zero), _sp(stream))
+    work, nbytes = _long_work(v) if length > 100000 else (None, 0)
+    call("gdsp_close_any", v.ptr, out.ptr, v.n, float(length), float(T), float(one), float(zero),
+         C.c_void_p(work.ptr) if work else None, nbytes, _sp(stream))
+    if work:
+        sync(stream)
     return out
 
 
 def open_(v, length, T=0.0, one=1.0, zero=0.0, out=None, stream=None):
     out = out if out is not None else v.like()
-    call("gdsp_open", v.ptr, out.ptr, v.n, float(length), float(T), float(one), float(zero), _sp(stream))
+    work, nbytes = _long_work(v) if length > 100000 else (None, 0)
+    call("gdsp_open_any", v.ptr, out.ptr, v.n, float(length), float(T), float(one), float(zero),
+         C.c_void_p(work.ptr) if work else None, nbytes, _sp(stream))
+    if work:
+        sync(stream)
+    return out
+
+
+def morph_bits(op, v, *args, **kw):
+    """the workspace form of dilate / erode / close / open whatever the length (GDSP_MORPH_FORCE_BITS is read once per
+    process by the library, so tests call the entry points with workspace and the variable set before the first call)"""
+    out = v.like()
+    work, nbytes = _long_work(v)
+    a = [float(x) if isinstance(x, float) else x for x in args]
+    call("gdsp_%s_any" % op, v.ptr, out.ptr, v.n, *a, C.c_void_p(work.ptr), nbytes, _sp(kw.get("stream")))
+    sync(kw.get("stream"))
     return out
 
 

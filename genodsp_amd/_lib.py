@@ -76,6 +76,10 @@ SIGNATURES = {
                                  _int, _f64, _int, _f64, _f64, _vp]),
     "gdsp_close": (_int, [_vp, _vp, _u32, _f64, _f64, _f64, _f64, _vp]),
     "gdsp_open": (_int, [_vp, _vp, _u32, _f64, _f64, _f64, _f64, _vp]),
+    "gdsp_dilate_any": (_int, [_vp, _vp, _u32, _u32, _u32, _f64, _f64, _f64, _vp, _sz, _vp]),
+    "gdsp_erode_any": (_int, [_vp, _vp, _u32, _u32, _u32, _f64, _f64, _f64, _vp, _sz, _vp]),
+    "gdsp_close_any": (_int, [_vp, _vp, _u32, _f64, _f64, _f64, _f64, _vp, _sz, _vp]),
+    "gdsp_open_any": (_int, [_vp, _vp, _u32, _f64, _f64, _f64, _f64, _vp, _sz, _vp]),
     "gdsp_binarize": (_int, [_vp, _u32, _f64, _int, _f64, _f64, _vp]),
     "gdsp_clip": (_int, [_vp, _u32, _int, _f64, _int, _f64, _vp]),
     "gdsp_erase": (_int, [_vp, _u32, _int, _f64, _int, _f64, _int, _f64, _vp]),

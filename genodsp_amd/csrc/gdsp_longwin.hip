@@ -146,7 +146,7 @@ extern "C" {
 /* workspace the *_any entry points may need for this vector length: two vectors of n doubles
  * (extrema) or one plus the scan totals (slidingsum) -- the larger is returned */
 size_t gdsp_long_window_work (uint32_t n)
-	{ return 2 * ((size_t) n + 2) * sizeof(double) + gdsp_cumulative_sum_work (n); }
+	{ return 2 * ((size_t) n + 2) * sizeof(double) + gdsp_cumulative_sum_work (n) + 1024; }   // (+ the fixed part of the morphology tables)
 
 int gdsp_best_extrema_any (const double* d_in, double* d_out, uint32_t n, uint32_t W, int wantMax,
                            void* d_work, size_t workBytes, void* stream)

@@ -22,6 +22,7 @@
 
 #include <math.h>
 #include <stdlib.h>
+#include <algorithm>
 #include "gdsp_common.h"
 
 #define MO_THREADS   256
@@ -324,6 +325,281 @@ void morph_dilate_erode_kernel (const double* __restrict__ in, double* __restric
 		}
 	}
 
+// ------------------------------------------------------------ any reach: the set as bits in HBM ----
+// A window longer than one LDS tile can stage (262 k bases) -- the reference accepts any length, morphology.c:696-866,
+// :1163-1315 -- is answered from the same three things the tile kernel keeps in LDS, now for the whole vector in HBM
+// workspace: the membership bits (n/8 bytes), and per 64-bit word the first member at or after it and the last member
+// at or before its end (two 8-byte tables, 0.25 B/base).  Four small passes build them (bits; extents of 256-word
+// groups; one workgroup joining the groups; the per-word tables); the answer pass settles 64 bases per lane by
+// walking the runs that cross its word -- a run is decided once, however long the reach -- and the workgroup writes
+// one / zero with 16-byte stores.  8 B/base read + 8 B/base written + ~0.5 B/base of tables, for any length.
+#define MG_THREADS 256
+#define MG_NONE_HI ((long long) 1 << 62)
+#define MG_NONE_LO ((long long) -1)
+
+template <int OP>
+__global__ __launch_bounds__(MG_THREADS)
+void mg_bits_kernel (const double* __restrict__ in, uint32_t n, double T, bool complement, unsigned long long* __restrict__ bits,
+                     size_t nwords)
+	{
+	const int    lane = threadIdx.x & 63;
+	const size_t wave = (size_t) blockIdx.x * (MG_THREADS/64) + (threadIdx.x >> 6);
+	const size_t nwaves = (size_t) gridDim.x * (MG_THREADS/64);
+	const size_t nchunks = (nwords + 1) / 2;                       // 128 bases each
+	for (size_t c=wave ; c<nchunks ; c+=nwaves)
+		{
+		const int64_t g = 128 * (int64_t) c + 2*lane;
+		double x = 0.0, y = 0.0;
+		const bool hx = (g < (int64_t) n), hy = (g + 1 < (int64_t) n);
+		if (hy) { const double2 d = *reinterpret_cast<const double2*> (in + g);  x = d.x;  y = d.y; }
+		else if (hx) x = in[g];
+		const uint64_t E = __ballot (hx && mo_member<OP> (x, T, g));
+		const uint64_t O = __ballot (hy && mo_member<OP> (y, T, g+1));
+		if (lane == 0)
+			{
+			uint64_t wA = mo_spread32 (E)       | (mo_spread32 (O)       << 1);
+			uint64_t wB = mo_spread32 (E >> 32) | (mo_spread32 (O >> 32) << 1);
+			if (complement) { wA = ~wA;  wB = ~wB; }               // (positions past n too: outside the vector is "not in S")
+			bits[2*c] = wA;
+			if (2*c + 1 < nwords) bits[2*c+1] = wB;
+			}
+		}
+	}
+
+__device__ __forceinline__ long long mg_first_in (unsigned long long w, long long base) { return (w == 0)? MG_NONE_HI : base + __builtin_ctzll (w); }
+__device__ __forceinline__ long long mg_last_in  (unsigned long long w, long long base) { return (w == 0)? MG_NONE_LO : base + 63 - __builtin_clzll (w); }
+
+// exclusive min-from-the-right / max-from-the-left over the workgroup's 256 values
+template <bool MAX>
+__device__ __forceinline__ long long mg_block_exclusive (long long x, long long* part)
+	{
+	const long long idle = MAX? MG_NONE_LO : MG_NONE_HI;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	long long incl = x;
+	for (int d=1 ; d<64 ; d*=2)
+		{
+		const long long o = MAX? __shfl_up (incl, d, 64) : __shfl_down (incl, d, 64);
+		const bool have = MAX? (lane >= d) : (lane + d < 64);
+		if (have) incl = MAX? max (incl, o) : min (incl, o);
+		}
+	long long excl = MAX? __shfl_up (incl, 1, 64) : __shfl_down (incl, 1, 64);
+	if (lane == (MAX? 0 : 63)) excl = idle;
+	if (lane == (MAX? 63 : 0)) part[wave] = incl;
+	__syncthreads ();
+	for (int w=0 ; w<4 ; w++)
+		{ if (MAX? (w < wave) : (w > wave)) excl = MAX? max (excl, part[w]) : min (excl, part[w]); }
+	__syncthreads ();
+	return excl;
+	}
+
+__global__ __launch_bounds__(MG_THREADS)
+void mg_extent_kernel (const unsigned long long* __restrict__ bits, size_t nwords, long long* __restrict__ groupFirst,
+                       long long* __restrict__ groupLast)
+	{
+	__shared__ long long partF[4], partL[4];
+	const size_t w = (size_t) blockIdx.x * MG_THREADS + threadIdx.x;
+	const unsigned long long x = (w < nwords)? bits[w] : 0;
+	long long first = mg_first_in (x, (long long) w * 64), last = mg_last_in (x, (long long) w * 64);
+	for (int off=32 ; off>0 ; off>>=1) { first = min (first, __shfl_down (first, off, 64));  last = max (last, __shfl_down (last, off, 64)); }
+	if ((threadIdx.x & 63) == 0) { partF[threadIdx.x >> 6] = first;  partL[threadIdx.x >> 6] = last; }
+	__syncthreads ();
+	if (threadIdx.x == 0)
+		{
+		groupFirst[blockIdx.x] = min (min (partF[0], partF[1]), min (partF[2], partF[3]));
+		groupLast[blockIdx.x]  = max (max (partL[0], partL[1]), max (partL[2], partL[3]));
+		}
+	}
+
+// one workgroup: groupFirst -> first member after each group, groupLast -> last member before it
+__global__ __launch_bounds__(1024)
+void mg_join_kernel (long long* __restrict__ groupFirst, long long* __restrict__ groupLast, uint32_t ngroups)
+	{
+	__shared__ long long a[1024];
+	const uint32_t per = (ngroups + 1023) / 1024;
+	const uint32_t lo = min (threadIdx.x * per, ngroups), hi = min (lo + per, ngroups);
+	long long m = MG_NONE_LO;
+	for (uint32_t b=lo ; b<hi ; b++) m = max (m, groupLast[b]);
+	a[threadIdx.x] = m;
+	__syncthreads ();
+	for (int d=1 ; d<1024 ; d*=2)
+		{
+		const long long up = ((int) threadIdx.x >= d)? a[threadIdx.x - d] : MG_NONE_LO;
+		__syncthreads ();
+		a[threadIdx.x] = max (up, a[threadIdx.x]);
+		__syncthreads ();
+		}
+	m = (threadIdx.x > 0)? a[threadIdx.x - 1] : MG_NONE_LO;
+	for (uint32_t b=lo ; b<hi ; b++) { const long long t = groupLast[b];  groupLast[b] = m;  m = max (m, t); }
+	__syncthreads ();
+	long long f = MG_NONE_HI;
+	for (uint32_t b=lo ; b<hi ; b++) f = min (f, groupFirst[b]);
+	a[threadIdx.x] = f;
+	__syncthreads ();
+	for (int d=1 ; d<1024 ; d*=2)
+		{
+		const long long dn = ((int) threadIdx.x + d < 1024)? a[threadIdx.x + d] : MG_NONE_HI;
+		__syncthreads ();
+		a[threadIdx.x] = min (dn, a[threadIdx.x]);
+		__syncthreads ();
+		}
+	f = (threadIdx.x < 1023)? a[threadIdx.x + 1] : MG_NONE_HI;
+	for (uint32_t b=hi ; b>lo ; b--) { const long long t = groupFirst[b-1];  groupFirst[b-1] = f;  f = min (f, t); }
+	}
+
+// per word: nextFrom[w] = first member at or after the start of word w (nwords+1 entries), prevTo[w] = last member at
+// or before the end of word w
+__global__ __launch_bounds__(MG_THREADS)
+void mg_tables_kernel (const unsigned long long* __restrict__ bits, size_t nwords, const long long* __restrict__ firstAfterGroup,
+                       const long long* __restrict__ lastBeforeGroup, long long* __restrict__ nextFrom, long long* __restrict__ prevTo)
+	{
+	__shared__ long long part[4];
+	const size_t w = (size_t) blockIdx.x * MG_THREADS + threadIdx.x;
+	const unsigned long long x = (w < nwords)? bits[w] : 0;
+	const long long first = mg_first_in (x, (long long) w * 64), last = mg_last_in (x, (long long) w * 64);
+	const long long after  = min (mg_block_exclusive<false> (first, part), firstAfterGroup[blockIdx.x]);
+	const long long before = max (mg_block_exclusive<true>  (last,  part), lastBeforeGroup[blockIdx.x]);
+	if (w < nwords) { nextFrom[w] = min (first, after);  prevTo[w] = max (last, before); }
+	if (w == nwords) nextFrom[w] = MG_NONE_HI;
+	}
+
+struct MgTables { const unsigned long long* bits;  const long long* nextFrom;  const long long* prevTo;  long long nbits; };
+
+// first member >= p / last member <= p, for any p (nothing outside [0, nbits))
+__device__ __forceinline__ long long mg_next (const MgTables& t, long long p)
+	{
+	if (p < 0) p = 0;
+	if (p >= t.nbits) return MG_NONE_HI;
+	const long long w = p >> 6;
+	const unsigned long long b = t.bits[w] >> (p & 63);
+	if (b) return p + __builtin_ctzll (b);
+	return t.nextFrom[w+1];
+	}
+__device__ __forceinline__ long long mg_prev (const MgTables& t, long long p)
+	{
+	if (p < 0) return MG_NONE_LO;
+	if (p >= t.nbits) p = t.nbits - 1;
+	const long long w = p >> 6;
+	const unsigned long long b = t.bits[w] << (63 - (p & 63));
+	if (b) return p - __builtin_clzll (b);
+	return (w > 0)? t.prevTo[w-1] : MG_NONE_LO;
+	}
+
+template <int OP>
+__global__ __launch_bounds__(MG_THREADS)
+void mg_answer_kernel (MgTables tb, uint32_t n, long long left, long long right, double length,
+                       double one, double zero, double* __restrict__ out)
+	{
+	__shared__ unsigned long long answer[MG_THREADS];
+	const long long w = (long long) blockIdx.x * MG_THREADS + threadIdx.x;
+	const long long P = w * 64;
+	unsigned long long res = 0;
+	if (P < (long long) n)
+		{
+		const long long stop = (P + 64 < (long long) n)? P + 64 : (long long) n;     // bases [P, stop) are settled here
+		if ((OP == MO_DILATE) || (OP == MO_ERODE))
+			{
+			// dilate: the bits are S; a base is covered while some member lies in [p-right, p+left].
+			// erode: the bits are the complement (outside the vector included); a base survives while none does.
+			long long p = P;
+			while (p < stop)
+				{
+				long long e = mg_next (tb, p - right);              // first member at or after the window's left end
+				if ((OP == MO_ERODE) && (p - right < 0)) e = p - right;                    // the window pokes out on the left: a non-member at once
+				if ((OP == MO_ERODE) && (e == MG_NONE_HI)) e = (long long) n;              // ... and the first one past the right end
+				long long upto;                                     // the same answer holds for [p, upto)
+				bool covered;
+				if (e <= p + left) { covered = true;   upto = (OP == MO_ERODE && e < 0)? right : e + right + 1; }   // until the member leaves the window
+				else               { covered = false;  upto = e - left; }                  // until the window reaches it
+				if (upto > stop) upto = stop;
+				if (upto <= p) upto = p + 1;
+				const bool isOne = (OP == MO_DILATE)? covered : !covered;
+				if (isOne)
+					{
+					const int a = (int) (p - P), b = (int) (upto - P);
+					res |= ((b >= 64)? ~0ULL : ((1ULL << b) - 1)) & ~((1ULL << a) - 1);
+					}
+				p = upto;
+				}
+			}
+		else
+			{
+			const unsigned long long m = tb.bits[w];
+			res = (OP == MO_CLOSE)? m : 0;
+			unsigned long long todo = ~m;
+			if (stop - P < 64) todo &= (1ULL << (stop - P)) - 1;
+			while (todo != 0)
+				{
+				const int       b = __builtin_ctzll (todo);
+				const long long p = P + b;
+				long long e = mg_next (tb, p), s = mg_prev (tb, p);
+				bool set;
+				if (OP == MO_CLOSE) set = (e != MG_NONE_HI) && (s != MG_NONE_LO) && !((double) (e - (s+1)) > length);   // a gap that touches an end of the vector stays
+				else
+					{
+					// (here the bits span the whole vector: no member of the complement beyond means the run ends with the vector)
+					if (e == MG_NONE_HI) e = (long long) n;
+					if (s == MG_NONE_LO) s = -1;
+					set = ((double) (e - (s+1)) > length);
+					}
+				const long long last = (e - P >= 64)? 64 : e - P;
+				const unsigned long long run = ((last >= 64)? ~0ULL : ((1ULL << last) - 1)) & ~((1ULL << b) - 1);
+				if (set) res |= run;
+				todo &= ~run;
+				}
+			}
+		}
+	answer[threadIdx.x] = res;
+	__syncthreads ();
+	const size_t t0 = (size_t) blockIdx.x * MG_THREADS * 64;
+	for (int q=threadIdx.x ; q<MG_THREADS*32 ; q+=MG_THREADS)
+		{
+		const size_t g = t0 + 2*(size_t) q;
+		if (g >= n) break;
+		const unsigned long long word = answer[q >> 5];
+		const int    b  = (2*q) & 63;
+		const double r0 = ((word >> b) & 1)? one : zero, r1 = ((word >> (b+1)) & 1)? one : zero;
+		if (g + 1 < n) *reinterpret_cast<double2*> (out + g) = make_double2 (r0, r1);
+		else           out[g] = r0;
+		}
+	}
+
+static size_t mg_words (size_t n)  { return (n + 63) / 64; }
+static size_t mg_groups (size_t n) { return (mg_words (n) + 1 + MG_THREADS - 1) / MG_THREADS; }
+static size_t mg_work_bytes (size_t n)
+	{ return (mg_words (n) + 2) * 8 + 2 * (mg_words (n) + 2) * 8 + 2 * (mg_groups (n) + 2) * 8 + 64; }
+
+template <int OP>
+static int morph_any (const double* d_in, double* d_out, uint32_t n, uint64_t left, uint64_t right, double length,
+                      double T, double one, double zero, void* d_work, size_t workBytes, void* stream)
+	{
+	GDSP_REQUIRE (d_work != NULL, "this reach needs workspace (gdsp_long_window_work)");
+	GDSP_REQUIRE (workBytes >= mg_work_bytes (n), "workspace too small (gdsp_long_window_work)");
+	GDSP_REQUIRE (gdsp_aligned16 (d_work), "workspace must be 16-byte aligned");
+	const size_t   nwords  = mg_words (n);
+	const uint32_t ngroups = (uint32_t) mg_groups (n);
+	unsigned long long* bits = (unsigned long long*) d_work;
+	long long* nextFrom   = (long long*) (bits + nwords + 2);
+	long long* prevTo     = nextFrom + nwords + 2;
+	long long* groupFirst = prevTo + nwords + 2;
+	long long* groupLast  = groupFirst + ngroups + 2;
+	hipStream_t s = gdsp_stream (stream);
+	const bool complement = (OP == MO_ERODE) || (OP == MO_OPEN);
+	const size_t   nchunks = (nwords + 1) / 2;
+	const uint32_t bblocks = (uint32_t) std::min<size_t> ((nchunks + 3) / 4, 16384);
+	hipLaunchKernelGGL ((mg_bits_kernel<OP>), dim3(bblocks? bblocks : 1), dim3(MG_THREADS), 0, s, d_in, n, T, complement, bits, nwords);
+	hipLaunchKernelGGL (mg_extent_kernel, dim3(ngroups), dim3(MG_THREADS), 0, s, bits, nwords, groupFirst, groupLast);
+	hipLaunchKernelGGL (mg_join_kernel,   dim3(1), dim3(1024), 0, s, groupFirst, groupLast, ngroups);
+	hipLaunchKernelGGL (mg_tables_kernel, dim3(ngroups), dim3(MG_THREADS), 0, s, bits, nwords, groupFirst, groupLast, nextFrom, prevTo);
+	MgTables tb = { bits, nextFrom, prevTo, (long long) nwords * 64 };
+	if (left  > n) left  = n;
+	if (right > n) right = n;
+	const uint32_t ablocks = (uint32_t) ((nwords + MG_THREADS - 1) / MG_THREADS);
+	hipLaunchKernelGGL ((mg_answer_kernel<OP>), dim3(ablocks), dim3(MG_THREADS), 0, s, tb, n, (long long) left, (long long) right, length,
+	                    one, zero, d_out);
+	GDSP_LAUNCH_CHECK ();
+	return GDSP_OK;
+	}
+
 template <int OP>
 static int morph_launch (const double* d_in, double* d_out, uint32_t n, uint64_t left, uint64_t right,
                          double length, double T, double one, double zero, void* stream)
@@ -441,5 +717,29 @@ int gdsp_close (const double* d_in, double* d_out, uint32_t n, double closingLen
 int gdsp_open (const double* d_in, double* d_out, uint32_t n, double openingLength,
                double T, double one, double zero, void* stream)
 	{ return morph_launch<MO_OPEN> (d_in, d_out, n, 0, 0, openingLength, T, one, zero, stream); }
+
+/* any length (the tile kernels above return GDSP_EINVAL beyond 262 k bases of reach): the tile kernel when it applies,
+ * otherwise the set as bits in d_work (>= gdsp_long_window_work(n) bytes).  GDSP_MORPH_FORCE_BITS=1 sends every call
+ * through the workspace form (tests). */
+#define MORPH_ANY(OP, LEFT, RIGHT, LENGTH)                                                                              \
+	{                                                                                                                   \
+	const bool force = (getenv ("GDSP_MORPH_FORCE_BITS") != NULL);                                                      \
+	int rc = force? GDSP_EINVAL : morph_launch<OP> (d_in, d_out, n, LEFT, RIGHT, LENGTH, T, one, zero, stream);         \
+	if ((rc != GDSP_EINVAL) || (n == 0) || (d_in == NULL) || (d_out == NULL) || (d_in == d_out)                         \
+	 || !gdsp_aligned16 (d_in) || !gdsp_aligned16 (d_out)) return rc;                                                   \
+	return morph_any<OP> (d_in, d_out, n, LEFT, RIGHT, LENGTH, T, one, zero, d_work, workBytes, stream);                \
+	}
+int gdsp_dilate_any (const double* d_in, double* d_out, uint32_t n, uint32_t left, uint32_t right, double T, double one, double zero,
+                     void* d_work, size_t workBytes, void* stream)
+	MORPH_ANY (MO_DILATE, left, right, 0.0)
+int gdsp_erode_any (const double* d_in, double* d_out, uint32_t n, uint32_t left, uint32_t right, double T, double one, double zero,
+                    void* d_work, size_t workBytes, void* stream)
+	MORPH_ANY (MO_ERODE, left, right, 0.0)
+int gdsp_close_any (const double* d_in, double* d_out, uint32_t n, double closingLength, double T, double one, double zero,
+                    void* d_work, size_t workBytes, void* stream)
+	MORPH_ANY (MO_CLOSE, 0, 0, closingLength)
+int gdsp_open_any (const double* d_in, double* d_out, uint32_t n, double openingLength, double T, double one, double zero,
+                   void* d_work, size_t workBytes, void* stream)
+	MORPH_ANY (MO_OPEN, 0, 0, openingLength)
 
 } // extern "C"

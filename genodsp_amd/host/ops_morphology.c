@@ -123,6 +123,17 @@ static void morph_apply (dspop* _op, char* vName, u32 vLen, valtype* v)
 		case M_DILATE: rc = gdsp_dilate (v, out, vLen, left, right, op->threshold, op->oneVal, op->zeroVal, st); break;
 		default:       rc = gdsp_erode  (v, out, vLen, left, right, op->threshold, op->oneVal, op->zeroVal, st); break;
 		}
+	if (rc == GDSP_EINVAL)                       /* reach beyond one LDS tile: the set as bits in HBM workspace, any length */
+		{
+		size_t bytes;  void* work = long_window_workspace (&bytes);
+		switch (op->kind)
+			{
+			case M_CLOSE:  rc = gdsp_close_any  (v, out, vLen, op->length, op->threshold, op->oneVal, op->zeroVal, work, bytes, st);  break;
+			case M_OPEN:   rc = gdsp_open_any   (v, out, vLen, op->length, op->threshold, op->oneVal, op->zeroVal, work, bytes, st);  break;
+			case M_DILATE: rc = gdsp_dilate_any (v, out, vLen, left, right, op->threshold, op->oneVal, op->zeroVal, work, bytes, st); break;
+			default:       rc = gdsp_erode_any  (v, out, vLen, left, right, op->threshold, op->oneVal, op->zeroVal, work, bytes, st); break;
+			}
+		}
 	check_gdsp (rc, _op->name);
 	flip_vector (vName);
 	}

@@ -146,6 +146,18 @@ int gdsp_close  (const double* d_in, double* d_out, uint32_t n, double closingLe
 int gdsp_open   (const double* d_in, double* d_out, uint32_t n, double openingLength,
                  double T, double one, double zero, void* stream);   /* :529-605   */
 
+/* Any length (the reference accepts any, morphology.c:696-866, :1163-1315; the tiled kernels above return GDSP_EINVAL
+ * once a window reaches beyond the 262 k bases one LDS tile can stage): the tiled kernel when it applies, otherwise
+ * the set as bits plus per-word next / previous-member tables in d_work (>= gdsp_long_window_work(n) bytes). */
+int gdsp_dilate_any (const double* d_in, double* d_out, uint32_t n, uint32_t left, uint32_t right,
+                     double T, double one, double zero, void* d_work, size_t workBytes, void* stream);
+int gdsp_erode_any  (const double* d_in, double* d_out, uint32_t n, uint32_t left, uint32_t right,
+                     double T, double one, double zero, void* d_work, size_t workBytes, void* stream);
+int gdsp_close_any  (const double* d_in, double* d_out, uint32_t n, double closingLength,
+                     double T, double one, double zero, void* d_work, size_t workBytes, void* stream);
+int gdsp_open_any   (const double* d_in, double* d_out, uint32_t n, double openingLength,
+                     double T, double one, double zero, void* d_work, size_t workBytes, void* stream);
+
 /* ---- logical.c, mask.c, add.c (in place) ---------------------------------------- */
 int gdsp_binarize     (double* d_v, uint32_t n, double T, int tiesAbove, double one, double zero,
                        void* stream);                                 /* logical.c:216-268 */
