@@ -68,9 +68,11 @@ __device__ __forceinline__ uint32_t hann_magnitude_hi (double x)
 // A tile the block sums must not touch: out[o] = sum_k taps[k] * x[first + o + k], ascending k, one fused
 // multiply-add per tap (what fir_*_kernel<.., FMA> does).  Output o = p + 256*i; results go back into the
 // LDS image like the block-sum results.  Rare (a tile holding inf / NaN / |x| >= 2^1017), so not tuned.
-__device__ __noinline__ void hann_direct_tile (double* lds, const double* __restrict__ taps, int W, int first, int nout)
+__device__ __noinline__ void hann_direct_tile (double* lds, const double* __restrict__ taps, int W, int first, int nout,
+                                               int nthreads = HN_THREADS)
 	{
 	const int p = threadIdx.x;
+	const int lastElem = nthreads * HN_G - 1;
 	double acc[HN_G];
 #pragma unroll
 	for (int i=0 ; i<HN_G ; i++) acc[i] = 0.0;
@@ -80,8 +82,8 @@ __device__ __noinline__ void hann_direct_tile (double* lds, const double* __rest
 #pragma unroll
 		for (int i=0 ; i<HN_G ; i++)
 			{
-			int e = first + p + HN_THREADS*i + k;
-			if (e > HN_ELEMS-1) e = HN_ELEMS-1;                    // (outputs past nout are computed and dropped)
+			int e = first + p + nthreads*i + k;
+			if (e > lastElem) e = lastElem;                        // (outputs past nout are computed and dropped)
 			acc[i] = __builtin_fma (w, lds[e + (e >> 4)], acc[i]);
 			}
 		}
@@ -89,7 +91,7 @@ __device__ __noinline__ void hann_direct_tile (double* lds, const double* __rest
 #pragma unroll
 	for (int i=0 ; i<HN_G ; i++)
 		{
-		const int o = p + HN_THREADS*i;
+		const int o = p + nthreads*i;
 		if (o < nout) lds[o + (o >> 4)] = acc[i];
 		}
 	__syncthreads ();
@@ -337,50 +339,61 @@ static void hann_launch (const double* d_in, double* d_out, uint32_t n, const do
 // smallest tap that goes through the block sums, and the bound of one rounding per operation
 // grows with W, which makes E ~ sqrt(0.15 W) enough (8 for W = 101, 16 for 1001, 20 for 2001);
 // E also carries the parity that keeps a tile's first element 16-byte aligned.
-#define HN_RT_MAX_NT 128
+#define HN_RT_SMALL_MAX_W 1501                                  // up to here the 256-thread form is the faster one (measured)
+#define HN_RT_MAX_NT 512
+#define HN_RT_BIG    768                                        // threads of the long-window form: 12288 staged elements, 122 KiB of LDS
 struct HannRT
 	{
 	int    DQ, DR, NT, HALO_L, HALO_R, LO, LEAD, OUT;
 	double scale;
-	double edge[24];                                               // 1 - cos(w k), k = 1..E
+	double edge[32];                                               // 1 - cos(w k), k = 1..E
 	double ownC[HN_G], ownS[HN_G];
 	double leftC[2*HN_G], leftS[2*HN_G];                           // exp(+j w (u - DM)), u = 0..15+DR
 	double demC[HN_G], demS[HN_G];                                 // exp(+j w (W-E - s))
 	};
 
-template <int E>
-__global__ __launch_bounds__(HN_THREADS)
+// THREADS = 256 stages 4096 elements (41 KiB of LDS, three workgroups per CU); windows of a thousand taps and more lose a
+// quarter to a half of such a tile to their halo and spend most of their time adding up the NT whole blocks between
+// the two ends one by one.  THREADS = 768 stages 12288 elements (122 KiB, one workgroup of twelve waves per CU; two
+// 448-thread workgroups per CU were slower at every window tried) and adds
+// the blocks between in two levels: the totals of aligned groups of 16 blocks, plus at most 15 single blocks at either
+// end of the range (additions only, as before; fewer roundings than one by one).
+template <int E, int THREADS>
+__global__ __launch_bounds__(THREADS)
 void hann_blocks_rt_kernel (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t ntiles,
                             HannRT K, const double2* __restrict__ rot, const double* __restrict__ taps, int W)
 	{
 	constexpr int NEDGE = HN_G + E - 1;
-	__shared__ __attribute__((aligned(16))) double lds[HN_THREADS * HN_PITCH];
-	__shared__ double tot[3][HN_THREADS];
-	__shared__ __attribute__((aligned(16))) uint32_t huge[HN_THREADS/64];
+	constexpr int ELEMS = THREADS * HN_G;
+	constexpr bool TWO_LEVEL = (THREADS > 256);
+	__shared__ __attribute__((aligned(16))) double lds[THREADS * HN_PITCH];
+	__shared__ double tot[3][THREADS];
+	__shared__ double grp[3][TWO_LEVEL? THREADS/16 : 1];             // totals of aligned groups of 16 blocks, in the group's own phase
+	__shared__ __attribute__((aligned(16))) uint32_t huge[16];
 
 	const uint32_t tile = gdsp_xcd_tile (blockIdx.x, ntiles);
 	const int64_t  out0 = (int64_t) tile * K.OUT;
 	const int64_t  e0   = out0 - K.LEAD;                          // first staged element (even)
 	const int      p    = threadIdx.x;
-	const bool     live = (p >= K.HALO_L) && (p < HN_THREADS - K.HALO_R);
+	const bool     live = (p >= K.HALO_L) && (p < THREADS - K.HALO_R);
 
-	if ((e0 >= 0) && (e0 + HN_ELEMS <= (int64_t) n))
+	if ((e0 >= 0) && (e0 + ELEMS <= (int64_t) n))
 		{
 		const double2* src = reinterpret_cast<const double2*> (in + e0);
 		double2 r[HN_G/2];
 #pragma unroll
-		for (int u=0 ; u<HN_G/2 ; u++) r[u] = src[u*HN_THREADS + p];
+		for (int u=0 ; u<HN_G/2 ; u++) r[u] = src[u*THREADS + p];
 #pragma unroll
 		for (int u=0 ; u<HN_G/2 ; u++)
 			{
-			const int e = 2 * (u*HN_THREADS + p);
+			const int e = 2 * (u*THREADS + p);
 			double* dst = lds + e + (e >> 4);
 			dst[0] = r[u].x;  dst[1] = r[u].y;
 			}
 		}
 	else
 		{
-		for (int e=p ; e<HN_ELEMS ; e+=HN_THREADS)
+		for (int e=p ; e<ELEMS ; e+=THREADS)
 			{
 			const int64_t g = e0 + e;
 			lds[e + (e >> 4)] = ((g >= 0) && (g < (int64_t) n))? in[g] : 0.0;
@@ -436,20 +449,64 @@ void hann_blocks_rt_kernel (const double* __restrict__ in, double* __restrict__ 
 		if ((p & 63) == 0) huge[p >> 6] = any? 1u : 0u;
 		}
 	__syncthreads ();
-	const uint4 hg     = *reinterpret_cast<const uint4*> (huge);
-	const bool  direct = ((hg.x | hg.y | hg.z | hg.w) != 0);       // uniform over the workgroup
+	if (TWO_LEVEL)
+		{
+		if (p < THREADS/16)                                        // one thread per group: its 16 blocks, each turned to the first one's phase
+			{
+			double g0 = 0.0, gr = 0.0, gi = 0.0;
+			for (int j=15 ; j>=0 ; j--)
+				{
+				const double b0 = tot[0][16*p+j], br = tot[1][16*p+j], bi = tot[2][16*p+j];
+				g0 += b0;
+				if (j == 0) { gr += br;  gi += bi; }
+				else
+					{
+					const double2 w = rot[j-1];                     // exp(-j w 16 j) is the turn from a later block back to an earlier one's
+					gr += __builtin_fma (br, w.x,   bi * w.y);      // ... so forward by j blocks is its conjugate
+					gi += __builtin_fma (bi, w.x, -(br * w.y));
+					}
+				}
+			grp[0][p] = g0;  grp[1][p] = gr;  grp[2][p] = gi;
+			}
+		__syncthreads ();
+		}
+	uint32_t anyHuge = 0;
+#pragma unroll
+	for (int w=0 ; w<THREADS/64 ; w++) anyHuge |= huge[w];
+	const bool direct = (anyHuge != 0);                            // uniform over the workgroup
 
 	// ---- phase 2: the middle stretch of one window per left end
 	if (live && !direct)
 		{
 		double T0 = 0.0, Tr = 0.0, Ti = 0.0;                       // whole blocks p-NT .. p-1
-		for (int d=K.NT ; d>=1 ; d--)
+		auto add_block = [&] (int q)                               // block q, turned from its own phase to this thread's
 			{
-			const double  b0 = tot[0][p-d], br = tot[1][p-d], bi = tot[2][p-d];
-			const double2 w  = rot[d-1];                            // exp(-j w 16 d)
+			const double  b0 = tot[0][q], br = tot[1][q], bi = tot[2][q];
+			const double2 w  = rot[p-q-1];                          // exp(-j w 16 (p-q))
 			T0 += b0;
 			Tr += __builtin_fma (br, w.x, -(bi * w.y));
 			Ti += __builtin_fma (br, w.y,   bi * w.x);
+			};
+		if (!TWO_LEVEL)
+			{ for (int d=K.NT ; d>=1 ; d--) add_block (p - d); }
+		else
+			{
+			const int first = p - K.NT;                             // blocks first .. p-1
+			const int g0 = (first + 15) >> 4, g1 = p >> 4;          // whole groups g0 .. g1-1 lie inside (if g0 < g1)
+			if (g0 >= g1) { for (int q=first ; q<p ; q++) add_block (q); }
+			else
+				{
+				for (int q=first ; q<16*g0 ; q++) add_block (q);
+				for (int g=g0 ; g<g1 ; g++)
+					{
+					const double  b0 = grp[0][g], br = grp[1][g], bi = grp[2][g];
+					const double2 w  = rot[p-16*g-1];               // a group's phase is its first block's
+					T0 += b0;
+					Tr += __builtin_fma (br, w.x, -(bi * w.y));
+					Ti += __builtin_fma (br, w.y,   bi * w.x);
+					}
+				for (int q=16*g1 ; q<p ; q++) add_block (q);
+				}
 			}
 		const double* lb = lds + (p - K.DQ) * HN_PITCH;             // block of the left ends of s >= DR
 		const double* la = lb - HN_PITCH + HN_G;                    // the block before it, indexed by u - DR < 0
@@ -474,7 +531,7 @@ void hann_blocks_rt_kernel (const double* __restrict__ in, double* __restrict__ 
 				}
 			}
 		}
-	if (direct) hann_direct_tile (lds, taps, W, K.LO, K.OUT);
+	if (direct) hann_direct_tile (lds, taps, W, K.LO, K.OUT, THREADS);
 	else
 		{
 		__syncthreads ();
@@ -491,7 +548,7 @@ void hann_blocks_rt_kernel (const double* __restrict__ in, double* __restrict__ 
 	if (out0 + K.OUT <= (int64_t) n)
 		{
 		double2* dst = reinterpret_cast<double2*> (out + out0);
-		for (int q=p ; q<K.OUT/2 ; q+=HN_THREADS)
+		for (int q=p ; q<K.OUT/2 ; q+=THREADS)
 			{
 			const int o = 2*q;
 			const double* src = lds + o + (o >> 4);
@@ -500,13 +557,13 @@ void hann_blocks_rt_kernel (const double* __restrict__ in, double* __restrict__ 
 		}
 	else
 		{
-		for (int o=p ; o<K.OUT ; o+=HN_THREADS)
+		for (int o=p ; o<K.OUT ; o+=THREADS)
 			{ if (out0 + o < (int64_t) n) out[out0 + o] = lds[o + (o >> 4)]; }
 		}
 	}
 
 // plans of the run-time kernel, cached per (device, W): the geometry and the rotation table in HBM
-struct HannPlanRT { int device;  uint32_t W;  int E;  HannRT K;  double2* d_rot; };
+struct HannPlanRT { int device;  uint32_t W;  int E;  int threads;  HannRT K;  double2* d_rot; };
 #define HN_PLAN_CACHE 32
 static HannPlanRT hannPlans[HN_PLAN_CACHE];
 static int        hannPlanLen = 0;
@@ -514,10 +571,12 @@ static std::mutex hannPlanLock;
 
 static int hann_direct_taps (uint32_t W)                            // E: enough taps, right parity, an instantiated value
 	{
-	static const int allowed[] = { 8, 9, 12, 13, 16, 17, 20, 21 };
+	// (instantiated values only: the 256-thread form needs up to 15 at W = 1501; the long-window form takes the next of 20/21, 28/29)
+	static const int small[] = { 8, 9, 12, 13, 16, 17 }, big[] = { 20, 21, 28, 29 };
 	const int H    = (int) (W - 1) / 2;
 	const int need = std::max (8, (int) ceil (sqrt (0.15 * W)));
-	for (int e : allowed) { if ((e >= need) && (((H - e) & 1) == 0)) return e; }
+	if (W <= HN_RT_SMALL_MAX_W) { for (int e : small) { if ((e >= need) && (((H - e) & 1) == 0)) return e; } }
+	else          { for (int e : big)   { if ((e >= need) && (((H - e) & 1) == 0)) return e; } }
 	return -1;
 	}
 
@@ -533,13 +592,14 @@ static int hann_plan_rt (uint32_t W, HannPlanRT** out)
 	memset (pl, 0, sizeof(*pl));
 	pl->device = device;  pl->W = W;
 	const int E = pl->E = hann_direct_taps (W);
+	const int THREADS = pl->threads = (W > HN_RT_SMALL_MAX_W)? HN_RT_BIG : HN_THREADS;   // long windows: the big tile, two-level block totals
 	const int H = (int) (W - 1) / 2, DM = (int) W - 2*E - 1, BACK = DM + E;
 	HannRT& K = pl->K;
 	K.DQ = DM / HN_G;  K.DR = DM % HN_G;  K.NT = K.DQ - 1;
 	K.HALO_L = (BACK + HN_G - 1) / HN_G;  K.HALO_R = (HN_G - 1 + E) / HN_G;
 	K.LO   = K.HALO_L * HN_G - BACK;
 	K.LEAD = K.HALO_L * HN_G - (H - E);
-	K.OUT  = (HN_THREADS - K.HALO_L - K.HALO_R) * HN_G;
+	K.OUT  = (THREADS - K.HALO_L - K.HALO_R) * HN_G;
 	const double pi = 3.14159265358979323846264;
 	const long   M  = (long) W + 1;
 	auto cs = [&] (long m, double* c, double* sn)
@@ -560,7 +620,7 @@ static int hann_plan_rt (uint32_t W, HannPlanRT** out)
 		}
 	K.scale = 0.5 / total;
 	double2 h_rot[HN_RT_MAX_NT];
-	for (int d=1 ; d<=K.NT ; d++) cs (-(long) HN_G * d, &h_rot[d-1].x, &h_rot[d-1].y);
+	for (int d=1 ; d<=K.NT+16 && d<=HN_RT_MAX_NT ; d++) cs (-(long) HN_G * d, &h_rot[d-1].x, &h_rot[d-1].y);
 	GDSP_HIP_TRY (hipMalloc ((void**) &pl->d_rot, sizeof(h_rot)));
 	GDSP_HIP_TRY (hipMemcpy (pl->d_rot, h_rot, sizeof(h_rot), hipMemcpyHostToDevice));
 	hannPlanLen++;
@@ -570,7 +630,7 @@ static int hann_plan_rt (uint32_t W, HannPlanRT** out)
 
 // 1 when GDSP_FIR_HANN has a kernel for this window
 bool gdsp_hann_blocks_available (uint32_t W)
-	{ return (W & 1) && (W >= 81) && (W <= 2001) && (hann_direct_taps (W) > 0); }   // (below ~80 taps the direct kernel is faster)
+	{ return (W & 1) && (W >= 81) && (W <= 4001) && (hann_direct_taps (W) > 0); }   // (below ~80 taps the direct kernel is faster)
 
 int gdsp_hann_blocks_apply (const double* d_in, double* d_out, uint32_t n, uint32_t W, void* stream)
 	{
@@ -586,21 +646,25 @@ int gdsp_hann_blocks_apply (const double* d_in, double* d_out, uint32_t n, uint3
 	HannPlanRT* pl = NULL;
 	int rc = hann_plan_rt (W, &pl);
 	if (rc != GDSP_OK) return rc;
-	GDSP_REQUIRE ((pl->K.DQ >= 2) && (pl->K.NT <= HN_RT_MAX_NT) && (pl->K.OUT >= 512) && ((pl->K.LEAD & 1) == 0), "window outside the block-sum kernel's range");
+	GDSP_REQUIRE ((pl->K.DQ >= 2) && (pl->K.NT + 16 <= HN_RT_MAX_NT) && (pl->K.OUT >= 512) && ((pl->K.LEAD & 1) == 0), "window outside the block-sum kernel's range");
 	const uint32_t ntiles = (uint32_t) (((uint64_t) n + pl->K.OUT - 1) / pl->K.OUT);
-#define HN_RT_LAUNCH(EE) hipLaunchKernelGGL ((hann_blocks_rt_kernel<EE>), dim3(ntiles), dim3(HN_THREADS), 0, s, d_in, d_out, n, ntiles, pl->K, pl->d_rot, d_taps, (int) W)
+#define HN_RT_SMALL(EE) hipLaunchKernelGGL ((hann_blocks_rt_kernel<EE, HN_THREADS>), dim3(ntiles), dim3(HN_THREADS), 0, s, d_in, d_out, n, ntiles, pl->K, pl->d_rot, d_taps, (int) W)
+#define HN_RT_BIGK(EE)  hipLaunchKernelGGL ((hann_blocks_rt_kernel<EE, HN_RT_BIG>),  dim3(ntiles), dim3(HN_RT_BIG),  0, s, d_in, d_out, n, ntiles, pl->K, pl->d_rot, d_taps, (int) W)
 	switch (pl->E)
 		{
-		case 8:  HN_RT_LAUNCH (8);   break;
-		case 9:  HN_RT_LAUNCH (9);   break;
-		case 12: HN_RT_LAUNCH (12);  break;
-		case 13: HN_RT_LAUNCH (13);  break;
-		case 16: HN_RT_LAUNCH (16);  break;
-		case 17: HN_RT_LAUNCH (17);  break;
-		case 20: HN_RT_LAUNCH (20);  break;
-		default: HN_RT_LAUNCH (21);  break;
+		case 8:  HN_RT_SMALL (8);  break;
+		case 9:  HN_RT_SMALL (9);  break;
+		case 12: HN_RT_SMALL (12); break;
+		case 13: HN_RT_SMALL (13); break;
+		case 16: HN_RT_SMALL (16); break;
+		case 17: HN_RT_SMALL (17); break;
+		case 20: HN_RT_BIGK (20);  break;
+		case 21: HN_RT_BIGK (21);  break;
+		case 28: HN_RT_BIGK (28);  break;
+		default: HN_RT_BIGK (29);  break;
 		}
-#undef HN_RT_LAUNCH
+#undef HN_RT_SMALL
+#undef HN_RT_BIGK
 	GDSP_LAUNCH_CHECK ();
 	return GDSP_OK;
 	}

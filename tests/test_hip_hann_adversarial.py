@@ -37,16 +37,16 @@ def test_impulse_at_every_base_of_ten_tiles_w101(gd):
     assert worst > 0.0            # (the comparison is not vacuous: block sums do differ from the reference's bits)
 
 
-@pytest.mark.parametrize("W", [81, 201, 427, 1001, 2001])
+@pytest.mark.parametrize("W", [81, 201, 427, 1001, 1501, 1503, 2001, 4001])
 def test_impulse_trains_runtime_windows(W, gd):
     spacing = W + 18 + (W + 18) % 2 + 1                       # odd, > W + 16
-    n = 3 * 4096 + 55
+    n = 3 * 12288 + 55
     for s, x in hc.impulse_trains(W, n, spacing, range(0, spacing, 5), seed=W):
         r, kinds = hc.worst_ratio(hann(gd, x, W), cpu.smooth(x, W), x, W)
         assert kinds and r <= 1.0, (W, s, r)
 
 
-@pytest.mark.parametrize("W", [101, 301, 1001])
+@pytest.mark.parametrize("W", [101, 301, 1001, 3001])
 def test_wide_dynamic_range_inside_every_window(W, gd):
     for seed in range(3):
         x = hc.wide_dynamic_range(30011, seed)
@@ -61,7 +61,7 @@ def test_subnormal_inputs(gd):
         assert kinds and r <= 1.0, (W, r)
 
 
-@pytest.mark.parametrize("W", [101, 201])
+@pytest.mark.parametrize("W", [101, 201, 1001])
 def test_nonfinite_and_huge_inputs_follow_direct_evaluation(W, gd):
     n = 5 * hc.TILE_OUT_W101 + 123
     clean = None

@@ -145,13 +145,13 @@ def test_smooth_hann_block_sums_within_one_rounding_per_op(n, kind, gd):
         assert np.all(got[sel][~ok] == 0.0)
 
 
-@pytest.mark.parametrize("W", [81, 83, 85, 99, 103, 201, 301, 427, 501, 1001, 1999, 2001])
+@pytest.mark.parametrize("W", [81, 83, 85, 99, 103, 201, 301, 427, 501, 1001, 1499, 1501, 1503, 1505, 1999, 2001, 2999, 3001, 3999, 4001])
 def test_smooth_hann_any_window_within_one_rounding_per_op(W, gd):
     """Windows of 81..2001 taps go through the run-time form of the block-sum kernel (direct taps at the ends
     growing like sqrt(0.15 W)); same bar as W=101, sizes around its tile seams."""
     rng = np.random.default_rng(W)
     taps = cpu.hann_window(W)
-    for kind, n in (("depth", 20011), ("real", 9000), ("noise", 4096), ("real", W // 2 + 3), ("depth", 1)):
+    for kind, n in (("depth", 20011), ("real", 9000), ("noise", 4096), ("real", W // 2 + 3), ("depth", 1), ("real", 60013)):
         x = _signal(kind, n, rng)
         if kind == "depth":
             x[(np.arange(n) // 900) % 3 == 1] = 0.0          # islands: windows that only touch the small end taps
@@ -180,7 +180,7 @@ def test_smooth_hann_bound_is_relative_to_the_signal(factor, gd):
 
 def test_smooth_hann_mode_other_windows_fall_back_to_fma(gd):
     x = _signal("real", 30000, np.random.default_rng(3))
-    for W in (21, 79, 2003):
+    for W in (21, 79, 4003):
         a = gd.smooth(gd.DeviceVector.from_numpy(x), W, mode=gd.FIR_HANN).numpy()
         b = gd.smooth(gd.DeviceVector.from_numpy(x), W, mode=gd.FIR_FMA).numpy()
         assert bits_equal(a, b)
