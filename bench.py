@@ -378,9 +378,23 @@ def measured_traffic(kernel, algorithmic_bytes_per_launch):
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(path):
         return None
-    with open(path) as f:
-        ratio = json.load(f).get("kernels", {}).get(kernel, {}).get("hbm_bytes_over_algorithmic")
+    k = _traffic_entry(path, kernel)
+    ratio = None if k is None else k.get("hbm_bytes_over_algorithmic")
     return None if ratio is None else int(ratio * algorithmic_bytes_per_launch)
+
+
+def _traffic_entry(path, kernel):
+    """the entry of profiles/traffic.json for this kernel: same name up to blanks, else the first one it is a prefix of"""
+    with open(path) as f:
+        kernels = json.load(f).get("kernels", {})
+    squeeze = lambda x: x.replace(" ", "")
+    for name, entry in kernels.items():
+        if squeeze(name) == squeeze(kernel):
+            return entry
+    for name, entry in kernels.items():
+        if squeeze(name).startswith(squeeze(kernel)):
+            return entry
+    return None
 
 
 def traffic_source(kernel):
@@ -388,8 +402,7 @@ def traffic_source(kernel):
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(path):
         return None
-    with open(path) as f:
-        k = json.load(f).get("kernels", {}).get(kernel)
+    k = _traffic_entry(path, kernel)
     return None if k is None else {"source": k.get("source"), "library": k.get("library")}
 
 
