@@ -15,6 +15,7 @@
 //     the reference's own accumulated rounding error (tests state the bound).
 // All three are HBM-bound (16 B/base).
 
+#include <stdlib.h>
 #include "gdsp_common.h"
 
 #define SU_THREADS 256
@@ -582,6 +583,14 @@ void cumsum_apply_kernel (double* __restrict__ v, uint32_t n, uint32_t nchunks, 
 			{ if (s + p < (int64_t) n) v[s+p] = off + csLds[p]; }
 		}
 	}
+
+// (A single pass -- 16 B/base instead of 24 -- was built twice in round 2 and dropped.  It needs every chunk's prefix
+// while the chunk is still on chip, i.e. a decoupled look-back; to keep the rounding independent of timing the
+// association was fixed by the chunk index (aggregates of aligned groups only, published as one 8-byte word that is
+// value and flag, waited for in ticket order).  Bit-identical results, but each hop through an agent-scope atomic
+// store and its polling loads costs microseconds on this part: a workgroup per 4096-base chunk with a binary tree took
+// 1.41 ms per 249 Mbp, a wave per 1024-base chunk with a 32-ary tree 2.83 ms, against 1.05 ms for the three launches
+// below; with the waits removed (wrong sums) the first form ran in 0.81 ms, so even free waits would buy little.)
 
 extern "C" {
 
