@@ -34,6 +34,10 @@ void gdsp_set_error (const char* fmt, ...);
 bool gdsp_hann_blocks_available (uint32_t W);
 int  gdsp_hann_blocks_apply (const double* d_in, double* d_out, uint32_t n, uint32_t W, void* stream);
 
+// gdsp_hann_far.hip: the same for windows longer than one LDS tile can hold (3201 .. 50001 taps), block totals in HBM
+bool gdsp_hann_far_available (uint32_t W);
+int  gdsp_hann_far_apply (const double* d_in, double* d_out, uint32_t n, uint32_t W, void* stream);
+
 // gdsp_fir.hip: the device copy of the reference's Hann taps for W (cached per device, never freed)
 int  gdsp_smooth_taps_device (uint32_t W, const double** d_taps);
 

@@ -458,6 +458,7 @@ int gdsp_smooth (const double* d_in, double* d_out, uint32_t n, uint32_t W, int 
 		GDSP_REQUIRE ((W >= 3) && (W & 1), "W must be odd and >= 3");
 		GDSP_REQUIRE (W <= 50001, "W exceeds 50001");
 		if (gdsp_hann_blocks_available (W)) return gdsp_hann_blocks_apply (d_in, d_out, n, W, stream);
+		if (gdsp_hann_far_available (W))    return gdsp_hann_far_apply (d_in, d_out, n, W, stream);
 		mode = GDSP_FIR_FMA;                                   // same tolerance class, direct evaluation
 		}
 	gdsp_fir_plan* plan = NULL;

@@ -38,7 +38,9 @@ extern "C" {
  * the reference, like FMA, and no further from the exact value than the reference is.
  * Unlike EXACT and FMA it is not shift invariant (a flat input gives outputs that differ in
  * their last bits), so gdsp_smooth_local_extrema evaluates HANN as FMA.
- * Odd windows of 81..2001 taps have such a kernel (W=101 a dedicated one); others are evaluated as FMA. */
+ * Odd windows of 81..50001 taps have such a kernel (W=101 a dedicated one; beyond 4001 taps the block totals go through HBM,
+ * gdsp_hann_far.hip); shorter ones are evaluated as FMA.  A tile that holds inf / NaN / a magnitude >= 2^1017 is evaluated tap by
+ * tap (FMA's bits there), so the mode differs from the reference by rounding only on any input. */
 #define GDSP_FIR_HANN  2
 
 /* interval overlap operators, values as genodsp_interface.h:157-159 */

@@ -89,3 +89,48 @@ def test_localmin_then_smooth_hann(gd):
     want = cpu.smooth(y, 101)
     r, kinds = hc.worst_ratio(got, want, y, 101)
     assert kinds and r <= 1.0, r
+
+
+# ---- windows beyond one LDS tile: block totals in HBM (gdsp_hann_far.hip), 3201 .. 50001 taps
+
+@pytest.mark.parametrize("W", [4003, 4005, 5001, 9999, 20001, 50001])
+def test_far_windows_within_one_rounding_per_op(W, gd):
+    rng = np.random.default_rng(W)
+    for kind, n in (("real", 70001), ("noise", 3 * 3072 + 17), ("depth", 1), ("real", W // 2 + 3), ("islands", 140000)):
+        if kind == "real":
+            x = cpu.synth_coverage(20240611, 3, 0, n, 1)
+        elif kind == "depth":
+            x = cpu.synth_coverage(20240611, 3, 0, n, 0)
+        elif kind == "noise":
+            x = rng.standard_normal(n) * 5
+        else:
+            x = cpu.synth_coverage(20240611, 3, 0, n, 0)
+            x[(np.arange(n) // 9000) % 3 == 1] = 0.0
+        r, kinds = hc.worst_ratio(hann(gd, x, W), cpu.smooth(x, W), x, W)
+        assert kinds and r <= 1.0, (W, kind, n, r)
+
+
+@pytest.mark.parametrize("W", [4003, 20001])
+def test_far_windows_impulse_trains(W, gd):
+    spacing = W + 18 + (W + 18) % 2 + 1
+    n = 8 * 3072 + 55 + 2 * W
+    for s, x in hc.impulse_trains(W, n, spacing, range(0, spacing, max(1, spacing // 97)), seed=W):
+        r, kinds = hc.worst_ratio(hann(gd, x, W), cpu.smooth(x, W), x, W)
+        assert kinds and r <= 1.0, (W, s, r)
+
+
+def test_far_windows_wide_dynamic_range_and_nonfinite(gd):
+    W = 5001
+    for seed in range(2):
+        x = hc.wide_dynamic_range(40011, seed)
+        r, kinds = hc.worst_ratio(hann(gd, x, W), cpu.smooth(x, W), x, W)
+        assert kinds and r <= 1.0, (seed, r)
+    n = 9 * 3072 + 123
+    for name, x in hc.nonfinite_cases(n, 4):
+        got = hann(gd, x, W)
+        fma = gd.smooth(gd.DeviceVector.from_numpy(x), W, mode=gd.FIR_FMA).numpy()
+        r, kinds = hc.worst_ratio(got, cpu.smooth(x, W), x, W)
+        assert kinds and r <= 1.0, (name, r)
+        with np.errstate(all="ignore"):
+            touched = cpu.fir((~(np.abs(x) < 2.0 ** 1017)).astype(np.float64), np.ones(W)) > 0
+        assert touched.any() and bits_equal(got[touched], fma[touched]), name

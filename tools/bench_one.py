@@ -35,6 +35,9 @@ OPS = {
     "smooth_hann501": (None, lambda: gd.smooth(real, 501, out=b, mode=gd.FIR_HANN, stream=s)),
     "smooth_hann1001": (None, lambda: gd.smooth(real, 1001, out=b, mode=gd.FIR_HANN, stream=s)),
     "smooth_hann2001": (None, lambda: gd.smooth(real, 2001, out=b, mode=gd.FIR_HANN, stream=s)),
+    "smooth_hann3201": (None, lambda: gd.smooth(real, 3201, out=b, mode=gd.FIR_HANN, stream=s)),
+    "smooth_hann4001": (None, lambda: gd.smooth(real, 4001, out=b, mode=gd.FIR_HANN, stream=s)),
+    "smooth_hann4003": (None, lambda: gd.smooth(real, 4003, out=b, mode=gd.FIR_HANN, stream=s)),
     "smooth_hann5001": (None, lambda: gd.smooth(real, 5001, out=b, mode=gd.FIR_HANN, stream=s)),
     "smooth_hann20001": (None, lambda: gd.smooth(real, 20001, out=b, mode=gd.FIR_HANN, stream=s)),
     "smooth_hann50001": (None, lambda: gd.smooth(real, 50001, out=b, mode=gd.FIR_HANN, stream=s)),

@@ -48,6 +48,8 @@ RUN = {
     "smooth_hann": lambda: gd.smooth(real, 101, out=b, mode=gd.FIR_HANN),
     "smooth_hann1001": lambda: gd.smooth(real, 1001, out=b, mode=gd.FIR_HANN),
     "smooth_hann2001": lambda: gd.smooth(real, 2001, out=b, mode=gd.FIR_HANN),
+    "smooth_hann5001": lambda: gd.smooth(real, 5001, out=b, mode=gd.FIR_HANN),
+    "smooth_hann50001": lambda: gd.smooth(real, 50001, out=b, mode=gd.FIR_HANN),
     "peaks_exact": lambda: gd.smooth_local_extrema(real, 101, 11, True, 0.0, out=b, mode=gd.FIR_EXACT),
     "peaks_fma": lambda: gd.smooth_local_extrema(real, 101, 11, True, 0.0, out=b, mode=gd.FIR_FMA),
     "morph_fused": lambda: gd.dilate_erode(depth, l, r, l, r, binarize=(0.0, False, 1.0, 0.0), out=b),
