@@ -1176,6 +1176,15 @@ static void out_line (FILE* f, const char* chrom, int start, int end, int withVa
 	if (outAt - outBuf > OUTBUF_BYTES) out_flush (f);
 	}
 
+typedef struct reportbuf
+	{
+	u32*     d_count;  void* d_work;
+	u32      cap;
+	u32     *d_start, *d_end, *h_start, *h_end;
+	valtype *d_val, *h_val;
+	} reportbuf;
+static reportbuf reportBufs[64];
+
 /* report_intervals, genodsp.c:1561-1691: runs come from the device
  * (gdsp_report_runs), the NA bookkeeping and formatting are done here */
 void report_intervals (FILE* f, int precision, int noValues, int collapse, int uncovered, int origin1)
@@ -1186,34 +1195,49 @@ void report_intervals (FILE* f, int precision, int noValues, int collapse, int u
 		{
 		if (trackOperations) tracking_report ("output(%s)\n", s->chrom);
 		select_device_of (s);
-		void* stream = op_stream ();
-		u32   count = 0;
-		u32*  d_count;  void* d_work;
-		check_gdsp (gdsp_malloc ((void**) &d_count, 16), "allocate run count");
-		check_gdsp (gdsp_malloc (&d_work, gdsp_report_runs_work (s->length)), "allocate run workspace");
-		check_gdsp (gdsp_report_runs (s->valVector, s->length, collapse, uncovered, NULL, NULL, NULL, 0, d_count, d_work, stream), "count runs");
-		check_gdsp (gdsp_memcpy_d2h (&count, d_count, sizeof(u32), stream), "fetch run count");
-		check_gdsp (gdsp_stream_sync (stream), "synchronise");
-
-		u32 *runStart = NULL, *runEnd = NULL;  valtype* runVal = NULL;
+		void*      stream = op_stream ();
+		reportbuf* rb     = &reportBufs[currentDevice];
+		u32        count  = 0;
+		/* per device, kept for the run: the count word, the workspace (longest local chromosome), and run arrays that
+		 * only grow.  One pass finds and writes the runs when they fit what is there (count + scan + write = 16 B/base);
+		 * only a chromosome with more runs than any before it costs a second call. */
+		if (rb->d_count == NULL)
+			{
+			check_gdsp (gdsp_malloc ((void**) &rb->d_count, 16), "allocate run count");
+			check_gdsp (gdsp_malloc (&rb->d_work, gdsp_report_runs_work (devs[currentDevice].maxLength)), "allocate run workspace");
+			}
+		for (int attempt=0 ; attempt<2 ; attempt++)
+			{
+			if (rb->cap < ((attempt == 0)? 1u << 16 : count))
+				{
+				u32 want = (attempt == 0)? 1u << 16 : count + count/8 + 1024;
+				if (rb->d_start != NULL)
+					{
+					gdsp_free (rb->d_start);  gdsp_free (rb->d_end);  gdsp_free (rb->d_val);
+					gdsp_host_free (rb->h_start);  gdsp_host_free (rb->h_end);  gdsp_host_free (rb->h_val);
+					}
+				check_gdsp (gdsp_malloc ((void**) &rb->d_start, (size_t) want * sizeof(u32)), "allocate runs");
+				check_gdsp (gdsp_malloc ((void**) &rb->d_end,   (size_t) want * sizeof(u32)), "allocate runs");
+				check_gdsp (gdsp_malloc ((void**) &rb->d_val,   (size_t) want * sizeof(valtype)), "allocate runs");
+				check_gdsp (gdsp_host_alloc ((void**) &rb->h_start, (size_t) want * sizeof(u32)), "allocate runs");
+				check_gdsp (gdsp_host_alloc ((void**) &rb->h_end,   (size_t) want * sizeof(u32)), "allocate runs");
+				check_gdsp (gdsp_host_alloc ((void**) &rb->h_val,   (size_t) want * sizeof(valtype)), "allocate runs");
+				rb->cap = want;
+				}
+			check_gdsp (gdsp_report_runs (s->valVector, s->length, collapse, uncovered, rb->d_start, rb->d_end, rb->d_val, rb->cap,
+			                              rb->d_count, rb->d_work, stream), "find runs");
+			check_gdsp (gdsp_memcpy_d2h (&count, rb->d_count, sizeof(u32), stream), "fetch run count");
+			check_gdsp (gdsp_stream_sync (stream), "synchronise");
+			if (count <= rb->cap) break;                               /* (else: the arrays hold only the first cap runs) */
+			}
+		u32 *runStart = rb->h_start, *runEnd = rb->h_end;  valtype* runVal = rb->h_val;
 		if (count != 0)
 			{
-			u32 *d_s, *d_e;  valtype* d_v;
-			check_gdsp (gdsp_malloc ((void**) &d_s, (size_t) count * sizeof(u32)), "allocate runs");
-			check_gdsp (gdsp_malloc ((void**) &d_e, (size_t) count * sizeof(u32)), "allocate runs");
-			check_gdsp (gdsp_malloc ((void**) &d_v, (size_t) count * sizeof(valtype)), "allocate runs");
-			check_gdsp (gdsp_report_runs (s->valVector, s->length, collapse, uncovered, d_s, d_e, d_v, count, d_count, d_work, stream), "find runs");
-			runStart = (u32*) malloc ((size_t) count * sizeof(u32));
-			runEnd   = (u32*) malloc ((size_t) count * sizeof(u32));
-			runVal   = (valtype*) malloc ((size_t) count * sizeof(valtype));
-			if ((runStart == NULL) || (runEnd == NULL) || (runVal == NULL)) { fprintf (stderr, "out of memory for output runs\n");  exit (EXIT_FAILURE); }
-			check_gdsp (gdsp_memcpy_d2h (runStart, d_s, (size_t) count * sizeof(u32), stream), "fetch runs");
-			check_gdsp (gdsp_memcpy_d2h (runEnd,   d_e, (size_t) count * sizeof(u32), stream), "fetch runs");
-			check_gdsp (gdsp_memcpy_d2h (runVal,   d_v, (size_t) count * sizeof(valtype), stream), "fetch runs");
+			check_gdsp (gdsp_memcpy_d2h (runStart, rb->d_start, (size_t) count * sizeof(u32), stream), "fetch runs");
+			check_gdsp (gdsp_memcpy_d2h (runEnd,   rb->d_end,   (size_t) count * sizeof(u32), stream), "fetch runs");
+			check_gdsp (gdsp_memcpy_d2h (runVal,   rb->d_val,   (size_t) count * sizeof(valtype), stream), "fetch runs");
 			check_gdsp (gdsp_stream_sync (stream), "synchronise");
-			gdsp_free (d_s);  gdsp_free (d_e);  gdsp_free (d_v);
 			}
-		gdsp_free (d_count);  gdsp_free (d_work);
 
 		u32 prevOutputEnd = 0;
 		for (u32 r=0 ; r<count ; r++)
@@ -1227,7 +1251,6 @@ void report_intervals (FILE* f, int precision, int noValues, int collapse, int u
 		if ((uncovered == uncovered_NA) && (s->start + s->length != prevOutputEnd))
 			out_line (f, s->chrom, (int) (prevOutputEnd+o), (int) (s->start + s->length), false, 0.0, 0, true);
 		out_flush (f);
-		free (runStart);  free (runEnd);  free (runVal);
 		}
 	if (trackOperations) tracking_report ("output(--done--)\n");
 	}
