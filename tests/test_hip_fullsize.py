@@ -191,3 +191,44 @@ def test_clump_full_chromosome(gd, depth):
     del want
     got = gd.clump(depth.copy(), T, N // 50, False, 1.0, 0.0).numpy()            # --length=CL/50
     assert bits_equal(got, cpu.clump(x, T, N // 50, False))
+
+
+# ---------------------------------------------------------------- round 2: forms that only exist beyond one LDS tile ----
+
+def test_smooth_hann_far_windows_full_chromosome(gd, real):
+    """`smooth --smooth=hann` with 20 001 taps (block totals in three HBM levels, gdsp_hann_far.hip) over the whole
+    chromosome: stretches at both ends, at the 3072-output tile seams of pass B and at random places recomputed by the
+    oracle from the regenerated signal, inside the one-rounding-per-operation bound."""
+    W, half, m = 20001, 10000, 1500
+    rng = np.random.default_rng(21)
+    out = gd.smooth(real, W, mode=gd.FIR_HANN)
+    taps = cpu.hann_window(W)
+    seams = [3072 * 40000 - (half - 17) - 700, 3072 * 1 - (half - 17), 4096 * 30000 - 700]
+    for s in [0, N - m] + [max(0, x) for x in seams] + [int(x) for x in rng.integers(0, N - m, 12)]:
+        x, left, right = regenerate(1, s, m, half)
+        want = cpu.smooth(x, W)[left:left + m]
+        bound = W * 2.0 ** -52 * cpu.fir(np.abs(x), taps)[left:left + m]
+        got = fetch(out, s, m)
+        assert np.all(np.abs(got - want) <= bound), (s, float(np.max(np.abs(got - want) / bound)))
+
+
+def test_morphology_any_reach_full_chromosome(gd, depth):
+    """dilate / erode reaching 300 000 bases and close / open 300 000 (bits and per-word member tables in HBM workspace)
+    on the whole chromosome against the oracle, bit for bit.  The depth signal is thinned first so that sets, gaps and
+    runs of every length up to several times the reach occur."""
+    x = depth.numpy()
+    rng = np.random.default_rng(22)
+    pos = 0
+    while pos < N:                                                  # blank out stretches of 1 k .. 900 k bases
+        gap = int(rng.choice([1000, 40000, 299999, 300001, 900000]))
+        keep = int(rng.choice([500, 150000, 300000, 700000]))
+        x[pos:pos + gap] = 0.0
+        pos += gap + keep
+    d = gd.DeviceVector.from_numpy(x)
+    reach = 300000
+    left, right = gd.split_length(reach)
+    for name, got, want in (("dilate", gd.dilate(d, left, right), cpu.dilate(x, left, right)),
+                            ("erode", gd.erode(d, left, right), cpu.erode(x, left, right)),
+                            ("close", gd.close(d, reach), cpu.close(x, reach)),
+                            ("open", gd.open_(d, reach), cpu.open_(x, reach))):
+        assert bits_equal(got.numpy(), want), name
