@@ -344,7 +344,7 @@ static void hann_launch (const double* d_in, double* d_out, uint32_t n, const do
 #define HN_RT_BIG    768                                        // threads of the long-window form: 12288 staged elements, 122 KiB of LDS
 struct HannRT
 	{
-	int    DQ, DR, NT, HALO_L, HALO_R, LO, LEAD, OUT;
+	int    DQ, DR, NT, HALO_L, HALO_R, LO, LEAD, OUT, SEG;
 	double scale;
 	double edge[32];                                               // 1 - cos(w k), k = 1..E
 	double ownC[HN_G], ownS[HN_G];
@@ -365,10 +365,10 @@ void hann_blocks_rt_kernel (const double* __restrict__ in, double* __restrict__ 
 	{
 	constexpr int NEDGE = HN_G + E - 1;
 	constexpr int ELEMS = THREADS * HN_G;
-	constexpr bool TWO_LEVEL = (THREADS > 256);
 	__shared__ __attribute__((aligned(16))) double lds[THREADS * HN_PITCH];
-	__shared__ double tot[3][THREADS];
-	__shared__ double grp[3][TWO_LEVEL? THREADS/16 : 1];             // totals of aligned groups of 16 blocks, in the group's own phase
+	__shared__ double tot[3][THREADS];                                // the blocks of p's segment up to and including p, in p's phase
+	constexpr bool SCAN = (THREADS > 256);                            // the long-window form scans its block totals; the 256-thread form walks them
+	__shared__ double vsf[3][SCAN? THREADS : 1];                      // the blocks of p's segment from p on, in p's phase
 	__shared__ __attribute__((aligned(16))) uint32_t huge[16];
 
 	const uint32_t tile = gdsp_xcd_tile (blockIdx.x, ntiles);
@@ -444,32 +444,31 @@ void hann_blocks_rt_kernel (const double* __restrict__ in, double* __restrict__ 
 			ai  = __builtin_fma (x, K.ownS[u], ai);
 			P0[u] = a0;  Pr[u] = ar;  Pi[u] = ai;
 			}
-		tot[0][p] = a0;  tot[1][p] = ar;  tot[2][p] = ai;
-		const bool any = (__builtin_amdgcn_ballot_w64 (big >= HN_HUGE_HI) != 0);   // the 256 blocks are the whole tile
+		// The whole blocks between a window's two ends, p-NT .. p-1, are a run of NT consecutive block totals.  Cut the
+		// tile's blocks into segments of SEG = 32: a run of NT >= SEG blocks is the tail of its
+		// first segment + whole segments + the head of its last one.  Heads and tails come from two scans inside the
+		// segments, done with wave shuffles right here (five steps each way, each step's rotation a constant of W),
+		// so the walk over NT blocks of round 1 -- three LDS reads and a rotation per block -- becomes at most five
+		// rotated terms per thread.  Additions only, as before.
+		double i0 = a0, ir = ar, ii = ai, v0 = a0, vr = ar, vi = ai;
+		if (SCAN && (K.SEG != 0))
+			{
+			const int inSeg = p & (K.SEG - 1);
+			for (int d=1 ; d<K.SEG ; d*=2)
+				{
+				const double2 w  = rot[d-1];                        // exp(-j w 16 d)
+				const double  u0 = __shfl_up (i0, d, 64), ur = __shfl_up (ir, d, 64), ui = __shfl_up (ii, d, 64);
+				if (inSeg >= d) { i0 += u0;  ir += __builtin_fma (ur, w.x, -(ui * w.y));  ii += __builtin_fma (ur, w.y, ui * w.x); }
+				const double  d0 = __shfl_down (v0, d, 64), dr = __shfl_down (vr, d, 64), di = __shfl_down (vi, d, 64);
+				if (inSeg + d < K.SEG) { v0 += d0;  vr += __builtin_fma (dr, w.x, di * w.y);  vi += __builtin_fma (di, w.x, -(dr * w.y)); }
+				}
+			vsf[0][p] = v0;  vsf[1][p] = vr;  vsf[2][p] = vi;
+			}
+		tot[0][p] = i0;  tot[1][p] = ir;  tot[2][p] = ii;           // (SEG == 0: the block's own totals, for the walk)
+		const bool any = (__builtin_amdgcn_ballot_w64 (big >= HN_HUGE_HI) != 0);   // the blocks are the whole tile
 		if ((p & 63) == 0) huge[p >> 6] = any? 1u : 0u;
 		}
 	__syncthreads ();
-	if (TWO_LEVEL)
-		{
-		if (p < THREADS/16)                                        // one thread per group: its 16 blocks, each turned to the first one's phase
-			{
-			double g0 = 0.0, gr = 0.0, gi = 0.0;
-			for (int j=15 ; j>=0 ; j--)
-				{
-				const double b0 = tot[0][16*p+j], br = tot[1][16*p+j], bi = tot[2][16*p+j];
-				g0 += b0;
-				if (j == 0) { gr += br;  gi += bi; }
-				else
-					{
-					const double2 w = rot[j-1];                     // exp(-j w 16 j) is the turn from a later block back to an earlier one's
-					gr += __builtin_fma (br, w.x,   bi * w.y);      // ... so forward by j blocks is its conjugate
-					gi += __builtin_fma (bi, w.x, -(br * w.y));
-					}
-				}
-			grp[0][p] = g0;  grp[1][p] = gr;  grp[2][p] = gi;
-			}
-		__syncthreads ();
-		}
 	uint32_t anyHuge = 0;
 #pragma unroll
 	for (int w=0 ; w<THREADS/64 ; w++) anyHuge |= huge[w];
@@ -479,34 +478,24 @@ void hann_blocks_rt_kernel (const double* __restrict__ in, double* __restrict__ 
 	if (live && !direct)
 		{
 		double T0 = 0.0, Tr = 0.0, Ti = 0.0;                       // whole blocks p-NT .. p-1
-		auto add_block = [&] (int q)                               // block q, turned from its own phase to this thread's
+		auto add_turned = [&] (const double* a0p, const double* arp, const double* aip, int q, int behind)   // entry q, `behind` blocks behind this thread's block
 			{
-			const double  b0 = tot[0][q], br = tot[1][q], bi = tot[2][q];
-			const double2 w  = rot[p-q-1];                          // exp(-j w 16 (p-q))
+			const double  b0 = a0p[q], br = arp[q], bi = aip[q];
+			const double2 w  = rot[behind-1];                       // exp(-j w 16 behind)
 			T0 += b0;
 			Tr += __builtin_fma (br, w.x, -(bi * w.y));
 			Ti += __builtin_fma (br, w.y,   bi * w.x);
 			};
-		if (!TWO_LEVEL)
-			{ for (int d=K.NT ; d>=1 ; d--) add_block (p - d); }
+		if (!SCAN || (K.SEG == 0))
+			{ for (int d=K.NT ; d>=1 ; d--) add_turned (tot[0], tot[1], tot[2], p - d, d); }
 		else
 			{
-			const int first = p - K.NT;                             // blocks first .. p-1
-			const int g0 = (first + 15) >> 4, g1 = p >> 4;          // whole groups g0 .. g1-1 lie inside (if g0 < g1)
-			if (g0 >= g1) { for (int q=first ; q<p ; q++) add_block (q); }
-			else
-				{
-				for (int q=first ; q<16*g0 ; q++) add_block (q);
-				for (int g=g0 ; g<g1 ; g++)
-					{
-					const double  b0 = grp[0][g], br = grp[1][g], bi = grp[2][g];
-					const double2 w  = rot[p-16*g-1];               // a group's phase is its first block's
-					T0 += b0;
-					Tr += __builtin_fma (br, w.x, -(bi * w.y));
-					Ti += __builtin_fma (br, w.y,   bi * w.x);
-					}
-				for (int q=16*g1 ; q<p ; q++) add_block (q);
-				}
+			const int a = p - K.NT, b = p - 1;                      // the run of blocks
+			const int sh = (K.SEG == 32)? 5 : 4;
+			const int sa = a >> sh, sb = b >> sh;
+			add_turned (vsf[0], vsf[1], vsf[2], a, K.NT);           // the tail of the first segment, from block a on
+			for (int sg=sa+1 ; sg<sb ; sg++) add_turned (vsf[0], vsf[1], vsf[2], sg * K.SEG, p - sg * K.SEG);   // whole segments, in their first block's phase
+			if (sb != sa) add_turned (tot[0], tot[1], tot[2], b, 1);     // the head of the last one, up to block b
 			}
 		const double* lb = lds + (p - K.DQ) * HN_PITCH;             // block of the left ends of s >= DR
 		const double* la = lb - HN_PITCH + HN_G;                    // the block before it, indexed by u - DR < 0
@@ -600,6 +589,7 @@ static int hann_plan_rt (uint32_t W, HannPlanRT** out)
 	K.LO   = K.HALO_L * HN_G - BACK;
 	K.LEAD = K.HALO_L * HN_G - (H - E);
 	K.OUT  = (THREADS - K.HALO_L - K.HALO_R) * HN_G;
+	K.SEG  = ((THREADS > HN_THREADS) && (K.NT >= 64))? 32 : 0;     // segments of the block scans (the long-window form only: below ~1500 taps walking the blocks is as fast and the scans' registers cost the 256-thread form a workgroup per CU)
 	const double pi = 3.14159265358979323846264;
 	const long   M  = (long) W + 1;
 	auto cs = [&] (long m, double* c, double* sn)
@@ -620,7 +610,7 @@ static int hann_plan_rt (uint32_t W, HannPlanRT** out)
 		}
 	K.scale = 0.5 / total;
 	double2 h_rot[HN_RT_MAX_NT];
-	for (int d=1 ; d<=K.NT+16 && d<=HN_RT_MAX_NT ; d++) cs (-(long) HN_G * d, &h_rot[d-1].x, &h_rot[d-1].y);
+	for (int d=1 ; d<=K.NT+40 && d<=HN_RT_MAX_NT ; d++) cs (-(long) HN_G * d, &h_rot[d-1].x, &h_rot[d-1].y);
 	GDSP_HIP_TRY (hipMalloc ((void**) &pl->d_rot, sizeof(h_rot)));
 	GDSP_HIP_TRY (hipMemcpy (pl->d_rot, h_rot, sizeof(h_rot), hipMemcpyHostToDevice));
 	hannPlanLen++;
@@ -646,7 +636,7 @@ int gdsp_hann_blocks_apply (const double* d_in, double* d_out, uint32_t n, uint3
 	HannPlanRT* pl = NULL;
 	int rc = hann_plan_rt (W, &pl);
 	if (rc != GDSP_OK) return rc;
-	GDSP_REQUIRE ((pl->K.DQ >= 2) && (pl->K.NT + 16 <= HN_RT_MAX_NT) && (pl->K.OUT >= 512) && ((pl->K.LEAD & 1) == 0), "window outside the block-sum kernel's range");
+	GDSP_REQUIRE ((pl->K.DQ >= 2) && (pl->K.NT + 40 <= HN_RT_MAX_NT) && (pl->K.OUT >= 512) && ((pl->K.LEAD & 1) == 0), "window outside the block-sum kernel's range");
 	const uint32_t ntiles = (uint32_t) (((uint64_t) n + pl->K.OUT - 1) / pl->K.OUT);
 #define HN_RT_SMALL(EE) hipLaunchKernelGGL ((hann_blocks_rt_kernel<EE, HN_THREADS>), dim3(ntiles), dim3(HN_THREADS), 0, s, d_in, d_out, n, ntiles, pl->K, pl->d_rot, d_taps, (int) W)
 #define HN_RT_BIGK(EE)  hipLaunchKernelGGL ((hann_blocks_rt_kernel<EE, HN_RT_BIG>),  dim3(ntiles), dim3(HN_RT_BIG),  0, s, d_in, d_out, n, ntiles, pl->K, pl->d_rot, d_taps, (int) W)
