@@ -221,6 +221,8 @@ void window_sum_tile_kernel (double* __restrict__ v, uint32_t n, uint32_t W, uin
 	extern __shared__ __attribute__((aligned(16))) double suLds[];
 	const uint32_t pitch = W | 1;                         // odd
 	double*        res   = suLds + (size_t) K * pitch;    // K results
+	__shared__ uint32_t inOrder;                          // windows (bit w) that have to be added in ascending order
+	if (threadIdx.x == 0) inOrder = 0;
 	const uint32_t tile  = gdsp_xcd_tile (blockIdx.x, ntiles);
 	const uint64_t base  = (uint64_t) tile * K * W;
 	const uint32_t span  = (uint32_t) ((base + (uint64_t) K*W <= n)? K*W : n - base);   // bases in this tile
@@ -274,10 +276,49 @@ void window_sum_tile_kernel (double* __restrict__ v, uint32_t n, uint32_t W, uin
 		}
 	__syncthreads ();
 
+	// One thread sums one window, in ascending order: the reference's order, hence its bits.  With few, long windows per
+	// tile (W > 256: at most 15) that leaves all but a handful of lanes idle behind a chain of W dependent adds -- unless
+	// the order cannot matter: when every base of the window is a multiple of 2^-20 below 2^19 in magnitude (read depth,
+	// counts, anything an interval file of small integers or dyadic fractions adds up to), every partial sum of up to 8192
+	// of them is exactly representable (< 2^32 at a resolution of 2^-20: 52 bits), so any order gives the sequential
+	// result bit for bit.  A wave checks that while it adds the window lane-parallel; the windows that fail the check are
+	// then added in order, one lane each.
+	const bool coop = (W > 256);                          // (at most 15 windows in the tile)
+	if (coop)
+		{
+		const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+		for (uint32_t w=wave ; w<K ; w+=SU_THREADS/64)
+			{
+			const uint64_t s = (uint64_t) w * W;
+			if (s >= span) break;
+			const uint32_t len = (uint32_t) ((s + W <= span)? W : span - s);
+			const double*  x   = suLds + (size_t) w * pitch;
+			double part = -0.0;                                     // (so that a window of nothing but -0 sums to -0, as it does in order)
+			bool   ok   = true;
+			for (uint32_t k=lane ; k<len ; k+=64)
+				{
+				const double t = x[k], scaled = t * 1048576.0;
+				ok = ok && (fabs (t) < 524288.0) && (scaled == rint (scaled));
+				part += t;
+				if (__builtin_amdgcn_ballot_w64 (!ok) != 0) break;   // (real-valued data leaves after the first 64 bases)
+				}
+			const bool exact = (__builtin_amdgcn_ballot_w64 (!ok) == 0);
+			for (int off=32 ; off>0 ; off>>=1) part += __shfl_down (part, off, 64);
+			if (lane == 0)
+				{
+				if (exact) res[w] = useActual? part / (double) len : part / denom;   // no rounding anywhere: the ascending sum
+				else       atomicOr (&inOrder, 1u << w);
+				}
+			}
+		__syncthreads ();
+		}
+	// (the windows left for the ascending order share one wave's lanes: a chain of dependent adds occupies the FP64 pipe
+	// the same whether one lane or sixty-four are active)
 	for (uint32_t w=threadIdx.x ; w<K ; w+=SU_THREADS)
 		{
 		const uint64_t s = (uint64_t) w * W;
 		if (s >= span) break;
+		if (coop && (((inOrder >> w) & 1) == 0)) continue;
 		const uint32_t len = (uint32_t) ((s + W <= span)? W : span - s);
 		const double*  x   = suLds + (size_t) w * pitch;
 		// The adds stay one after the other in the reference's order; what can be hidden is the latency of the LDS

@@ -388,6 +388,34 @@ def test_window_sum(n, W, gd):
             assert bits_equal(got, want)
 
 
+@pytest.mark.parametrize("W", [257, 300, 500, 1000, 1023, 1024])
+def test_window_sum_exactly_summable_windows(W, gd):
+    """Windows of 257..1024 bases are added lane-parallel when every base in them is a multiple of 2^-20 below
+    2^19 (no partial sum rounds, so the order cannot matter) and in the reference's order otherwise
+    (gdsp_sums.hip).  The signals here put both kinds of window, the boundary values of the test, signed zeros
+    and a ragged last window under the bit-for-bit comparison."""
+    rng = np.random.default_rng(W)
+    n = 40 * W + W // 3
+    base = rng.poisson(30, n).astype(np.float64)
+    cases = {"depth": base.copy()}
+    x = base.copy(); x[rng.integers(0, n, 25)] += rng.random(25)              # some windows hold a non-dyadic base
+    cases["mixed"] = x
+    x = base * 2.0 ** -20; x[::7] *= -1.0                                      # the finest resolution the fast path takes
+    cases["fine"] = x
+    x = base.copy(); x[5 * W + 3] = 2.0 ** -21; x[9 * W] = 524288.0; x[11 * W + 1] = 524287.0 + 2.0 ** -20
+    x[13 * W + 2] = -524288.0; x[15 * W + 4] = 2.0 ** 60; x[17 * W + 5] = np.inf; x[19 * W + 6] = np.nan
+    cases["edges"] = x
+    x = np.zeros(n); x[: 3 * W] = -0.0; x[4 * W + 1] = -0.0; x[6 * W: 7 * W] = -0.0; x[6 * W + 9] = 0.0
+    x[8 * W] = 3.0; x[8 * W + 1] = -3.0
+    cases["zeros"] = x
+    cases["real"] = _signal("real", n, rng)
+    for name, x in cases.items():
+        for denom, actual, zero in ((1.0, False, 0.0), (float(W), False, 0.0), (1.0, True, -1.0)):
+            got = gd.window_sum(gd.DeviceVector.from_numpy(x), W, denom, actual, zero).numpy()
+            want = cpu.window_sum(x, W, denom=denom, use_actual=actual, zero=zero)
+            assert bits_equal(got, want), (name, denom, actual, first_diff(got, want))
+
+
 @pytest.mark.parametrize("n", [1, 2, 8191, 8192, 8193, 1000003])
 def test_cumulative_sum(n, gd):
     rng = np.random.default_rng(n)

@@ -24,6 +24,9 @@ OPS = {
     "sum1000": (cp, lambda: gd.window_sum(a, 1000, stream=s)),
     "sum2000": (cp, lambda: gd.window_sum(a, 2000, stream=s)),
     "sum500": (cp, lambda: gd.window_sum(a, 500, stream=s)),
+    "sum300": (cp, lambda: gd.window_sum(a, 300, stream=s)),
+    "sum1000real": (lambda: gd.call("gdsp_memcpy_d2d", a.ptr, real.ptr, n * 8, gd._sp(s)), lambda: gd.window_sum(a, 1000, stream=s)),
+    "sum300real": (lambda: gd.call("gdsp_memcpy_d2d", a.ptr, real.ptr, n * 8, gd._sp(s)), lambda: gd.window_sum(a, 300, stream=s)),
     "sum100": (cp, lambda: gd.window_sum(a, 100, stream=s)),
     "close": (None, lambda: gd.close(depth, 1001, out=b, stream=s)),
     "open": (None, lambda: gd.open_(depth, 1001, out=b, stream=s)),
