@@ -15,6 +15,8 @@
 //     the reference's own accumulated rounding error (tests state the bound).
 // All three are HBM-bound (16 B/base).
 
+#include <mutex>
+#include <vector>
 #include <stdlib.h>
 #include "gdsp_common.h"
 
@@ -376,6 +378,66 @@ void window_sum_tile_kernel (double* __restrict__ v, uint32_t n, uint32_t W, uin
 		}
 	}
 
+// Windows of 1025..8192 bases, first pass: one wave per window reads it with coalesced 16-byte loads, adds it
+// lane-parallel and checks, as window_sum_tile_kernel does, that no partial sum of it can round (every base a multiple
+// of 2^-20 below 2^19 in magnitude).  Such a window is rewritten on the spot -- any order is the reference's sum bit for
+// bit -- and flagged done; a window that fails is left untouched for window_sum_rows_kernel (real-valued data fails
+// within the first 128 bases of each window: one kilobyte read in vain per window).
+#define WX_THREADS 256
+#define WX_BATCH   8
+
+__global__ __launch_bounds__(WX_THREADS)
+void window_sum_exact_kernel (double* __restrict__ v, uint32_t n, uint32_t W, uint32_t nwin,
+                              double denom, int useActual, double zeroVal, unsigned char* __restrict__ done)
+	{
+	const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const uint64_t w    = (uint64_t) blockIdx.x * (WX_THREADS/64) + wave;
+	if (w >= nwin) return;
+	const uint64_t s  = w * W;
+	const uint64_t e  = (s + W <= n)? s + W : n;
+	const uint64_t p0 = (s + 1) / 2, p1 = e / 2;               // whole 16-byte words [p0, p1) of the window
+	double2*       words = reinterpret_cast<double2*> (v);
+
+	double part = -0.0;                                        // (a window of nothing but -0 sums to -0)
+	bool   ok   = true;
+	auto take = [&] (double t)
+		{
+		const double scaled = t * 1048576.0;
+		ok = ok && (fabs (t) < 524288.0) && (scaled == rint (scaled));
+		part += t;
+		};
+	if ((lane == 0) && (s & 1)) take (v[s]);                   // a base before the first whole word
+	if ((lane == 1) && (e & 1)) take (v[e-1]);                 // ... and one after the last (e-1 = s only when s is even)
+	uint64_t p = p0 + lane;
+	if (p < p1) { const double2 x = words[p];  take (x.x);  take (x.y); }   // a first, short look: real-valued data stops here
+	p += 64;
+	while ((__builtin_amdgcn_ballot_w64 (!ok) == 0) && (__builtin_amdgcn_ballot_w64 (p < p1) != 0))
+		{
+		double2 x[WX_BATCH];
+#pragma unroll
+		for (int u=0 ; u<WX_BATCH ; u++)
+			{
+			const uint64_t q = p + 64*u;
+			x[u] = words[(q < p1)? q : p1 - 1];                     // (p1 > p0 here; clamped, the extra copies are not added)
+			}
+#pragma unroll
+		for (int u=0 ; u<WX_BATCH ; u++)
+			{ if (p + 64*u < p1) { take (x[u].x);  take (x[u].y); } }
+		p += 64*WX_BATCH;
+		}
+	if (__builtin_amdgcn_ballot_w64 (!ok) != 0)
+		{ if (lane == 0) done[w] = 0;  return; }
+
+	for (int off=32 ; off>0 ; off>>=1) part += __shfl_down (part, off, 64);
+	part = __shfl (part, 0, 64);
+	const double val = useActual? part / (double) (e - s) : part / denom;
+	if ((lane == 0) && (s & 1)) v[s]   = val;
+	if ((lane == 1) && (e & 1)) v[e-1] = (e - 1 == s)? val : zeroVal;
+	for (uint64_t q=p0+lane ; q<p1 ; q+=64)
+		words[q] = make_double2 ((2*q == s)? val : zeroVal, zeroVal);
+	if (lane == 0) done[w] = 1;
+	}
+
 // ---- long windows (W > WS_TILE_MAX_W): one LANE per window, one 128-byte line of every window at a time.
 // In the tiled kernel a 1000-base window keeps one lane busy for a thousand dependent adds while the other 252
 // threads of its workgroup wait, and LDS holds only a handful of whole windows per CU.  Here a wave takes 64
@@ -395,15 +457,19 @@ void window_sum_tile_kernel (double* __restrict__ v, uint32_t n, uint32_t W, uin
 
 __global__ __launch_bounds__(WR_THREADS)
 void window_sum_rows_kernel (double* __restrict__ v, uint32_t n, uint32_t W, uint32_t nwin,
-                             double denom, int useActual, double zeroVal)
+                             double denom, int useActual, double zeroVal, const unsigned char* __restrict__ done)
 	{
 	__shared__ __attribute__((aligned(16))) double stage[WR_THREADS/64][2][64 * WR_PITCH];
 	const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const uint64_t w0   = ((uint64_t) blockIdx.x * (WR_THREADS/64) + wave) * 64;      // first window of this wave
 	if (w0 >= nwin) return;                                        // (whole waves only: no workgroup barrier below)
 	const uint64_t myWin   = w0 + lane;
+	// windows that window_sum_exact_kernel has already rewritten count as empty here: nothing of theirs is added or stored
+	const bool     mine    = (myWin < nwin) && (done[myWin] == 0);
+	const uint64_t todo    = __builtin_amdgcn_ballot_w64 (mine);   // bit r: window w0+r is still to be summed
+	if (todo == 0) return;
 	const uint64_t myStart = myWin * W;
-	const uint64_t myEnd   = (myWin >= nwin)? myStart : ((myStart + W <= n)? myStart + W : n);
+	const uint64_t myEnd   = (!mine)? myStart : ((myStart + W <= n)? myStart + W : n);
 	const uint64_t myLine0 = myStart / WR_PIECE;
 	const uint32_t nstages = W / WR_PIECE + 2;                     // pieces a window can touch
 	double2*       base    = reinterpret_cast<double2*> (v);
@@ -433,7 +499,7 @@ void window_sum_rows_kernel (double* __restrict__ v, uint32_t n, uint32_t W, uin
 			// the bases of this piece that belong to the window (all but its first slot) become zeroVal
 			const uint64_t win   = w0 + (uint64_t) (WR_RPI*j + myRowInGroup);
 			const uint64_t start = win * W;
-			const uint64_t end   = (win >= nwin)? start : ((start + W <= n)? start + W : n);
+			const uint64_t end   = (((todo >> (WR_RPI*j + myRowInGroup)) & 1) == 0)? start : ((start + W <= n)? start + W : n);
 			const uint64_t e0    = (start / WR_PIECE + st) * WR_PIECE + 2*myWord;
 			const bool in0 = (e0     > start) && (e0     < end);
 			const bool in1 = (e0 + 1 > start) && (e0 + 1 < end);
@@ -633,6 +699,30 @@ void cumsum_apply_kernel (double* __restrict__ v, uint32_t n, uint32_t nchunks, 
 // 1.41 ms per 249 Mbp, a wave per 1024-base chunk with a 32-ary tree 2.83 ms, against 1.05 ms for the three launches
 // below; with the waits removed (wrong sums) the first form ran in 0.81 ms, so even free waits would buy little.)
 
+// one flag per window for the two passes above, kept per (device, stream): calls on one stream follow one another,
+// calls on different streams must not share them
+struct WsFlags { int device;  void* stream;  size_t nwin;  unsigned char* d_done; };
+static std::vector<WsFlags> wsFlags;
+static std::mutex           wsLock;
+
+static int ws_done_flags (void* stream, size_t nwin, unsigned char** out)
+	{
+	int device = 0;
+	GDSP_HIP_TRY (hipGetDevice (&device));
+	WsFlags* f = NULL;
+	for (WsFlags& x : wsFlags) { if ((x.device == device) && (x.stream == stream)) f = &x; }
+	if (f == NULL) { wsFlags.push_back (WsFlags { device, stream, 0, NULL });  f = &wsFlags.back (); }
+	if (f->nwin < nwin)
+		{
+		if (f->d_done != NULL) { GDSP_HIP_TRY (hipStreamSynchronize (gdsp_stream (stream)));  GDSP_HIP_TRY (hipFree (f->d_done)); }
+		f->d_done = NULL;  f->nwin = 0;
+		GDSP_HIP_TRY (hipMalloc ((void**) &f->d_done, nwin + 64));
+		f->nwin = nwin;
+		}
+	*out = f->d_done;
+	return GDSP_OK;
+	}
+
 extern "C" {
 
 int gdsp_sliding_sum (const double* d_in, double* d_out, uint32_t n, uint32_t W, double denom, void* stream)
@@ -701,8 +791,16 @@ int gdsp_window_sum (double* d_v, uint32_t n, uint32_t W, double denom, int useA
 		}
 	else if ((W <= WS_SEQ_MAX) && gdsp_aligned16 (d_v))
 		{
+		unsigned char* d_done = NULL;
+		{
+		std::lock_guard<std::mutex> hold (wsLock);
+		const int rc = ws_done_flags (stream, nwin, &d_done);
+		if (rc != GDSP_OK) return rc;
+		}
+		hipLaunchKernelGGL (window_sum_exact_kernel, dim3((nwin + WX_THREADS/64 - 1)/(WX_THREADS/64)), dim3(WX_THREADS), 0,
+		                    gdsp_stream (stream), d_v, n, W, nwin, denom, useActual, zeroVal, d_done);
 		hipLaunchKernelGGL (window_sum_rows_kernel, dim3((nwin + WR_THREADS - 1)/WR_THREADS), dim3(WR_THREADS), 0,
-		                    gdsp_stream (stream), d_v, n, W, nwin, denom, useActual, zeroVal);
+		                    gdsp_stream (stream), d_v, n, W, nwin, denom, useActual, zeroVal, d_done);
 		}
 	else if (W <= WS_SEQ_MAX)
 		hipLaunchKernelGGL (window_sum_seq_kernel, dim3((nwin + SU_THREADS - 1)/SU_THREADS), dim3(SU_THREADS), 0,

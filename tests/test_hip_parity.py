@@ -388,11 +388,11 @@ def test_window_sum(n, W, gd):
             assert bits_equal(got, want)
 
 
-@pytest.mark.parametrize("W", [257, 300, 500, 1000, 1023, 1024])
+@pytest.mark.parametrize("W", [257, 300, 500, 1000, 1023, 1024, 1025, 1500, 2000, 2001, 4097, 8191, 8192])
 def test_window_sum_exactly_summable_windows(W, gd):
-    """Windows of 257..1024 bases are added lane-parallel when every base in them is a multiple of 2^-20 below
+    """Windows of 257..8192 bases are added lane-parallel when every base in them is a multiple of 2^-20 below
     2^19 (no partial sum rounds, so the order cannot matter) and in the reference's order otherwise
-    (gdsp_sums.hip).  The signals here put both kinds of window, the boundary values of the test, signed zeros
+    (gdsp_sums.hip: inside the tile kernel up to 1024 bases, as a first pass of one wave per window above).  The signals here put both kinds of window, the boundary values of the test, signed zeros
     and a ragged last window under the bit-for-bit comparison."""
     rng = np.random.default_rng(W)
     n = 40 * W + W // 3

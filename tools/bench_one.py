@@ -26,6 +26,9 @@ OPS = {
     "sum500": (cp, lambda: gd.window_sum(a, 500, stream=s)),
     "sum300": (cp, lambda: gd.window_sum(a, 300, stream=s)),
     "sum1000real": (lambda: gd.call("gdsp_memcpy_d2d", a.ptr, real.ptr, n * 8, gd._sp(s)), lambda: gd.window_sum(a, 1000, stream=s)),
+    "sum2000real": (lambda: gd.call("gdsp_memcpy_d2d", a.ptr, real.ptr, n * 8, gd._sp(s)), lambda: gd.window_sum(a, 2000, stream=s)),
+    "sum4000": (cp, lambda: gd.window_sum(a, 4000, stream=s)),
+    "sum8000": (cp, lambda: gd.window_sum(a, 8000, stream=s)),
     "sum300real": (lambda: gd.call("gdsp_memcpy_d2d", a.ptr, real.ptr, n * 8, gd._sp(s)), lambda: gd.window_sum(a, 300, stream=s)),
     "sum100": (cp, lambda: gd.window_sum(a, 100, stream=s)),
     "close": (None, lambda: gd.close(depth, 1001, out=b, stream=s)),

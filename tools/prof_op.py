@@ -35,6 +35,7 @@ RUN = {
     "cumsum": lambda: (copy(a, depth), gd.call("gdsp_cumulative_sum", a.ptr, n, C.c_void_p(work.ptr), None)),
     "sum1000": lambda: (copy(a, depth), gd.window_sum(a, 1000)),
     "sum100": lambda: (copy(a, depth), gd.window_sum(a, 100)),
+    "sum2000": lambda: (copy(a, depth), gd.window_sum(a, 2000)),
     "slidingsum": lambda: gd.sliding_sum(depth, 101, out=b),
     "close": lambda: gd.close(depth, 1001, out=b),
     "open": lambda: gd.open_(depth, 1001, out=b),
