@@ -108,6 +108,9 @@ static const char* notInThisBuild[] = { NULL };    /* every operator of the refe
 spec*  chromsOfInterest = NULL;
 spec** chromsSorted     = NULL;
 int    trackOperations  = false;
+int    dbgInput         = false;     /* --debug=input, --debug=pipe, --debug=globals: genodsp.c:61-63 */
+int    dbgPipe          = false;
+int    dbgGlobals       = false;
 int    reportComments   = false;
 u32    reportInputProgress = 0;
 
@@ -270,6 +273,7 @@ static namedglobal* find_named_global (const char* name)
 
 void set_named_global (char* name, valtype val)   /* newest first, like genodsp.c:2093-2104 */
 	{
+	if (dbgGlobals) fprintf (stderr, "set_named_global(%s," valtypeFmt ")\n", name, val);
 	namedglobal* g = find_named_global (name);
 	if (g == NULL)
 		{
@@ -283,11 +287,26 @@ void set_named_global (char* name, valtype val)   /* newest first, like genodsp.
 	}
 
 valtype get_named_global (char* name, valtype defaultVal)
-	{ namedglobal* g = find_named_global (name);  return (g == NULL)? defaultVal : g->v; }
+	{
+	namedglobal* g = find_named_global (name);
+	if (dbgGlobals)                                /* genodsp.c:2110-2131 */
+		{
+		fprintf (stderr, "get_named_global(%s) = ", name);
+		if (g == NULL) fprintf (stderr, valtypeFmt " (default)\n", defaultVal);
+		else           fprintf (stderr, valtypeFmt "\n", g->v);
+		}
+	return (g == NULL)? defaultVal : g->v;
+	}
 
 int named_global_exists (char* name, valtype* val)
 	{
 	namedglobal* g = find_named_global (name);
+	if (dbgGlobals)                                /* genodsp.c:2143-2163 */
+		{
+		fprintf (stderr, "named_global_exists(%s) = ", name);
+		if (g == NULL) fprintf (stderr, " (not found)\n");
+		else           fprintf (stderr, valtypeFmt "\n", g->v);
+		}
 	if (g == NULL) return false;
 	if (val != NULL) *val = g->v;
 	return true;
@@ -1291,6 +1310,7 @@ static int process_operator_options (int argc, char** argv)    /* genodsp.c:634-
 
 	if ((arg[0] == specialPipeChar) && (arg[1] == 0)) { argv++;  argc--;  consumed++;  dspName = argv[0]; }
 	else dspName = skip_whitespace (arg+1);
+	if (dbgPipe) fprintf (stderr, "  dspName=\"%s\"\n", dspName);
 
 	dspinfo* info = find_operator (dspName);
 	if (info == NULL)
@@ -1309,6 +1329,12 @@ static int process_operator_options (int argc, char** argv)    /* genodsp.c:634-
 
 	int dspArgC = 0;
 	while ((dspArgC < argc) && (argv[dspArgC][0] != specialPipeChar)) { dspArgC++;  consumed++; }
+	if (dbgPipe)                                   /* genodsp.c:691-697: every argument left, not only this operator's */
+		{
+		fprintf (stderr, "  args:");
+		for (int i=0 ; i<argc ; i++) fprintf (stderr, " %s", argv[i]);
+		fprintf (stderr, "\n");
+		}
 
 	chastiseUsage = info->funcUsage;  chastiseUsageName = info->name;
 	dspop* op = (*info->funcParse) (info->name, dspArgC, argv);
@@ -1320,6 +1346,7 @@ static int process_operator_options (int argc, char** argv)    /* genodsp.c:634-
 	op->next      = NULL;
 	if (tailOp == NULL) pipeline = op;  else tailOp->next = op;
 	tailOp = op;
+	if (dbgPipe) fprintf (stderr, "  argsConsumed=%d\n", consumed);
 	return consumed;
 	}
 
@@ -1347,6 +1374,7 @@ static void parse_options (int _argc, char** _argv)            /* genodsp.c:284-
 
 		if (arg[0] == specialPipeChar)
 			{
+			if (dbgPipe) fprintf (stderr, "pipe char in arg[%d]\n", (int) (argv - _argv));
 			if ((argc == 1) && (arg[1] == 0))
 				chastise ("%c at end of command line, with no operation\n", specialPipeChar);
 			int consumed = process_operator_options (argc, argv);
@@ -1450,6 +1478,9 @@ static void parse_options (int _argc, char** _argv)            /* genodsp.c:284-
 			{ trackOperations = true;  continue; }
 		if (strcmp (arg, "--version") == 0)
 			{ fprintf (stderr, "%s (version %s)\n", programName, programVersion);  exit (EXIT_SUCCESS); }
+		if (strcmp (arg, "--debug=input") == 0)   { dbgInput   = true;  continue; }
+		if (strcmp (arg, "--debug=pipe") == 0)    { dbgPipe    = true;  continue; }
+		if (strcmp (arg, "--debug=globals") == 0) { dbgGlobals = true;  continue; }
 		if (strcmp_prefix (arg, "--") == 0) chastise ("Can't understand \"%s\"\n", arg);
 
 		/* <chromosome>:<length> or <chromosome>:<start>:<end> */

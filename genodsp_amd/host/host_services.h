@@ -8,6 +8,7 @@
 
 extern int selectStrategy;                  /* GDSP_SELECT_* (--percentile=) */
 extern int firMode;                         /* GDSP_FIR_EXACT or GDSP_FIR_FMA (--smooth=) */
+extern int dbgInput;                        /* --debug=input: echo every input line (genodsp.c:1422) */
 
 /* pending-interval batches: collect in file order, apply on the owning device */
 void ib_begin       (void);

@@ -266,7 +266,7 @@ static int read_interval_serial (FILE* f, char* buffer, int bufferLen, int valCo
 int read_interval (FILE* f, char* buffer, int bufferLen, int valCol,     /* genodsp.c:1384-1534 */
                    char** _chrom, u32* _start, u32* _end, valtype* _val)
 	{
-	if ((reportInputProgress != 0) || reportComments || (team_size () == 1))
+	if ((reportInputProgress != 0) || reportComments || dbgInput || (team_size () == 1))
 		return read_interval_serial (f, buffer, bufferLen, valCol, _chrom, _start, _end, _val);
 
 	stream* sm = stream_of (f);
@@ -307,6 +307,7 @@ static int read_interval_serial (FILE* f, char* buffer, int bufferLen, int valCo
 			{ fprintf (stderr, "problem at line %s, line is longer than internal buffer\n", ucommatize (lineNumber-1));  exit (EXIT_FAILURE); }
 		size_t len = strlen (buffer);
 		if (len != 0) missingEol = (buffer[len-1] != '\n');
+		if (dbgInput) fprintf (stderr, "input = \"%s\"\n", buffer);      /* genodsp.c:1422 */
 		if (strcmp_prefix (buffer, "track ") == 0) continue;
 
 		int progressNow = (reportInputProgress != 0)

@@ -32,7 +32,9 @@ static dspop* fileop_parse (char* name, int argc, char** argv, int kind)
 	{
 	dspop_fileop* op = (dspop_fileop*) new_op (name, sizeof(dspop_fileop), true);
 	op->kind        = kind;
-	op->valColumn   = (int) get_named_global ("valColumn", 4-1);
+	/* mask, masknot, minover and maxover read no value column and never ask for it (mask.c:92,400 minmax.c:102,503) */
+	const int noValues = (kind == K_MASK) || (kind == K_MASKNOT) || (kind == K_MINOVER) || (kind == K_MAXOVER);
+	op->valColumn   = noValues? -1 : (int) get_named_global ("valColumn", 4-1);
 	op->originOne   = (int) get_named_global ("originOne", false);
 	op->infinityVal = valtypeMax;
 	if (kind == K_MINOVER) op->maskVal = valtypeMax;     /* minmax.c:103; maxover's zero value is 0.0 (:504) */

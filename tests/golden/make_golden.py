@@ -451,6 +451,11 @@ for tag, what in (("0", ["0"]), ("100", ["100"]), ("0_to_100by10", ["0..100by10"
              ["--novalue", "=", "percentile"] + what + ["--min=1/inf", "=", "variables"], APPENDIX_C_IV,
              {"m": ""} if "--map=@m@" in what else None)
 
+# the three diagnostics of genodsp.c:553-561: argument scanning, the named-variable channel, every input line echoed
+cli_case("cli_debug_pipe_globals_input", APPENDIX_C_CH,
+         ["--novalue", "--debug=pipe", "--debug=globals", "--precision=2", "--debug=input", "--window=5", "=", "addconst", "1",
+          "=", "slidingsum", "=", "mask", "@m@", "=", "variables"], APPENDIX_C_IV, {"m": "chr1 12 40\n# kept\n"})
+
 np.savez_compressed(os.path.join(HERE, "golden.npz"), **arrays)
 with open(os.path.join(HERE, "golden.json"), "w") as f:
     json.dump({"seed": SEED, "cases": cases}, f, indent=1)

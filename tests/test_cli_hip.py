@@ -55,10 +55,14 @@ def test_cli_stdout_matches_reference(case, tmp_path):
         assert out == golden().cases["cli_coverage"]["stdout"]
     else:
         assert out == case["stdout"]
-    if case["name"].startswith("cli_percentile_"):
+    if case["name"].startswith(("cli_percentile_", "cli_debug_")):
         # what percentile reports and what it does not (the extremes are answered silently, percentile.c:432-530),
         # and the variables it leaves behind, in the reference's order
-        assert err == case["stderr"]
+        want = case["stderr"]
+        for key in case.get("files") or {}:        # (--debug=pipe echoes the arguments: the file paths differ)
+            want = want.replace("/tmp/golden_%s_%s" % (case["name"], key), "@%s@" % key)
+            err = err.replace(os.path.join(str(tmp_path), key + ".dat"), "@%s@" % key)
+        assert err == want
     # the percentile report line goes to stderr in both programs
     for line in case["stderr"].splitlines():
         if line.startswith("percentile "):
