@@ -339,7 +339,8 @@ static void hann_launch (const double* d_in, double* d_out, uint32_t n, const do
 // smallest tap that goes through the block sums, and the bound of one rounding per operation
 // grows with W, which makes E ~ sqrt(0.15 W) enough (8 for W = 101, 16 for 1001, 20 for 2001);
 // E also carries the parity that keeps a tile's first element 16-byte aligned.
-#define HN_RT_SMALL_MAX_W 1501                                  // up to here the 256-thread form is the faster one (measured)
+#define HN_RT_SMALL_MAX_W 1701                                  // up to here the 256-thread form is the faster one (measured)
+#define HN_RT_SCAN_MIN_W  1001                                  // from here on it scans its block totals instead of walking them (measured: 801 -4 %, 1001 +4 %, 1501 +20 %)
 #define HN_RT_MAX_NT 512
 #define HN_RT_BIG    768                                        // threads of the long-window form: 12288 staged elements, 122 KiB of LDS
 struct HannRT
@@ -358,8 +359,8 @@ struct HannRT
 // 448-thread workgroups per CU were slower at every window tried) and adds
 // the blocks between in two levels: the totals of aligned groups of 16 blocks, plus at most 15 single blocks at either
 // end of the range (additions only, as before; fewer roundings than one by one).
-template <int E, int THREADS>
-__global__ __launch_bounds__(THREADS)
+template <int E, int THREADS, bool SCAN>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3)))
 void hann_blocks_rt_kernel (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t ntiles,
                             HannRT K, const double2* __restrict__ rot, const double* __restrict__ taps, int W)
 	{
@@ -367,7 +368,6 @@ void hann_blocks_rt_kernel (const double* __restrict__ in, double* __restrict__ 
 	constexpr int ELEMS = THREADS * HN_G;
 	__shared__ __attribute__((aligned(16))) double lds[THREADS * HN_PITCH];
 	__shared__ double tot[3][THREADS];                                // the blocks of p's segment up to and including p, in p's phase
-	constexpr bool SCAN = (THREADS > 256);                            // the long-window form scans its block totals; the 256-thread form walks them
 	__shared__ double vsf[3][SCAN? THREADS : 1];                      // the blocks of p's segment from p on, in p's phase
 	__shared__ __attribute__((aligned(16))) uint32_t huge[16];
 
@@ -552,7 +552,7 @@ void hann_blocks_rt_kernel (const double* __restrict__ in, double* __restrict__ 
 	}
 
 // plans of the run-time kernel, cached per (device, W): the geometry and the rotation table in HBM
-struct HannPlanRT { int device;  uint32_t W;  int E;  int threads;  HannRT K;  double2* d_rot; };
+struct HannPlanRT { int device;  uint32_t W;  int E;  int threads;  bool scan;  HannRT K;  double2* d_rot; };
 #define HN_PLAN_CACHE 32
 static HannPlanRT hannPlans[HN_PLAN_CACHE];
 static int        hannPlanLen = 0;
@@ -560,7 +560,7 @@ static std::mutex hannPlanLock;
 
 static int hann_direct_taps (uint32_t W)                            // E: enough taps, right parity, an instantiated value
 	{
-	// (instantiated values only: the 256-thread form needs up to 15 at W = 1501; the long-window form takes the next of 20/21, 28/29)
+	// (instantiated values only: the 256-thread form needs up to 16 at W = 1701; the long-window form takes the next of 20/21, 28/29)
 	static const int small[] = { 8, 9, 12, 13, 16, 17 }, big[] = { 20, 21, 28, 29 };
 	const int H    = (int) (W - 1) / 2;
 	const int need = std::max (8, (int) ceil (sqrt (0.15 * W)));
@@ -589,7 +589,11 @@ static int hann_plan_rt (uint32_t W, HannPlanRT** out)
 	K.LO   = K.HALO_L * HN_G - BACK;
 	K.LEAD = K.HALO_L * HN_G - (H - E);
 	K.OUT  = (THREADS - K.HALO_L - K.HALO_R) * HN_G;
-	K.SEG  = ((THREADS > HN_THREADS) && (K.NT >= 64))? 32 : 0;     // segments of the block scans (the long-window form only: below ~1500 taps walking the blocks is as fast and the scans' registers cost the 256-thread form a workgroup per CU)
+	// the blocks between the ends: walked one by one below HN_RT_SCAN_MIN_W (a short walk, and the kernel without the scans
+	// needs no spill to keep three waves per SIMD), segmented scans above; the segments need runs of at least 32 blocks,
+	// the long-window form's 64 is what it was tuned with
+	pl->scan = (THREADS > HN_THREADS) || ((W >= HN_RT_SCAN_MIN_W) && (getenv ("GDSP_HANN_WALK") == NULL));   // (GDSP_HANN_WALK: the walk at any window of the 256-thread form, for A/B timing)
+	K.SEG    = (pl->scan && (K.NT >= ((THREADS > HN_THREADS)? 64 : 32)))? 32 : 0;
 	const double pi = 3.14159265358979323846264;
 	const long   M  = (long) W + 1;
 	auto cs = [&] (long m, double* c, double* sn)
@@ -638,22 +642,24 @@ int gdsp_hann_blocks_apply (const double* d_in, double* d_out, uint32_t n, uint3
 	if (rc != GDSP_OK) return rc;
 	GDSP_REQUIRE ((pl->K.DQ >= 2) && (pl->K.NT + 40 <= HN_RT_MAX_NT) && (pl->K.OUT >= 512) && ((pl->K.LEAD & 1) == 0), "window outside the block-sum kernel's range");
 	const uint32_t ntiles = (uint32_t) (((uint64_t) n + pl->K.OUT - 1) / pl->K.OUT);
-#define HN_RT_SMALL(EE) hipLaunchKernelGGL ((hann_blocks_rt_kernel<EE, HN_THREADS>), dim3(ntiles), dim3(HN_THREADS), 0, s, d_in, d_out, n, ntiles, pl->K, pl->d_rot, d_taps, (int) W)
-#define HN_RT_BIGK(EE)  hipLaunchKernelGGL ((hann_blocks_rt_kernel<EE, HN_RT_BIG>),  dim3(ntiles), dim3(HN_RT_BIG),  0, s, d_in, d_out, n, ntiles, pl->K, pl->d_rot, d_taps, (int) W)
+#define HN_RT_SMALL(EE) hipLaunchKernelGGL ((hann_blocks_rt_kernel<EE, HN_THREADS, false>), dim3(ntiles), dim3(HN_THREADS), 0, s, d_in, d_out, n, ntiles, pl->K, pl->d_rot, d_taps, (int) W)
+#define HN_RT_MID(EE)   hipLaunchKernelGGL ((hann_blocks_rt_kernel<EE, HN_THREADS, true>),  dim3(ntiles), dim3(HN_THREADS), 0, s, d_in, d_out, n, ntiles, pl->K, pl->d_rot, d_taps, (int) W)
+#define HN_RT_BIGK(EE)  hipLaunchKernelGGL ((hann_blocks_rt_kernel<EE, HN_RT_BIG, true>),   dim3(ntiles), dim3(HN_RT_BIG),  0, s, d_in, d_out, n, ntiles, pl->K, pl->d_rot, d_taps, (int) W)
 	switch (pl->E)
 		{
 		case 8:  HN_RT_SMALL (8);  break;
 		case 9:  HN_RT_SMALL (9);  break;
 		case 12: HN_RT_SMALL (12); break;
-		case 13: HN_RT_SMALL (13); break;
-		case 16: HN_RT_SMALL (16); break;
-		case 17: HN_RT_SMALL (17); break;
+		case 13: if (pl->scan) HN_RT_MID (13); else HN_RT_SMALL (13);  break;      // (windows of 1001 taps and more need 13 or more)
+		case 16: if (pl->scan) HN_RT_MID (16); else HN_RT_SMALL (16);  break;
+		case 17: if (pl->scan) HN_RT_MID (17); else HN_RT_SMALL (17);  break;
 		case 20: HN_RT_BIGK (20);  break;
 		case 21: HN_RT_BIGK (21);  break;
 		case 28: HN_RT_BIGK (28);  break;
 		default: HN_RT_BIGK (29);  break;
 		}
 #undef HN_RT_SMALL
+#undef HN_RT_MID
 #undef HN_RT_BIGK
 	GDSP_LAUNCH_CHECK ();
 	return GDSP_OK;

@@ -145,7 +145,7 @@ def test_smooth_hann_block_sums_within_one_rounding_per_op(n, kind, gd):
         assert np.all(got[sel][~ok] == 0.0)
 
 
-@pytest.mark.parametrize("W", [81, 83, 85, 99, 103, 201, 301, 427, 501, 1001, 1499, 1501, 1503, 1505, 1999, 2001, 2999, 3001, 3999, 4001])
+@pytest.mark.parametrize("W", [81, 83, 85, 99, 103, 201, 301, 427, 501, 999, 1001, 1003, 1499, 1501, 1699, 1701, 1703, 1705, 1999, 2001, 2999, 3001, 3999, 4001])
 def test_smooth_hann_any_window_within_one_rounding_per_op(W, gd):
     """Windows of 81..2001 taps go through the run-time form of the block-sum kernel (direct taps at the ends
     growing like sqrt(0.15 W)); same bar as W=101, sizes around its tile seams."""

@@ -51,6 +51,8 @@ OPS = {
     "smooth_fma": (None, lambda: gd.smooth(real, 101, out=b, mode=gd.FIR_FMA, stream=s)),
 }
 for name in op.split(","):
+    if name not in OPS and name.startswith("smooth_hann"):          # any window: smooth_hann<W>
+        OPS[name] = (None, lambda W=int(name[len("smooth_hann"):]): gd.smooth(real, W, out=b, mode=gd.FIR_HANN, stream=s))
     prep, fn = OPS[name]
     best = 1e30
     for _ in range(reps):
