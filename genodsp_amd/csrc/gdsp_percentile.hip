@@ -44,7 +44,7 @@
 #define PC_MAX_BLOCKS  2048
 #define PC_MAX_PIVOTS  32
 #define PC_WAVE_BUF    512
-#define PC_SAMPLE_TARGET (1u << 24)
+#define PC_SAMPLE_TARGET (1u << 20)
 
 // sorted distinct pivots as doubles (padded with NaN, which compares false); collect bit j: keep what lies
 // strictly between pivot j-1 and pivot j (bit 0: below the first, bit m: above the last)
@@ -107,7 +107,7 @@ template <int M, bool BOUNDED, bool DENSE>
 __global__ __launch_bounds__(PC_THREADS)
 void pc_partition_kernel (const double* __restrict__ v, uint32_t n, uint32_t window, double lo, double hi, PcPivots P,
                           unsigned long long* __restrict__ ctr, uint64_t* __restrict__ cand, unsigned long long cap,
-                          uint32_t ntiles, uint32_t tilesPerWG)
+                          uint32_t ntiles)
 	{
 	constexpr int NC = 2*M + 5;                                // counters of this instantiation
 	__shared__ uint64_t wbuf[PC_THREADS/64][PC_WAVE_BUF];
@@ -115,9 +115,10 @@ void pc_partition_kernel (const double* __restrict__ v, uint32_t n, uint32_t win
 
 	const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const size_t   npop = DENSE? (size_t) n : ((size_t) n + window - 1) / window;
-	const uint32_t wg   = gdsp_xcd_tile (blockIdx.x, gridDim.x);
-	const uint32_t t0   = wg * tilesPerWG;
-	const uint32_t t1   = (t0 + tilesPerWG < ntiles)? t0 + tilesPerWG : ntiles;
+	// a workgroup's tiles are blockIdx.x, + gridDim.x, ...: the workgroups in flight read one compact stretch of the vector
+	// between them (a workgroup streaming its own contiguous 512 KiB, next tile prefetched, ran at 5.1 TB/s; this way, with the
+	// registers of the prefetch given back for occupancy, 5.5)
+	const uint32_t step = gridDim.x;
 	unsigned long long* candCount = ctr + (size_t) PC_REPL * PC_CTR_WORDS;
 	uint32_t held = 0;                                         // candidates waiting in this wave's buffer (wave uniform)
 	uint32_t cGt[M], cEq[M], cGeLo = 0, cGtHi = 0, cNanPos = 0, cNanNeg = 0, cNegInf = 0;   // per lane
@@ -203,15 +204,12 @@ void pc_partition_kernel (const double* __restrict__ v, uint32_t n, uint32_t win
 			}
 		};
 
-	double2 cur[8], nxt[8];
-	if (t0 < t1) load (t0, cur);
-	for (uint32_t tile=t0 ; tile<t1 ; tile++)
+	for (uint32_t tile=blockIdx.x ; tile<ntiles ; tile+=step)
 		{
-		if (tile + 1 < t1) load (tile + 1, nxt);
+		double2 cur[8];
+		load (tile, cur);
 #pragma unroll
 		for (int u=0 ; u<8 ; u++) { count (cur[u].x);  count (cur[u].y); }
-#pragma unroll
-		for (int u=0 ; u<8 ; u++) cur[u] = nxt[u];
 		}
 	if (held) flush ();
 
@@ -562,9 +560,14 @@ int gdsp_percentiles (const gdsp_select_source* sources, int nsources, uint32_t 
 	// ---- how: brackets need a population worth sampling and pivots that fit the counting kernel
 	const bool bracket = (strategy == GDSP_SELECT_BRACKET)
 	                  || ((strategy == GDSP_SELECT_AUTO) && (pop > (uint64_t) sampleTarget) && (2*npercentiles <= PC_MAX_PIVOTS));
-	// a gathered value costs a 64-byte sector: no more than one value in 64, which still brackets a rank within
-	// 8*sqrt(64/pop) of the population (a 249 Mbp chromosome: 3.9 M values sampled, ~0.2 % kept as candidates)
-	if (defaultTarget) sampleTarget = (uint32_t) std::min<uint64_t> (PC_SAMPLE_TARGET, std::max<uint64_t> (1u << 16, pop / 64));
+	// The subsample only has to place the pivots: a rank is bracketed within 8*sqrt(p(1-p)/s) of the population whatever s
+	// is, so s trades the candidates the counting pass keeps (one 8-byte store each, then a few passes over them) against
+	// the gather itself -- every sampled value costs a 64-byte sector -- and the ten or so histogram passes over the
+	// subsample, each a launch and a host round trip.  One value in 1024, at least 2^16 and at most 2^20 of them
+	// (chr1: 243 k sampled, 0.3 % of the chromosome kept as candidates for the 99th percentile; the 3.1 Gbp genome: 2^20,
+	// 0.08 %).  Measured against one value in 64 up to 2^24 (round 1): a 249 Mbp call 1.25 -> 0.97 ms, the genome-wide
+	// percentile of bench.py's workload 7.1 -> 6.6 ms.
+	if (defaultTarget) sampleTarget = (uint32_t) std::min<uint64_t> (PC_SAMPLE_TARGET, std::max<uint64_t> (1u << 16, pop / 1024));
 	const uint32_t sstride = (uint32_t) std::max<uint64_t> (1, (pop + sampleTarget - 1) / sampleTarget);
 
 	// scratch per device: the subsample and a candidate list sized for the expected bracket widths
@@ -692,10 +695,10 @@ int gdsp_percentiles (const gdsp_select_source* sources, int nsources, uint32_t 
 #define PC_LAUNCH_B(MM, BB)                                                                                                    \
 			do { if (dense) hipLaunchKernelGGL ((pc_partition_kernel<MM, BB, true>),  dim3(blocks), dim3(PC_THREADS), 0,          \
 			                                     gdsp_stream (J.stream[d]), sources[i].d_v, sources[i].n, window, lo, hi, P, ctr, \
-			                                     J.scratch[d]->cand, (unsigned long long) J.scratch[d]->candCap, ntiles, perWG);  \
+			                                     J.scratch[d]->cand, (unsigned long long) J.scratch[d]->candCap, ntiles);  \
 			     else       hipLaunchKernelGGL ((pc_partition_kernel<MM, BB, false>), dim3(blocks), dim3(PC_THREADS), 0,          \
 			                                     gdsp_stream (J.stream[d]), sources[i].d_v, sources[i].n, window, lo, hi, P, ctr, \
-			                                     J.scratch[d]->cand, (unsigned long long) J.scratch[d]->candCap, ntiles, perWG); } while (0)
+			                                     J.scratch[d]->cand, (unsigned long long) J.scratch[d]->candCap, ntiles); } while (0)
 #define PC_LAUNCH(MM) do { if (bounded) PC_LAUNCH_B (MM, true);  else PC_LAUNCH_B (MM, false); } while (0)
 			padded += (uint64_t) ntiles * PC_TILE;
 			if      (P.m <= 2)  PC_LAUNCH (2);

@@ -225,8 +225,8 @@ uint32_t gdsp_percentile_rank (uint32_t numValues, uint32_t pThousandths);
  * decisions and gets the same values.  That reduction (a few KiB per step) is the path's only
  * collective.
  * strategy: AUTO brackets the ranks with pivots from a strided subsample of `sampleTarget`
- * values (0 = 2^24) and settles all percentiles in one counting pass over the population when it
- * is larger than that, RADIX is five histogram passes per percentile (the fallback of AUTO
+ * values (0 = one value in 1024, between 2^16 and 2^20) and settles all percentiles in one counting pass over the
+ * population when it is larger than 2^20 (or than an explicit sampleTarget), RADIX is five histogram passes per percentile (the fallback of AUTO
  * whenever a bracket misses), BRACKET forces the first route (tests). */
 typedef struct gdsp_select_source { const double* d_v; uint32_t n; int device; void* stream; } gdsp_select_source;
 typedef int (*gdsp_reduce_fn) (void* ctx, uint64_t* words, size_t count, int op);
