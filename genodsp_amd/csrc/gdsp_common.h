@@ -33,6 +33,9 @@ void gdsp_set_error (const char* fmt, ...);
 // gdsp_hann.hip: `smooth` through block sums of the Hann window's constant and cosine parts
 bool gdsp_hann_blocks_available (uint32_t W);
 int  gdsp_hann_blocks_apply (const double* d_in, double* d_out, uint32_t n, uint32_t W, void* stream);
+// ... and `smooth W=101 = localmax|localmin N` with the block sums as a filter in front of the exact evaluation (bit-identical to it)
+int  gdsp_hann_extrema_apply (const double* d_in, double* d_out, uint32_t n, uint32_t W, const double* h_taps, int fma,
+                              uint32_t N, int wantMax, double fill, void* stream);
 
 // gdsp_hann_far.hip: the same for windows longer than one LDS tile can hold (3201 .. 50001 taps), block totals in HBM
 bool gdsp_hann_far_available (uint32_t W);

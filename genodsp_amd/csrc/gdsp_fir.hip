@@ -441,6 +441,11 @@ int gdsp_smooth_local_extrema (const double* d_in, double* d_out, uint32_t n, ui
 	if (rc != GDSP_OK) return rc;
 	const int   h = (int) ((N - 1) / 2);
 	hipStream_t s = gdsp_stream (stream);
+	// EXACT: the block sums as a filter in front of the tap-by-tap evaluation, which then runs only for the bases that can
+	// survive and what ties with them (gdsp_hann.hip; 145 against 120 Gbases/s on one chromosome; GDSP_PEAKS_DIRECT=1
+	// evaluates every base with the kernel below).  With fused multiply-adds the kernel below is the faster one (204).
+	if ((mode == GDSP_FIR_EXACT) && (getenv ("GDSP_PEAKS_DIRECT") == NULL))
+		return gdsp_hann_extrema_apply (d_in, d_out, n, W, plan->h_taps, 0, N, wantMax, fill, stream);
 	if (mode == GDSP_FIR_FMA)
 		{ if (wantMax) fir_extrema_launch<true, true>  (d_in, d_out, n, plan->h_taps, h, fill, s);
 		  else         fir_extrema_launch<true, false> (d_in, d_out, n, plan->h_taps, h, fill, s); }

@@ -47,6 +47,8 @@
 // With that, the mode differs from the reference by rounding only, on any input.
 
 #include <math.h>
+#include <stdlib.h>
+#include <float.h>
 #include <string.h>
 #include <algorithm>
 #include <mutex>
@@ -127,21 +129,19 @@ template <int W> struct HannConsts
 	double scale;                                                  // c = 1 / (2 * sum of raw taps)
 	};
 
-template <int W>
-__global__ __launch_bounds__(HN_THREADS)
-void hann_blocks_kernel (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t ntiles,
-                         HannConsts<W> K, const double* __restrict__ taps)
+// Staging and phases 0-2 for one tile whose first staged element is e0 (even): on return acc[u] of a live thread p holds
+// output (p - HALO_L)*16 + u of the tile, unless the tile must not go through the block sums (the return value: uniform
+// over the workgroup), and the staged inputs are still in the LDS image (no barrier after the last read).
+// With STATS, stats[wave] = { largest magnitude's high word, bit 0: a sign bit is set, bit 1: 0 < |x| < 2^-500 } of the wave's
+// 64 blocks (visible on return).
+template <int W, bool STATS = false>
+__device__ __forceinline__ bool hann_tile_sums (double* lds, double (*tot)[HN_THREADS], uint32_t* huge,
+                                                const double* __restrict__ in, uint32_t n, int64_t e0,
+                                                const HannConsts<W>& K, double (&acc)[HN_G], uint32_t (*stats)[2] = NULL)
 	{
 	typedef HannGeom<W> G;
-	__shared__ __attribute__((aligned(16))) double lds[HN_THREADS * HN_PITCH];
-	__shared__ double tot[3][HN_THREADS];
-	__shared__ __attribute__((aligned(16))) uint32_t huge[HN_THREADS/64];
-
-	const uint32_t tile = gdsp_xcd_tile (blockIdx.x, ntiles);
-	const int64_t  out0 = (int64_t) tile * G::OUT;
-	const int64_t  e0   = out0 - G::LEAD;                         // first staged element (even)
-	const int      p    = threadIdx.x;
-	const bool     live = (p >= G::HALO_L) && (p < HN_THREADS - G::HALO_R);
+	const int  p    = threadIdx.x;
+	const bool live = (p >= G::HALO_L) && (p < HN_THREADS - G::HALO_R);
 
 	// ---- stage 4096 elements, zero outside the chromosome
 	if ((e0 >= 0) && (e0 + HN_ELEMS <= (int64_t) n))
@@ -169,7 +169,6 @@ void hann_blocks_kernel (const double* __restrict__ in, double* __restrict__ out
 	__syncthreads ();
 
 	// ---- phase 0: the E taps at either end of each of the 16 windows, directly
-	double acc[HN_G];
 #pragma unroll
 	for (int s=0 ; s<HN_G ; s++) acc[s] = 0.0;
 	if (live)
@@ -201,11 +200,18 @@ void hann_blocks_kernel (const double* __restrict__ in, double* __restrict__ out
 		const double* xb = lds + p * HN_PITCH;
 		double a0 = 0.0, ar = 0.0, ai = 0.0;
 		uint32_t big = 0;                                          // largest exponent seen in the own block
+		uint32_t signs = 0;  bool tiny = false;
 #pragma unroll
 		for (int u=0 ; u<HN_G ; u++)
 			{
 			const double x = xb[u];
 			big = max (big, hann_magnitude_hi (x));
+			if (STATS)
+				{
+				const uint32_t hi = (uint32_t) (__double_as_longlong (x) >> 32), lo = (uint32_t) __double_as_longlong (x);
+				signs |= hi;
+				tiny = tiny || (((hi & 0x7FFFFFFFu) < 0x20B00000u) && (((hi & 0x7FFFFFFFu) | lo) != 0));
+				}
 			a0 += x;
 			ar  = __builtin_fma (x, K.ownC[u], ar);
 			ai  = __builtin_fma (x, K.ownS[u], ai);
@@ -214,6 +220,13 @@ void hann_blocks_kernel (const double* __restrict__ in, double* __restrict__ out
 		tot[0][p] = a0;  tot[1][p] = ar;  tot[2][p] = ai;
 		const bool any = (__builtin_amdgcn_ballot_w64 (big >= HN_HUGE_HI) != 0);   // the 256 blocks are the whole tile
 		if ((p & 63) == 0) huge[p >> 6] = any? 1u : 0u;
+		if (STATS)
+			{
+			const uint32_t flags = ((__builtin_amdgcn_ballot_w64 ((signs >> 31) != 0) != 0)? 1u : 0u)
+			                     | ((__builtin_amdgcn_ballot_w64 (tiny) != 0)? 2u : 0u);
+			for (int off=32 ; off>0 ; off>>=1) big = max (big, (uint32_t) __shfl_xor ((int) big, off, 64));
+			if ((p & 63) == 0) { stats[p >> 6][0] = big;  stats[p >> 6][1] = flags; }
+			}
 		}
 	__syncthreads ();
 	const uint4 hg     = *reinterpret_cast<const uint4*> (huge);
@@ -266,6 +279,27 @@ void hann_blocks_kernel (const double* __restrict__ in, double* __restrict__ out
 			acc[u] = K.scale * ((z0 - c) + acc[u]);
 			}
 		}
+	return direct;
+	}
+
+template <int W>
+__global__ __launch_bounds__(HN_THREADS)
+void hann_blocks_kernel (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t ntiles,
+                         HannConsts<W> K, const double* __restrict__ taps)
+	{
+	typedef HannGeom<W> G;
+	__shared__ __attribute__((aligned(16))) double lds[HN_THREADS * HN_PITCH];
+	__shared__ double tot[3][HN_THREADS];
+	__shared__ __attribute__((aligned(16))) uint32_t huge[HN_THREADS/64];
+
+	const uint32_t tile = gdsp_xcd_tile (blockIdx.x, ntiles);
+	const int64_t  out0 = (int64_t) tile * G::OUT;
+	const int64_t  e0   = out0 - G::LEAD;                         // first staged element (even)
+	const int      p    = threadIdx.x;
+	const bool     live = (p >= G::HALO_L) && (p < HN_THREADS - G::HALO_R);
+
+	double acc[HN_G];
+	const bool direct = hann_tile_sums<W> (lds, tot, huge, in, n, e0, K, acc);
 	if (direct) hann_direct_tile (lds, taps, W, G::LO, G::OUT);    // (output o sits under taps LO+o .. LO+o+W-1 of the staged elements)
 	else
 		{
@@ -304,10 +338,9 @@ void hann_blocks_kernel (const double* __restrict__ in, double* __restrict__ out
 	}
 
 template <int W>
-static void hann_launch (const double* d_in, double* d_out, uint32_t n, const double* d_taps, hipStream_t s)
+static void hann_consts (HannConsts<W>& K)
 	{
 	typedef HannGeom<W> G;
-	HannConsts<W> K;
 	const double pi = 3.14159265358979323846264;
 	const int    M  = W + 1;                                       // the window's period
 	auto cs = [&] (long m, double* c, double* sn)                   // exp(j*2*pi*m/M), argument reduced first
@@ -328,8 +361,306 @@ static void hann_launch (const double* d_in, double* d_out, uint32_t n, const do
 		total += (1 - cos (2*pi*((kk+1) / (double) M))) / 2;
 		}
 	K.scale = 0.5 / total;
+	}
+
+template <int W>
+static void hann_launch (const double* d_in, double* d_out, uint32_t n, const double* d_taps, hipStream_t s)
+	{
+	typedef HannGeom<W> G;
+	HannConsts<W> K;
+	hann_consts<W> (K);
 	const uint32_t ntiles = (uint32_t) (((uint64_t) n + G::OUT - 1) / G::OUT);
 	hipLaunchKernelGGL ((hann_blocks_kernel<W>), dim3(ntiles), dim3(HN_THREADS), 0, s, d_in, d_out, n, ntiles, K, d_taps);
+	}
+
+// ------------------------------------------- smooth fused with localmax / localmin, filtered ----
+// `= smooth W=101 = localmax N` (BASELINE configs[2]) has to give the reference's bits: the survivors carry their
+// smoothed value and the neighbourhood test is a strict comparison of smoothed values, so every value that reaches the
+// output or decides a comparison must be the reference's own -- 101 multiplies and 100 adds, each rounded, in order.
+// Evaluating every base that way keeps the FP64 pipe busy 94 % of the time at 0.28 of the HBM rate
+// (fir_fixed_extrema_kernel).  But few bases need it.  The block sums above give every smoothed value to within
+// eps = KAPPA * sum|w_k x_k| of the reference's (KAPPA = 16 W 2^-52: sixteen times the bound the tolerance tests hold
+// the block sums to, forty times the worst ratio ever measured, profiles/r02_hann_adversarial.txt), and with an
+// interval [s - eps, s + eps] around each:
+//   - a base whose interval lies wholly below a neighbour's is beaten whatever the exact values are: fill, nothing more;
+//   - any other base is a candidate: its exact value is needed (it may be output), and so are the exact values of the
+//     neighbours whose intervals overlap its own; neighbours wholly below cannot beat it;
+//   - the candidates and those neighbours -- the local extrema of a smoothed signal and what ties with them, a few
+//     per cent of the bases -- are evaluated tap by tap in the reference's order, and the test is repeated on exact values.
+// The outcome is the reference's bit for bit; only the work is filtered.  sum|w_k x_k| is the smoothed value itself
+// where the tile holds no negative input (read depth: eps relative, and an all-zero window is exactly zero, so zero
+// stretches cost nothing); otherwise the largest magnitude of the tile bounds it (the taps add up to 1).  A tile holding
+// NaN, an infinity, a magnitude of 2^1017 or more (as above) or a nonzero magnitude below 2^-500 (products that
+// underflow) evaluates every base exactly.
+template <int W> struct HannTaps { double w[W]; };
+#define HX_LIST 1024                                    // doubles of the buffer that holds the block totals, then the list: 4096 entries of 2 bytes
+#define HX_HMAX 8                                       // neighbourhoods up to 17 bases take the unrolled interval test
+
+// HH = the neighbourhood's half width when it is at most HX_HMAX (the interval test then runs unrolled, one block of 16
+// bases per thread), 0 for any other (a loop).
+template <int W, bool FMA, bool MAX, int HH>
+__global__ __launch_bounds__(HN_THREADS)
+void hann_extrema_kernel (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t ntiles,
+                          HannConsts<W> K, HannTaps<W> taps, int h, double fill)
+	{
+	typedef HannGeom<W> G;
+	constexpr int    NWORD = (G::OUT + 31) / 32;
+	constexpr double KAPPA = 16.0 * W * 2.220446049250313e-16;
+	// the staged inputs stay (the exact evaluation reads them: from global memory, L2 hits as they are, it took 2.5 us
+	// per tile); the smoothed values -- approximate, then (where needed) exact -- get an image of their own.  78 KiB:
+	// two workgroups per CU, which is what the registers allow anyway.
+	__shared__ __attribute__((aligned(16))) double lds[HN_THREADS * HN_PITCH];
+	__shared__ __attribute__((aligned(16))) double totbuf[HX_LIST];    // block totals, later the list
+	__shared__ __attribute__((aligned(16))) double sm[(G::OUT / HN_G) * HN_PITCH];
+	__shared__ uint32_t candBits[NWORD], needBits[NWORD], markBits[NWORD];
+	__shared__ __attribute__((aligned(16))) uint32_t huge[HN_THREADS/64];
+	__shared__ uint32_t stats[HN_THREADS/64][2], counters[2];
+	double (*tot)[HN_THREADS] = reinterpret_cast<double (*)[HN_THREADS]> (totbuf);
+	static_assert (sizeof(double) * 3 * HN_THREADS <= sizeof(double) * HX_LIST, "block totals need 6 KiB");
+	static_assert (G::OUT <= 4 * HX_LIST, "the list holds 2-byte entries");
+	static_assert (NWORD <= 4 * 32, "a wave scans 32 words of flags");
+	static_assert (G::OUT % HN_G == 0, "whole blocks");
+
+	const int      p         = threadIdx.x, lane = p & 63, wave = p >> 6;
+	const int      sh        = h & 1;                              // keeps the first staged index even
+	const int      stride    = G::OUT - 2*h - 2*sh;                // outputs kept per tile (even)
+	const uint32_t tile      = gdsp_xcd_tile (blockIdx.x, ntiles);
+	const int64_t  keepStart = (int64_t) tile * stride;            // first output this tile stores
+	const int64_t  compStart = keepStart - h - sh;                 // first smoothed value it computes (even)
+	const int64_t  e0        = compStart - G::LEAD;
+	const bool     live      = (p >= G::HALO_L) && (p < HN_THREADS - G::HALO_R);
+	const int      blk       = p - G::HALO_L;                      // the block of smoothed values a live thread holds
+	const double   never     = MAX? -DBL_MAX : DBL_MAX;            // what a position outside the vector holds: it beats nothing
+	// smoothed values [validLo, validHi) of the tile lie inside the vector (compStart < 0 only in the first tile)
+	const int      validLo   = (compStart < 0)? (int) -compStart : 0;
+	const int      validHi   = (compStart + G::OUT <= (int64_t) n)? G::OUT : (int) ((int64_t) n - compStart);
+
+	if (p < NWORD) { candBits[p] = 0;  needBits[p] = 0;  markBits[p] = 0; }
+	if (p < 2) counters[p] = 0;                                    // (the barriers of the block sums come before their first use)
+	double acc[HN_G];
+	bool direct = hann_tile_sums<W, true> (lds, tot, huge, in, n, e0, K, acc, stats);
+
+	// what kind of tile: any sign bit set, any nonzero magnitude below 2^-500, the largest magnitude
+	uint32_t bigAll = 0, flagsAll = 0;
+#pragma unroll
+	for (int w=0 ; w<HN_THREADS/64 ; w++) { bigAll = max (bigAll, stats[w][0]);  flagsAll |= stats[w][1]; }
+	if (flagsAll & 2u) direct = true;
+	const bool   nonneg = ((flagsAll & 1u) == 0);
+	const double amax   = __longlong_as_double (((long long) (bigAll | 0x000FFFFFu) << 32) | 0xFFFFFFFFll);   // >= every |x| of the tile
+	const double epsAbs = KAPPA * amax;
+	auto eps = [&] (double v) { return nonneg? KAPPA * fabs (v) : epsAbs; };
+	// `a certainly beats b`: a's interval wholly beyond b's.  Without negative inputs every smoothed value is >= 0 (the
+	// stand-in for "outside the vector" aside, which these forms also treat as beating nothing) and the intervals are relative
+	const double shrink = 1.0 - KAPPA, grow = 1.0 + KAPPA, eps2 = 2.0 * epsAbs * grow;
+	auto beats = [&] (double a, double b)
+		{
+		if (MAX) return nonneg? (a * shrink > b * grow) : (a - eps2 > b);
+		else     return nonneg? (a * grow < b * shrink) : (a + eps2 < b);
+		};
+
+	// ---- approximate smoothed values (or, in a tile evaluated exactly, every base a candidate)
+	if (live)
+		{
+		double*  mine = sm + blk * HN_PITCH;
+		uint32_t bits = 0;
+#pragma unroll
+		for (int u=0 ; u<HN_G ; u++)
+			{
+			const int  c      = blk * HN_G + u;
+			const bool inside = (c >= validLo) && (c < validHi);
+			mine[u] = !inside? never : (acc[u] == 0.0)? 0.0 : acc[u];
+			if (inside) bits |= 1u << u;
+			}
+		if (direct)
+			{
+			atomicOr (&candBits[blk >> 1], bits << ((blk & 1) * 16));
+			atomicOr (&needBits[blk >> 1], bits << ((blk & 1) * 16));
+			}
+		}
+	__syncthreads ();
+
+	// The set bits of a bitmap, queued in one list for the workgroup (each wave scans 32 words and appends what it finds;
+	// the order does not matter).  The list is then worked through by threads 0, 1, ...: a few dozen bases per tile, so
+	// one wave runs the loops below and the other three skip them.  Callers put a barrier before the list is read.
+	uint16_t* list = reinterpret_cast<uint16_t*> (totbuf);
+	const int widx = wave * 32 + lane;
+	auto queue = [&] (uint32_t word, uint32_t* counter)
+		{
+		const int cnt  = __popc (word);
+		int       incl = cnt;
+		for (int d=1 ; d<32 ; d*=2) { const int up = __shfl_up (incl, d, 64);  if (lane >= d) incl += up; }
+		const int total = __shfl (incl, 31, 64);
+		int base = 0;
+		if ((lane == 0) && (total != 0)) base = (int) atomicAdd (counter, (uint32_t) total);
+		base = __shfl (base, 0, 64);
+		int off = base + incl - cnt;
+		while (word != 0) { const int b = __ffs ((int) word) - 1;  list[off++] = (uint16_t) (widx * 32 + b);  word &= word - 1; }
+		};
+	auto at = [&] (int j) { return sm[j + (j >> 4)]; };
+	const int keepLo = h + sh;                                     // smoothed values [keepLo, keepHi) are this tile's outputs
+	const int keepHi = (h + sh + stride < validHi)? h + sh + stride : validHi;
+
+	// ---- who is certainly beaten (every base: the extreme of its neighbourhood, one interval test)
+	if (!direct && (HH > 0))
+		{
+		if (live)
+			{
+			// the block and HH values either side of it, in registers; (a block is 17 doubles on in the image)
+			double v[HN_G + 2*HX_HMAX];
+			const double* mine = sm + blk * HN_PITCH;
+#pragma unroll
+			for (int t=-HH ; t<HN_G+HH ; t++)
+				{
+				const int rel = t + ((t >= HN_G)? 1 : 0) - ((t < 0)? 1 : 0);
+				v[t + HH] = ((t < 0) && (blk == 0))? never : mine[rel];     // (what lies before the first block is no output's neighbour)
+				}
+			uint32_t isCand = 0, isNeed = 0;
+#pragma unroll
+			for (int u=0 ; u<HN_G ; u+=2)
+				{
+				double mid = v[u + 1];
+#pragma unroll
+				for (int k=2 ; k<=2*HH ; k++) mid = MAX? fmax (mid, v[u + k]) : fmin (mid, v[u + k]);
+				const double ext0 = MAX? fmax (v[u], mid) : fmin (v[u], mid);
+				const double ext1 = MAX? fmax (mid, v[u + 2*HH + 1]) : fmin (mid, v[u + 2*HH + 1]);
+#pragma unroll
+				for (int q=0 ; q<2 ; q++)
+					{
+					const int    c = blk * HN_G + u + q;
+					const double x = v[u + q + HH], ext = q? ext1 : ext0;
+					// (the extreme of the window includes the base itself, which never beats itself under these tests)
+					const bool beaten = beats (ext, x);
+					const bool kept   = (c >= keepLo) && (c < keepHi);
+					if (kept && !beaten)
+						{
+						isCand |= 1u << (u + q);
+						if (!(nonneg && (x == 0.0))) isNeed |= 1u << (u + q);   // (an all-zero window is exactly zero, and only a tie can meet it)
+						}
+					}
+				}
+			if (isCand) atomicOr (&candBits[blk >> 1], isCand << ((blk & 1) * 16));
+			if (isNeed) atomicOr (&needBits[blk >> 1], isNeed << ((blk & 1) * 16));
+			}
+		}
+	else if (!direct)
+		{
+		for (int o = 2*p ; o < stride ; o += 2*HN_THREADS)
+			{
+			const int c = o + h + sh;                                  // smoothed value of output o (even)
+			double e0v = at (c - h), e1v = at (c + h + 1), mid = at (c - h + 1);
+			for (int k=2 ; k<=2*h ; k++) mid = MAX? fmax (mid, at (c - h + k)) : fmin (mid, at (c - h + k));
+			if (h > 0) { e0v = MAX? fmax (e0v, mid) : fmin (e0v, mid);  e1v = MAX? fmax (mid, e1v) : fmin (mid, e1v); }
+			else       { e0v = at (c);  e1v = at (c + 1); }
+			uint32_t isCand = 0, isNeed = 0;
+#pragma unroll
+			for (int q=0 ; q<2 ; q++)
+				{
+				if (c + q >= keepHi) continue;
+				const double x = at (c + q), ext = q? e1v : e0v;
+				if (beats (ext, x)) continue;
+				isCand |= 1u << q;
+				if (!(nonneg && (x == 0.0))) isNeed |= 1u << q;
+				}
+			if (isCand) atomicOr (&candBits[c >> 5], isCand << (c & 31));     // (c is even: c + 1 sits in the same word)
+			if (isNeed) atomicOr (&needBits[c >> 5], isNeed << (c & 31));
+			}
+		}
+	__syncthreads ();
+
+	// ---- the neighbours whose intervals overlap a candidate's: their exact values are needed too
+	if (!direct)
+		{
+		queue (((lane < 32) && (widx < NWORD))? needBits[widx] : 0, &counters[0]);
+		__syncthreads ();
+		const int total = (int) counters[0];
+		for (int t=p ; t<total ; t+=HN_THREADS)
+			{
+			const int    ci = list[t];
+			const double x  = at (ci), mineLo = x - eps (x), mineHi = x + eps (x);
+			for (int j=ci-h ; j<=ci+h ; j++)
+				{
+				const double vj = at (j);
+				const bool overlaps = MAX? (vj + eps (vj) > mineLo) : (vj - eps (vj) < mineHi);
+				if (overlaps && (j != ci) && !(nonneg && (vj == 0.0))) atomicOr (&markBits[j >> 5], 1u << (j & 31));
+				}
+			}
+		__syncthreads ();
+		}
+
+	// ---- exact values where they are needed: tap by tap in the reference's order (sum.c:655-663)
+	queue (((lane < 32) && (widx < NWORD))? (needBits[widx] | markBits[widx]) : 0, &counters[1]);
+	__syncthreads ();
+	const int nexact = (int) counters[1];
+	for (int t=p ; t<nexact ; t+=HN_THREADS)
+		{
+		const int c = list[t];
+		const int e = G::LO + c;                                   // the window's first staged element
+		// element e+k sits at e+k + ((e+k) >> 4) in the image: with e = 16 q + r that is 17 q + r + k + ((r + k) >> 4), and
+		// (r + k) >> 4 = (k >> 4) + ((k & 15) >= 16 - r).  Sixteen addresses per lane, one for each k & 15, leave every
+		// tap's read with a compile-time offset: one instruction instead of four.
+		const double* at16[16];
+#pragma unroll
+		for (int j=0 ; j<16 ; j++) at16[j] = lds + (e + (e >> 4)) + ((j >= 16 - (e & 15))? 1 : 0);
+		double a = 0.0;
+#pragma unroll
+		for (int k=0 ; k<W ; k++)
+			{
+			const double x = at16[k & 15][k + (k >> 4)];
+			a = FMA? __builtin_fma (taps.w[k], x, a) : a + taps.w[k] * x;
+			}
+		sm[c + (c >> 4)] = a;
+		}
+	__syncthreads ();
+
+	// ---- the test again, on exact values: every base evaluated exactly strikes the candidates it beats
+	for (int t=p ; t<nexact ; t+=HN_THREADS)
+		{
+		const int    cj = list[t];
+		const double vj = at (cj);
+		for (int i=cj-h ; i<=cj+h ; i++)
+			{
+			if ((i < 0) || (i >= G::OUT) || (i == cj)) continue;
+			if (((candBits[i >> 5] >> (i & 31)) & 1) == 0) continue;
+			const double vi = at (i);                                  // a candidate's value is exact: evaluated, or an exact zero
+			if (MAX? (vj > vi) : (vj < vi)) atomicAnd (&candBits[i >> 5], ~(1u << (i & 31)));
+			}
+		}
+	__syncthreads ();
+
+	double* dst = out + keepStart;
+	for (int c = keepLo + 2*p ; c < keepHi ; c += 2*HN_THREADS)    // (c even: the pair shares a word of flags and a block of values)
+		{
+		const uint32_t two = candBits[c >> 5] >> (c & 31);
+		const double*  val = sm + c + (c >> 4);
+		const double   r0  = (two & 1u)? val[0] : fill;
+		const double   r1  = (two & 2u)? val[1] : fill;
+		if (c + 1 < keepHi) *reinterpret_cast<double2*> (dst + (c - keepLo)) = make_double2 (r0, r1);
+		else                dst[c - keepLo] = r0;
+		}
+	}
+
+int gdsp_hann_extrema_apply (const double* d_in, double* d_out, uint32_t n, uint32_t W, const double* h_taps, int fma,
+                             uint32_t N, int wantMax, double fill, void* stream)
+	{
+	GDSP_REQUIRE (W == 101, "filtered smooth+extrema is built for W = 101");
+	typedef HannGeom<101> G;
+	const int h = (int) ((N - 1) / 2);
+	GDSP_REQUIRE ((h >= 0) && (h <= 64), "neighbourhood too wide for the fused kernel");
+	HannConsts<101> K;
+	hann_consts<101> (K);
+	HannTaps<101> taps;
+	memcpy (taps.w, h_taps, sizeof(taps.w));
+	const int      stride = G::OUT - 2*h - 2*(h & 1);
+	const uint32_t ntiles = (uint32_t) (((uint64_t) n + stride - 1) / stride);
+	hipStream_t    s      = gdsp_stream (stream);
+#define HX_LAUNCH_H(FF, MM, HHH) hipLaunchKernelGGL ((hann_extrema_kernel<101, FF, MM, HHH>), dim3(ntiles), dim3(HN_THREADS), 0, s, d_in, d_out, n, ntiles, K, taps, h, fill)
+#define HX_LAUNCH(FF, MM) do { if (h == 5) HX_LAUNCH_H (FF, MM, 5);  else HX_LAUNCH_H (FF, MM, 0); } while (0)
+	GDSP_REQUIRE (!fma, "the filtered kernel is built for the reference's arithmetic (with fused multiply-adds the direct kernel is faster)");
+	if (wantMax) HX_LAUNCH (false, true);  else HX_LAUNCH (false, false);
+#undef HX_LAUNCH_H
+#undef HX_LAUNCH
+	GDSP_LAUNCH_CHECK ();
+	return GDSP_OK;
 	}
 
 // ------------------------------------------------------ any window, 81 .. 2001 ----

@@ -5,6 +5,8 @@ bit-exact in EXACT mode and within one rounding per floating-point op in FMA mod
 running-sum operators bit-exact on exactly-summable signals (read depth) and within
 the reference's own accumulated rounding on arbitrary reals (bound stated inline).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -617,6 +619,55 @@ def test_fused_smooth_localmax_is_the_two_operators(n, N, gd):
     assert gd.lib().gdsp_smooth_local_extrema_fusable(101, 11) == 1
     assert gd.lib().gdsp_smooth_local_extrema_fusable(21, 11) == 0
     assert gd.lib().gdsp_smooth_local_extrema_fusable(101, 131) == 0
+
+
+def _filter_cases(n, rng):
+    """Signals for the filtered fused kernel (hann_extrema_kernel): ties, near-ties, zero stretches, mixed signs, and the
+    values that send a tile to the tap-by-tap evaluation."""
+    t = np.arange(n)
+    cases = {}
+    x = np.full(n, 30.0); x[n // 3: n // 2] = 31.0; x[n // 2: n // 2 + 7] = 0.0
+    cases["flat steps"] = x                                       # long stretches of equal smoothed values
+    x = _signal("depth", n, rng); x[(t // 700) % 3 == 1] = 0.0
+    cases["zero islands"] = x
+    cases["mixed signs"] = _signal("real", n, rng) - 40.0
+    x = _signal("real", n, rng); half = n // 2; x[n - half:] = x[:half][::-1]
+    cases["mirror image"] = x                                     # smoothed values either side of the centre agree to a rounding
+    cases["period 7"] = (t % 7 == 0) * 5.0 + (t % 7 == 3) * 5.0
+    x = np.zeros(n); x[::2] = -0.0; x[n // 4] = 2.0
+    cases["signed zeros"] = x
+    x = _signal("real", n, rng) * 1e-200; x[(t // 500) % 2 == 0] = 0.0
+    cases["below 2^-500"] = x
+    x = _signal("real", n, rng); x[n // 5] = 2.0 ** 1020; x[n // 2] = -2.0 ** 1018
+    cases["huge"] = x
+    x = _signal("depth", n, rng); x[n // 7] = np.inf; x[n // 3] = np.nan; x[n // 2] = -np.inf
+    cases["nan and inf"] = x
+    x = rng.standard_normal(n); x[np.abs(x) < 0.3] = 0.0
+    cases["sparse noise"] = x
+    return cases
+
+
+@pytest.mark.parametrize("n", [3971, 3972, 3973, 3974, 7944, 7945, 20011])
+@pytest.mark.parametrize("N", [2, 3, 11, 12, 41])
+def test_filtered_smooth_extrema_is_bit_identical(n, N, gd):
+    """`smooth W=101 = localmax|localmin N` evaluates tap by tap only the bases the block sums cannot rule out
+    (gdsp_hann.hip: hann_extrema_kernel, tiles of 3984 - 2h - 2(h&1) outputs): the output is still that of the two
+    reference loops run one after the other, on every kind of signal, and that of the kernel that evaluates every base."""
+    rng = np.random.default_rng(n * 131 + N)
+    for name, x in _filter_cases(n, rng).items():
+        d = gd.DeviceVector.from_numpy(x)
+        with np.errstate(all="ignore"):
+            sm = cpu.smooth(x, 101)
+        for want_max, fill in ((True, 0.0), (False, cpu.DBL_MAX)):
+            got = gd.smooth_local_extrema(d, 101, N, want_max, fill).numpy()
+            want = cpu.local_extrema(sm, N, 1 if want_max else 0, fill)
+            assert bits_equal(got, want), (name, want_max, first_diff(got, want))
+            os.environ["GDSP_PEAKS_DIRECT"] = "1"                  # ... and of the kernel that evaluates every base
+            try:
+                every = gd.smooth_local_extrema(d, 101, N, want_max, fill).numpy()
+            finally:
+                del os.environ["GDSP_PEAKS_DIRECT"]
+            assert bits_equal(got, every), (name, want_max, "direct", first_diff(got, every))
 
 
 @pytest.mark.parametrize("n", [1, 2, 127, 129, 16384, 16385, 100000, 300007])

@@ -49,6 +49,8 @@ OPS = {
     "smooth_hann50001": (None, lambda: gd.smooth(real, 50001, out=b, mode=gd.FIR_HANN, stream=s)),
     "smooth_exact": (None, lambda: gd.smooth(real, 101, out=b, mode=gd.FIR_EXACT, stream=s)),
     "smooth_fma": (None, lambda: gd.smooth(real, 101, out=b, mode=gd.FIR_FMA, stream=s)),
+    "peaks_exact": (None, lambda: gd.smooth_local_extrema(real, 101, 11, True, 0.0, out=b, stream=s)),
+    "peaks_fma": (None, lambda: gd.smooth_local_extrema(real, 101, 11, True, 0.0, out=b, mode=gd.FIR_FMA, stream=s)),
 }
 for name in op.split(","):
     if name not in OPS and name.startswith("smooth_hann"):          # any window: smooth_hann<W>
