@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json from the rocprofv3 summaries tools/prof_any.sh writes (profiles/r02_prof_<op>.txt): per kernel the
+HBM bytes of one launch (FETCH_SIZE, WRITE_SIZE, corrected as the summaries say) over its algorithmic bytes (B/base of
+the operator x bases of the launch).  bench.py multiplies a live launch's algorithmic bytes by that ratio for
+roofline.traffic and prints where the ratio came from.
+usage: python3 tools/make_traffic.py <library build id> [profiles dir]"""
+import glob
+import json
+import os
+import re
+import sys
+
+SKIP = ("synth_coverage_kernel", "__amd_rocclr", "fill", "copyBuffer")
+# bytes the operator has to move per base: in + out, or in only for the passes that only read
+ALGORITHMIC = {"pc_sample_kernel": 8, "pc_partition_kernel": 8, "cumsum_totals_kernel": 8, "report_count_kernel": 8,
+               "report_write_kernel": 8, "clump_chunk_stats_kernel": 8, "clump_write_kernel": 8,
+               # launches over a few words per chunk, or whose traffic is not a per-base figure: bytes only
+               "clump_chunk_scan_kernel": None, "clump_bits_": None, "report_scan_kernel": None, "pc_hist_keys_kernel": None,
+               "cumsum_offsets_kernel": None, "hf_": None, "window_sum_rows_kernel": None}
+
+lib = sys.argv[1]
+root = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+kernels = {}
+for path in sorted(glob.glob(os.path.join(root, "r02_prof_*.txt"))):
+    lines = open(path).read().splitlines()
+    m = re.match(r"# (\S+) on (\d+) bases", lines[0])
+    if not m:
+        continue
+    bases = int(m.group(2))
+    for line in lines:
+        f = line[74:].split()
+        if line.startswith("#") or line.startswith("kernel") or len(f) < 6:
+            continue
+        name = line[:74].split("(")[0].replace("void ", "").strip()
+        if any(s in name for s in SKIP) or name in kernels:
+            continue
+        try:
+            fetch, write = int(f[3]), int(f[4])
+        except ValueError:
+            continue
+        per_base = 16
+        for key, val in ALGORITHMIC.items():
+            if name.startswith(key):
+                per_base = val
+        entry = {"source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; tools/prof_any.sh)" % os.path.basename(path),
+                 "library": lib, "bases_per_launch": bases, "fetch_bytes": fetch, "write_bytes": write}
+        if per_base is not None:
+            entry["algorithmic_bytes"] = per_base * bases
+            entry["hbm_bytes_over_algorithmic"] = round((fetch + write) / (per_base * bases), 4)
+        kernels[name] = entry
+note = ("HBM bytes per launch over algorithmic bytes, from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (gfx950 "
+        "corrections of MI355X_MICROARCH.md applied: FETCH_SIZE doubled, KiB -> bytes); `library` = git hash of the build that was "
+        "profiled, so a stale ratio shows in bench.py's roofline.traffic_measured; written by tools/make_traffic.py")
+with open(os.path.join(root, "traffic.json"), "w") as f:
+    json.dump({"note": note, "kernels": kernels}, f, indent=1)
+print("%d kernels" % len(kernels))
