@@ -50,6 +50,7 @@ OPS = {
     "smooth_exact": (None, lambda: gd.smooth(real, 101, out=b, mode=gd.FIR_EXACT, stream=s)),
     "smooth_fma": (None, lambda: gd.smooth(real, 101, out=b, mode=gd.FIR_FMA, stream=s)),
     "peaks_exact": (None, lambda: gd.smooth_local_extrema(real, 101, 11, True, 0.0, out=b, stream=s)),
+    "peaks_exact_depth": (None, lambda: gd.smooth_local_extrema(depth, 101, 11, True, 0.0, out=b, stream=s)),
     "peaks_fma": (None, lambda: gd.smooth_local_extrema(real, 101, 11, True, 0.0, out=b, mode=gd.FIR_FMA, stream=s)),
 }
 for name in op.split(","):
