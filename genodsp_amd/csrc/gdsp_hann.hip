@@ -416,7 +416,7 @@ void hann_extrema_kernel (const double* __restrict__ in, double* __restrict__ ou
 	__shared__ __attribute__((aligned(16))) double sm[(G::OUT / HN_G) * HN_PITCH];
 	__shared__ uint32_t candBits[NWORD], needBits[NWORD], markBits[NWORD];
 	__shared__ __attribute__((aligned(16))) uint32_t huge[HN_THREADS/64];
-	__shared__ uint32_t stats[HN_THREADS/64][2], counters[2];
+	__shared__ uint32_t stats[HN_THREADS/64][2];
 	double (*tot)[HN_THREADS] = reinterpret_cast<double (*)[HN_THREADS]> (totbuf);
 	static_assert (sizeof(double) * 3 * HN_THREADS <= sizeof(double) * HX_LIST, "block totals need 6 KiB");
 	static_assert (G::OUT <= 4 * HX_LIST, "the list holds 2-byte entries");
@@ -440,8 +440,7 @@ void hann_extrema_kernel (const double* __restrict__ in, double* __restrict__ ou
 	const int      validLo   = (compStart < 0)? (int) -compStart : 0;
 	const int      validHi   = (compStart + G::OUT <= (int64_t) n)? G::OUT : (int) ((int64_t) n - compStart);
 
-	if (p < NWORD) { candBits[p] = 0;  needBits[p] = 0;  markBits[p] = 0; }
-	if (p < 2) counters[p] = 0;                                    // (the barriers of the block sums come before their first use)
+	if (p < NWORD) { candBits[p] = 0;  needBits[p] = 0;  markBits[p] = 0; }       // (the barriers of the block sums come before their first use)
 	double acc[HN_G];
 	bool direct = hann_tile_sums<W, true> (lds, tot, huge, in, n, e0, K, acc, stats);
 
@@ -484,23 +483,28 @@ void hann_extrema_kernel (const double* __restrict__ in, double* __restrict__ ou
 		}
 	__syncthreads ();
 
-	// The set bits of a bitmap, queued in one list for the workgroup (each wave scans 32 words and appends what it finds;
-	// the order does not matter).  The list is then worked through by threads 0, 1, ...: a few dozen bases per tile, so
-	// one wave runs the loops below and the other three skip them.  Callers put a barrier before the list is read.
+	// The set bits of a bitmap of the tile, queued by one wave (two words per lane, the list in LDS); returns how many.
 	uint16_t* list = reinterpret_cast<uint16_t*> (totbuf);
-	const int widx = wave * 32 + lane;
-	auto queue = [&] (uint32_t word, uint32_t* counter)
+	auto queue = [&] (const uint32_t* bitsA, const uint32_t* bitsB)
 		{
-		const int cnt  = __popc (word);
-		int       incl = cnt;
-		for (int d=1 ; d<32 ; d*=2) { const int up = __shfl_up (incl, d, 64);  if (lane >= d) incl += up; }
-		const int total = __shfl (incl, 31, 64);
-		int base = 0;
-		if ((lane == 0) && (total != 0)) base = (int) atomicAdd (counter, (uint32_t) total);
-		base = __shfl (base, 0, 64);
-		int off = base + incl - cnt;
-		while (word != 0) { const int b = __ffs ((int) word) - 1;  list[off++] = (uint16_t) (widx * 32 + b);  word &= word - 1; }
+		int total = 0;
+#pragma unroll
+		for (int half=0 ; half<2 ; half++)
+			{
+			const int idx  = half * 64 + lane;
+			uint32_t  word = (idx < NWORD)? (bitsA[idx] | ((bitsB != NULL)? bitsB[idx] : 0u)) : 0u;
+			const int cnt  = __popc (word);
+			int       incl = cnt;
+			for (int d=1 ; d<64 ; d*=2) { const int up = __shfl_up (incl, d, 64);  if (lane >= d) incl += up; }
+			int off = total + incl - cnt;
+			total  += __shfl (incl, 63, 64);
+			while (word != 0) { const int b = __ffs ((int) word) - 1;  list[off++] = (uint16_t) (idx * 32 + b);  word &= word - 1; }
+			}
+		__builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier ();
+		return total;
 		};
+	auto wave_sync = [] () { __builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");  __builtin_amdgcn_wave_barrier (); };
 	auto at = [&] (int j) { return sm[j + (j >> 4)]; };
 	const int keepLo = h + sh;                                     // smoothed values [keepLo, keepHi) are this tile's outputs
 	const int keepHi = (h + sh + stride < validHi)? h + sh + stride : validHi;
@@ -572,13 +576,35 @@ void hann_extrema_kernel (const double* __restrict__ in, double* __restrict__ ou
 		}
 	__syncthreads ();
 
+	// From here on the work is a few dozen bases per tile, so one wave does it, with no barrier of the workgroup in its
+	// way, while the other three write the tile's bulk -- fill where a base is beaten, the (exact) zero of a candidate
+	// in a zero stretch -- and leave: every pair of outputs that holds no candidate awaiting an exact value.
+	double* dst = out + keepStart;
+	auto store_pair = [&] (int c)                                  // (c even: the pair shares a word of flags and a block of values)
+		{
+		const uint32_t two = candBits[c >> 5] >> (c & 31);
+		const double*  val = sm + c + (c >> 4);
+		const double   r0  = (two & 1u)? val[0] : fill;
+		const double   r1  = (two & 2u)? val[1] : fill;
+		if (c + 1 < keepHi) *reinterpret_cast<double2*> (dst + (c - keepLo)) = make_double2 (r0, r1);
+		else                dst[c - keepLo] = r0;
+		};
+	if ((wave != 0) && (probeStep == 0))
+		{
+		for (int c = keepLo + 2*(p - 64) ; c < keepHi ; c += 2*(HN_THREADS - 64))
+			{
+			const uint32_t pending = needBits[c >> 5] >> (c & 31);      // (flags of the interval test: nobody changes them any more)
+			if ((pending & 3u) == 0) store_pair (c);
+			}
+		return;
+		}
+	if (wave != 0) return;
+
 	// ---- the neighbours whose intervals overlap a candidate's: their exact values are needed too
 	if (!direct)
 		{
-		queue (((lane < 32) && (widx < NWORD))? needBits[widx] : 0, &counters[0]);
-		__syncthreads ();
-		const int total = (int) counters[0];
-		for (int t=p ; t<total ; t+=HN_THREADS)
+		const int total = queue (needBits, NULL);
+		for (int t=lane ; t<total ; t+=64)
 			{
 			const int    ci = list[t];
 			const double x  = at (ci), mineLo = x - eps (x), mineHi = x + eps (x);
@@ -589,15 +615,13 @@ void hann_extrema_kernel (const double* __restrict__ in, double* __restrict__ ou
 				if (overlaps && (j != ci) && !(nonneg && (vj == 0.0))) atomicOr (&markBits[j >> 5], 1u << (j & 31));
 				}
 			}
-		__syncthreads ();
+		wave_sync ();
 		}
 
 	// ---- exact values where they are needed: tap by tap in the reference's order (sum.c:655-663)
-	queue (((lane < 32) && (widx < NWORD))? (needBits[widx] | markBits[widx]) : 0, &counters[1]);
-	__syncthreads ();
-	const int nexact = (int) counters[1];
-	if (probeStep != 0) { if (p == 0) atomicAdd (probeCount, (unsigned int) nexact);  return; }
-	for (int t=p ; t<nexact ; t+=HN_THREADS)
+	const int nexact = queue (needBits, markBits);
+	if (probeStep != 0) { if (lane == 0) atomicAdd (probeCount, (unsigned int) nexact);  return; }
+	for (int t=lane ; t<nexact ; t+=64)
 		{
 		const int c = list[t];
 		const int e = G::LO + c;                                   // the window's first staged element
@@ -616,10 +640,10 @@ void hann_extrema_kernel (const double* __restrict__ in, double* __restrict__ ou
 			}
 		sm[c + (c >> 4)] = a;
 		}
-	__syncthreads ();
+	wave_sync ();
 
 	// ---- the test again, on exact values: every base evaluated exactly strikes the candidates it beats
-	for (int t=p ; t<nexact ; t+=HN_THREADS)
+	for (int t=lane ; t<nexact ; t+=64)
 		{
 		const int    cj = list[t];
 		const double vj = at (cj);
@@ -631,17 +655,17 @@ void hann_extrema_kernel (const double* __restrict__ in, double* __restrict__ ou
 			if (MAX? (vj > vi) : (vj < vi)) atomicAnd (&candBits[i >> 5], ~(1u << (i & 31)));
 			}
 		}
-	__syncthreads ();
+	wave_sync ();
 
-	double* dst = out + keepStart;
-	for (int c = keepLo + 2*p ; c < keepHi ; c += 2*HN_THREADS)    // (c even: the pair shares a word of flags and a block of values)
+	// ---- and the pairs of outputs that were waiting: once each, by the candidate that is first in its pair
+	for (int t=lane ; t<nexact ; t+=64)
 		{
-		const uint32_t two = candBits[c >> 5] >> (c & 31);
-		const double*  val = sm + c + (c >> 4);
-		const double   r0  = (two & 1u)? val[0] : fill;
-		const double   r1  = (two & 2u)? val[1] : fill;
-		if (c + 1 < keepHi) *reinterpret_cast<double2*> (dst + (c - keepLo)) = make_double2 (r0, r1);
-		else                dst[c - keepLo] = r0;
+		const int c = list[t], c2 = c & ~1;
+		if ((c < keepLo) || (c >= keepHi)) continue;
+		const uint32_t pending = (needBits[c2 >> 5] >> (c2 & 31)) & 3u;   // (every base flagged by the interval test was a candidate then)
+		if (((needBits[c >> 5] >> (c & 31)) & 1u) == 0) continue;           // a neighbour evaluated for a comparison only
+		if ((c & 1) && (pending & 1u)) continue;                             // the pair is its first candidate's
+		store_pair (c2);
 		}
 	}
 
