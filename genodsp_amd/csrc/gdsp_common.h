@@ -34,10 +34,9 @@ void gdsp_set_error (const char* fmt, ...);
 bool gdsp_hann_blocks_available (uint32_t W);
 int  gdsp_hann_blocks_apply (const double* d_in, double* d_out, uint32_t n, uint32_t W, void* stream);
 // ... and `smooth W=101 = localmax|localmin N` with the block sums as a filter in front of the exact evaluation (bit-identical to
-// it).  On return *d_gate is NULL when the output is complete; otherwise a probe on the device decides: the caller launches the
-// kernel that evaluates every base gated on *d_gate > gateLimit (it leaves at once when the filtered kernel did the work)
+// it; opt-in, see gdsp_smooth_local_extrema)
 int  gdsp_hann_extrema_apply (const double* d_in, double* d_out, uint32_t n, uint32_t W, const double* h_taps, int fma,
-                              uint32_t N, int wantMax, double fill, void* stream, const unsigned int** d_gate, uint32_t* gateLimit);
+                              uint32_t N, int wantMax, double fill, void* stream);
 
 // gdsp_hann_far.hip: the same for windows longer than one LDS tile can hold (3201 .. 50001 taps), block totals in HBM
 bool gdsp_hann_far_available (uint32_t W);

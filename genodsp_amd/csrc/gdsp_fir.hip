@@ -154,14 +154,12 @@ void fir_fixed_kernel (const double* __restrict__ in, double* __restrict__ out,
 template <int W, int R, bool FMA, bool MAX>
 __global__ __launch_bounds__(FIR_THREADS)
 void fir_fixed_extrema_kernel (const double* __restrict__ in, double* __restrict__ out,
-                               uint32_t n, uint32_t ntiles, FirTaps<W> taps, int h, double fill,
-                               const unsigned int* __restrict__ gate, uint32_t gateLimit)
+                               uint32_t n, uint32_t ntiles, FirTaps<W> taps, int h, double fill)
 	{
 	constexpr int H  = (W - 1) / 2;
 	constexpr int T  = FIR_THREADS * R;
 	constexpr int LP = (T + W - 1 + 1 + 1) & ~1;           // room for the alignment shift
 	__shared__ __attribute__((aligned(16))) double lds[LP];
-	if ((gate != NULL) && (*gate <= gateLimit)) return;    // the filtered kernel (gdsp_hann.hip) has done the work
 
 	const int      sh        = (h + H) & 1;                // keeps the first staged index even
 	const int      stride    = T - 2*h;                    // outputs kept per tile (even)
@@ -403,14 +401,14 @@ int gdsp_smooth_taps_device (uint32_t W, const double** d_taps)
 
 template <bool FMA, bool MAX>
 static void fir_extrema_launch (const double* d_in, double* d_out, uint32_t n, const double* h_taps,
-                                int h, double fill, hipStream_t s, const unsigned int* gate = NULL, uint32_t gateLimit = 0)
+                                int h, double fill, hipStream_t s)
 	{
 	FirTaps<101> taps;
 	memcpy (taps.w, h_taps, sizeof(taps.w));
 	const int      stride = FIR_THREADS*FIR_R - 2*h;
 	const uint32_t ntiles = (uint32_t) (((uint64_t) n + stride - 1) / stride);
 	hipLaunchKernelGGL ((fir_fixed_extrema_kernel<101, FIR_R, FMA, MAX>), dim3(ntiles), dim3(FIR_THREADS), 0, s,
-	                    d_in, d_out, n, ntiles, taps, h, fill, gate, gateLimit);
+	                    d_in, d_out, n, ntiles, taps, h, fill);
 	}
 
 extern "C" {
@@ -443,24 +441,17 @@ int gdsp_smooth_local_extrema (const double* d_in, double* d_out, uint32_t n, ui
 	if (rc != GDSP_OK) return rc;
 	const int   h = (int) ((N - 1) / 2);
 	hipStream_t s = gdsp_stream (stream);
-	// EXACT: the block sums as a filter in front of the tap-by-tap evaluation, which then runs only for the bases that can
-	// survive and what ties with them (gdsp_hann.hip: 145 against 120 Gbases/s on real-valued coverage).  A probe on the
-	// device sends signals full of exact ties to the kernel below instead, which is launched behind the filtered one with
-	// the probe's word as its gate; GDSP_PEAKS_DIRECT=1 always evaluates every base.  With fused multiply-adds the kernel
-	// below is the faster one (204).
-	const unsigned int* gate = NULL;
-	uint32_t gateLimit = 0;
-	if ((mode == GDSP_FIR_EXACT) && (getenv ("GDSP_PEAKS_DIRECT") == NULL))
-		{
-		rc = gdsp_hann_extrema_apply (d_in, d_out, n, W, plan->h_taps, 0, N, wantMax, fill, stream, &gate, &gateLimit);
-		if ((rc != GDSP_OK) || (gate == NULL)) return rc;
-		}
+	// GDSP_PEAKS_FILTER=1 (EXACT only): the block sums of gdsp_hann.hip as an interval filter in front of the tap-by-tap
+	// evaluation, which then runs only for the bases that can survive and what ties with them -- bit-identical, tested,
+	// and not the default: once the clocks have settled it is no faster than evaluating every base
+	if ((mode == GDSP_FIR_EXACT) && (getenv ("GDSP_PEAKS_FILTER") != NULL) && (strcmp (getenv ("GDSP_PEAKS_FILTER"), "1") == 0))
+		return gdsp_hann_extrema_apply (d_in, d_out, n, W, plan->h_taps, 0, N, wantMax, fill, stream);
 	if (mode == GDSP_FIR_FMA)
 		{ if (wantMax) fir_extrema_launch<true, true>  (d_in, d_out, n, plan->h_taps, h, fill, s);
 		  else         fir_extrema_launch<true, false> (d_in, d_out, n, plan->h_taps, h, fill, s); }
 	else
-		{ if (wantMax) fir_extrema_launch<false, true>  (d_in, d_out, n, plan->h_taps, h, fill, s, gate, gateLimit);
-		  else         fir_extrema_launch<false, false> (d_in, d_out, n, plan->h_taps, h, fill, s, gate, gateLimit); }
+		{ if (wantMax) fir_extrema_launch<false, true>  (d_in, d_out, n, plan->h_taps, h, fill, s);
+		  else         fir_extrema_launch<false, false> (d_in, d_out, n, plan->h_taps, h, fill, s); }
 	GDSP_LAUNCH_CHECK ();
 	return GDSP_OK;
 	}

@@ -402,8 +402,7 @@ template <int W> struct HannTaps { double w[W]; };
 template <int W, bool FMA, bool MAX, int HH>
 __global__ __launch_bounds__(HN_THREADS)
 void hann_extrema_kernel (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t ntiles,
-                          HannConsts<W> K, HannTaps<W> taps, int h, double fill, uint32_t probeStep, unsigned int* probeCount,
-                          uint32_t probeLimit)
+                          HannConsts<W> K, HannTaps<W> taps, int h, double fill)
 	{
 	typedef HannGeom<W> G;
 	constexpr int    NWORD = (G::OUT + 31) / 32;
@@ -423,13 +422,10 @@ void hann_extrema_kernel (const double* __restrict__ in, double* __restrict__ ou
 	static_assert (NWORD <= 4 * 32, "a wave scans 32 words of flags");
 	static_assert (G::OUT % HN_G == 0, "whole blocks");
 
-	if ((probeStep == 0) && (probeCount != NULL) && (*probeCount > probeLimit)) return;   // the probe found too many ties: the direct kernel runs instead
 	const int      p         = threadIdx.x, lane = p & 63, wave = p >> 6;
 	const int      sh        = h & 1;                              // keeps the first staged index even
 	const int      stride    = G::OUT - 2*h - 2*sh;                // outputs kept per tile (even)
-	// (probeStep != 0: a sample of the tiles, every probeStep-th, run up to the point where the number of tap-by-tap
-	// evaluations is known, which is all that leaves the kernel)
-	const uint32_t tile      = probeStep? blockIdx.x * probeStep : gdsp_xcd_tile (blockIdx.x, ntiles);
+	const uint32_t tile      = gdsp_xcd_tile (blockIdx.x, ntiles);
 	const int64_t  keepStart = (int64_t) tile * stride;            // first output this tile stores
 	const int64_t  compStart = keepStart - h - sh;                 // first smoothed value it computes (even)
 	const int64_t  e0        = compStart - G::LEAD;
@@ -589,7 +585,7 @@ void hann_extrema_kernel (const double* __restrict__ in, double* __restrict__ ou
 		if (c + 1 < keepHi) *reinterpret_cast<double2*> (dst + (c - keepLo)) = make_double2 (r0, r1);
 		else                dst[c - keepLo] = r0;
 		};
-	if ((wave != 0) && (probeStep == 0))
+	if (wave != 0)
 		{
 		for (int c = keepLo + 2*(p - 64) ; c < keepHi ; c += 2*(HN_THREADS - 64))
 			{
@@ -598,7 +594,6 @@ void hann_extrema_kernel (const double* __restrict__ in, double* __restrict__ ou
 			}
 		return;
 		}
-	if (wave != 0) return;
 
 	// ---- the neighbours whose intervals overlap a candidate's: their exact values are needed too
 	if (!direct)
@@ -620,7 +615,6 @@ void hann_extrema_kernel (const double* __restrict__ in, double* __restrict__ ou
 
 	// ---- exact values where they are needed: tap by tap in the reference's order (sum.c:655-663)
 	const int nexact = queue (needBits, markBits);
-	if (probeStep != 0) { if (lane == 0) atomicAdd (probeCount, (unsigned int) nexact);  return; }
 	for (int t=lane ; t<nexact ; t+=64)
 		{
 		const int c = list[t];
@@ -669,27 +663,12 @@ void hann_extrema_kernel (const double* __restrict__ in, double* __restrict__ ou
 		}
 	}
 
-// One word per (device, stream) for the probe below: calls on one stream follow one another, calls on different streams
-// must not share it.
-struct HxProbe { int device;  void* stream;  unsigned int* d_word; };
-static std::vector<HxProbe> hxProbes;
-static std::mutex           hxProbeLock;
-
-// Which kernel pays depends on the signal, so a probe decides, on the device: up to 256 tiles spread over the vector run
-// the filter alone and add up how many tap-by-tap evaluations they would need; the filtered kernel, launched next, leaves
-// at once when that exceeds HX_PROBE_THRESHOLD per tile, and the caller then launches the kernel that evaluates every
-// base with the same word as its gate (it leaves at once in the other case).  No host round trip; 20 us of probe and one
-// grid of workgroups that only read a word.  Real-valued coverage needs ~20 evaluations per tile of 3972 outputs (1.7 ms
-// per 249 Mbp against 2.1 for every base); piecewise-constant integer depth smooths into long runs of exactly equal
-// values, every one a tie that has to be evaluated -- 700 per tile, 4.8 ms -- and is left to the direct kernel.  The
-// output does not depend on the choice.  GDSP_PEAKS_FILTER=1: the filter whatever the probe would say (tests, timing).
-#define HX_PROBE_TILES     256
-#define HX_PROBE_THRESHOLD 64                           // evaluations per tile, on average, up to which the filter is used
+// Opt-in (GDSP_PEAKS_FILTER=1, see gdsp_smooth_local_extrema).
 int gdsp_hann_extrema_apply (const double* d_in, double* d_out, uint32_t n, uint32_t W, const double* h_taps, int fma,
-                             uint32_t N, int wantMax, double fill, void* stream, const unsigned int** d_gate, uint32_t* gateLimit)
+                             uint32_t N, int wantMax, double fill, void* stream)
 	{
 	GDSP_REQUIRE (W == 101, "filtered smooth+extrema is built for W = 101");
-	GDSP_REQUIRE (!fma, "the filtered kernel is built for the reference's arithmetic (with fused multiply-adds the direct kernel is faster)");
+	GDSP_REQUIRE (!fma, "the filtered kernel is built for the reference's arithmetic");
 	typedef HannGeom<101> G;
 	const int h = (int) ((N - 1) / 2);
 	GDSP_REQUIRE ((h >= 0) && (h <= 64), "neighbourhood too wide for the fused kernel");
@@ -700,36 +679,9 @@ int gdsp_hann_extrema_apply (const double* d_in, double* d_out, uint32_t n, uint
 	const int      stride = G::OUT - 2*h - 2*(h & 1);
 	const uint32_t ntiles = (uint32_t) (((uint64_t) n + stride - 1) / stride);
 	hipStream_t    s      = gdsp_stream (stream);
-#define HX_LAUNCH_H(MM, HHH, GRID, STEP, WORD, LIMIT) hipLaunchKernelGGL ((hann_extrema_kernel<101, false, MM, HHH>), dim3(GRID), dim3(HN_THREADS), 0, s, d_in, d_out, n, ntiles, K, taps, h, fill, STEP, WORD, LIMIT)
-#define HX_LAUNCH(GRID, STEP, WORD, LIMIT) do { if (wantMax) { if (h == 5) HX_LAUNCH_H (true, 5, GRID, STEP, WORD, LIMIT);   else HX_LAUNCH_H (true, 0, GRID, STEP, WORD, LIMIT); } \
-                                                else         { if (h == 5) HX_LAUNCH_H (false, 5, GRID, STEP, WORD, LIMIT);  else HX_LAUNCH_H (false, 0, GRID, STEP, WORD, LIMIT); } } while (0)
-	*d_gate = NULL;  *gateLimit = 0;
-	const char* force = getenv ("GDSP_PEAKS_FILTER");
-	if ((force != NULL) && (strcmp (force, "1") == 0))
-		HX_LAUNCH (ntiles, 0u, (unsigned int*) NULL, 0u);
-	else
-		{
-		int device = 0;
-		GDSP_HIP_TRY (hipGetDevice (&device));
-		unsigned int* word = NULL;
-			{
-			std::lock_guard<std::mutex> hold (hxProbeLock);
-			for (HxProbe& x : hxProbes) { if ((x.device == device) && (x.stream == stream)) word = x.d_word; }
-			if (word == NULL)
-				{
-				GDSP_HIP_TRY (hipMalloc ((void**) &word, 64));
-				hxProbes.push_back (HxProbe { device, stream, word });
-				}
-			}
-		const uint32_t step   = (ntiles > HX_PROBE_TILES)? ntiles / HX_PROBE_TILES : 1;
-		const uint32_t probed = (ntiles + step - 1) / step;
-		const uint32_t limit  = HX_PROBE_THRESHOLD * probed;
-		GDSP_HIP_TRY (hipMemsetAsync (word, 0, sizeof(unsigned int), s));
-		HX_LAUNCH (probed, step, word, 0u);
-		HX_LAUNCH (ntiles, 0u, word, limit);
-		*d_gate = word;  *gateLimit = limit;
-		}
-#undef HX_LAUNCH
+#define HX_LAUNCH_H(MM, HHH) hipLaunchKernelGGL ((hann_extrema_kernel<101, false, MM, HHH>), dim3(ntiles), dim3(HN_THREADS), 0, s, d_in, d_out, n, ntiles, K, taps, h, fill)
+	if (wantMax) { if (h == 5) HX_LAUNCH_H (true, 5);   else HX_LAUNCH_H (true, 0); }
+	else         { if (h == 5) HX_LAUNCH_H (false, 5);  else HX_LAUNCH_H (false, 0); }
 #undef HX_LAUNCH_H
 	GDSP_LAUNCH_CHECK ();
 	return GDSP_OK;

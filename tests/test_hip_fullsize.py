@@ -99,16 +99,25 @@ def test_smooth_w101_full_chromosome(gd, real):
     # the index output of config 3: peaks of the smoothed track
     peaks = gd.localmax(out, 11)
     stencil_check(peaks, lambda x: cpu.local_extrema(cpu.smooth(x, 101), 11, 1, 0.0), 1, 55, rng)
-    # ... and the fused kernel, which evaluates tap by tap only what its interval filter cannot rule out
-    # (hann_extrema_kernel): every one of the 249 M bases carries the bits of the two kernels run one after the other
-    fused = gd.smooth_local_extrema(real, 101, 11, True, 0.0)
-    survivors = 0
-    for s in range(0, N, 1 << 24):
-        m = min(1 << 24, N - s)
-        a, b = fetch(fused, s, m), fetch(peaks, s, m)
-        assert bits_equal(a, b), (s, int(np.flatnonzero(a != b)[0]))
-        survivors += int(np.count_nonzero(a))
-    assert 0 < survivors < N // 20                                # (peaks are sparse: the filter has something to rule out)
+    # ... and the fused kernels -- the one that evaluates every base, and the one (opt-in) that evaluates tap by tap only
+    # what its interval filter cannot rule out (hann_extrema_kernel): every one of the 249 M bases carries the bits of
+    # the two kernels run one after the other
+    for env in ({}, {"GDSP_PEAKS_FILTER": "1"}):
+        os.environ.update(env)
+        try:
+            fused = gd.smooth_local_extrema(real, 101, 11, True, 0.0)
+            gd.sync()
+        finally:
+            for key in env:
+                del os.environ[key]
+        survivors = 0
+        for s in range(0, N, 1 << 24):
+            m = min(1 << 24, N - s)
+            a, b = fetch(fused, s, m), fetch(peaks, s, m)
+            assert bits_equal(a, b), (env, s, int(np.flatnonzero(a != b)[0]))
+            survivors += int(np.count_nonzero(a))
+        assert 0 < survivors < N // 20                            # (peaks are sparse: the filter has something to rule out)
+        del fused
 
 
 def test_fused_peaks_on_read_depth_full_chromosome(gd, depth):
@@ -117,7 +126,7 @@ def test_fused_peaks_on_read_depth_full_chromosome(gd, depth):
     out = gd.smooth(depth, 101, mode=gd.FIR_EXACT)
     for want_max, fill in ((True, 0.0), (False, cpu.DBL_MAX)):
         two = gd.local_extrema(out, 11, want_max, fill)
-        for env in ({"GDSP_PEAKS_FILTER": "1"}, {}):              # the filter forced onto this signal; the library's choice (its probe says no)
+        for env in ({"GDSP_PEAKS_FILTER": "1"}, {}):              # the filtered kernel (opt-in) on this signal full of ties; the default
             os.environ.update(env)
             try:
                 fused = gd.smooth_local_extrema(depth, 101, 11, want_max, fill)

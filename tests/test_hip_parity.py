@@ -644,15 +644,19 @@ def _filter_cases(n, rng):
     cases["nan and inf"] = x
     x = rng.standard_normal(n); x[np.abs(x) < 0.3] = 0.0
     cases["sparse noise"] = x
+    x = _signal("real", n, rng); x[n // 3] = 2.0 ** 64; x[n // 3 + 200] = 2.0 ** 63.9; x[2 * n // 3] = 2.0 ** -64.5; x[2 * n // 3 + 300] = 2.0 ** -63.5
+    cases["edges of the single-precision range"] = x
+    cases["one part in 1e6 apart"] = 1000.0 + 1e-3 * np.sin(t / 40.0)   # smoothed values closer than single precision resolves
     return cases
 
 
-@pytest.mark.parametrize("n", [3971, 3972, 3973, 3974, 7944, 7945, 20011])
+@pytest.mark.parametrize("n", [2291, 2292, 2293, 2294, 3971, 3972, 3973, 3974, 4584, 7944, 7945, 20011])
 @pytest.mark.parametrize("N", [2, 3, 11, 12, 41])
 def test_filtered_smooth_extrema_is_bit_identical(n, N, gd):
-    """`smooth W=101 = localmax|localmin N` evaluates tap by tap only the bases the block sums cannot rule out
-    (gdsp_hann.hip: hann_extrema_kernel, tiles of 3984 - 2h - 2(h&1) outputs): the output is still that of the two
-    reference loops run one after the other, on every kind of signal, and that of the kernel that evaluates every base."""
+    """`smooth W=101 = localmax|localmin N` with GDSP_PEAKS_FILTER=1 evaluates tap by tap only the bases the block sums
+    cannot rule out (gdsp_hann.hip: hann_extrema_kernel, tiles of 3984 - 2h - 2(h&1) outputs): the output is still that
+    of the two reference loops run one after the other, on every kind of signal, and that of the kernel that evaluates
+    every base (tiles of 2304 - 2h)."""
     rng = np.random.default_rng(n * 131 + N)
     for name, x in _filter_cases(n, rng).items():
         d = gd.DeviceVector.from_numpy(x)
@@ -660,9 +664,8 @@ def test_filtered_smooth_extrema_is_bit_identical(n, N, gd):
             sm = cpu.smooth(x, 101)
         for want_max, fill in ((True, 0.0), (False, cpu.DBL_MAX)):
             want = cpu.local_extrema(sm, N, 1 if want_max else 0, fill)
-            # the filter whatever the signal; the library's own choice (a probe sends tie-ridden signals to the kernel that
-            # evaluates every base); that kernel
-            for env in ({"GDSP_PEAKS_FILTER": "1"}, {}, {"GDSP_PEAKS_DIRECT": "1"}):
+            # the kernel that evaluates every base (the default), and the filtered one (opt-in)
+            for env in ({}, {"GDSP_PEAKS_FILTER": "1"}):
                 os.environ.update(env)
                 try:
                     got = gd.smooth_local_extrema(d, 101, N, want_max, fill).numpy()
