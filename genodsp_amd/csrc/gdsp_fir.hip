@@ -67,7 +67,7 @@ __device__ __forceinline__ void fir_store_tile (double* lds, const double (&acc)
 		for (int i=0 ; i<(T/2 + FIR_THREADS - 1)/FIR_THREADS ; i++)
 			{
 			int p = threadIdx.x + i*FIR_THREADS;
-			if (p < T/2) dst[p] = src[p];
+			if (p < T/2) gdsp_st2 (&dst[p], src[p]);
 			}
 		}
 	else
@@ -215,7 +215,7 @@ void fir_fixed_extrema_kernel (const double* __restrict__ in, double* __restrict
 		const double c0 = w[h], c1 = w[h+1];
 		const double r0 = (MAX? (e0 > c0) : (e0 < c0))? fill : c0;
 		const double r1 = (MAX? (e1 > c1) : (e1 < c1))? fill : c1;
-		if (g + 1 < (int64_t) n) *reinterpret_cast<double2*> (out + g) = make_double2 (r0, r1);
+		if (g + 1 < (int64_t) n) gdsp_st2 (reinterpret_cast<double2*> (out + g), make_double2 (r0, r1));
 		else                     out[g] = r0;
 		}
 	}

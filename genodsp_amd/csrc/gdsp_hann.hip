@@ -150,7 +150,7 @@ __device__ __forceinline__ bool hann_tile_sums (double* lds, double (*tot)[HN_TH
 		const double2* src = reinterpret_cast<const double2*> (in + e0);
 		double2 r[HN_G/2];
 #pragma unroll
-		for (int u=0 ; u<HN_G/2 ; u++) r[u] = src[u*HN_THREADS + p];
+		for (int u=0 ; u<HN_G/2 ; u++) r[u] = gdsp_ld2 (&src[u*HN_THREADS + p]);
 #pragma unroll
 		for (int u=0 ; u<HN_G/2 ; u++)
 			{
@@ -327,7 +327,7 @@ void hann_blocks_kernel (const double* __restrict__ in, double* __restrict__ out
 				{
 				const int o = 2*q;
 				const double* src = lds + o + (o >> 4);
-				dst[q] = make_double2 (src[0], src[1]);
+				gdsp_st2 (&dst[q], make_double2 (src[0], src[1]));
 				}
 			}
 		}
@@ -582,7 +582,7 @@ void hann_extrema_kernel (const double* __restrict__ in, double* __restrict__ ou
 		const double*  val = sm + c + (c >> 4);
 		const double   r0  = (two & 1u)? val[0] : fill;
 		const double   r1  = (two & 2u)? val[1] : fill;
-		if (c + 1 < keepHi) *reinterpret_cast<double2*> (dst + (c - keepLo)) = make_double2 (r0, r1);
+		if (c + 1 < keepHi) gdsp_st2 (reinterpret_cast<double2*> (dst + (c - keepLo)), make_double2 (r0, r1));
 		else                dst[c - keepLo] = r0;
 		};
 	if (wave != 0)
@@ -737,7 +737,7 @@ void hann_blocks_rt_kernel (const double* __restrict__ in, double* __restrict__ 
 		const double2* src = reinterpret_cast<const double2*> (in + e0);
 		double2 r[HN_G/2];
 #pragma unroll
-		for (int u=0 ; u<HN_G/2 ; u++) r[u] = src[u*THREADS + p];
+		for (int u=0 ; u<HN_G/2 ; u++) r[u] = gdsp_ld2 (&src[u*THREADS + p]);
 #pragma unroll
 		for (int u=0 ; u<HN_G/2 ; u++)
 			{
@@ -896,7 +896,7 @@ void hann_blocks_rt_kernel (const double* __restrict__ in, double* __restrict__ 
 			{
 			const int o = 2*q;
 			const double* src = lds + o + (o >> 4);
-			dst[q] = make_double2 (src[0], src[1]);
+			gdsp_st2 (&dst[q], make_double2 (src[0], src[1]));
 			}
 		}
 	else

@@ -82,7 +82,7 @@ void hf_totals_kernel (const double* __restrict__ in, uint32_t n, HfLevels Lv, H
 		const double2* src = reinterpret_cast<const double2*> (in + e0);
 		double2 r[8];
 #pragma unroll
-		for (int u=0 ; u<8 ; u++) r[u] = src[u*256 + p];
+		for (int u=0 ; u<8 ; u++) r[u] = gdsp_ld2 (&src[u*256 + p]);
 #pragma unroll
 		for (int u=0 ; u<8 ; u++)
 			{ const int e = 2 * (u*256 + p);  double* d = lds + e + (e >> 4);  d[0] = r[u].x;  d[1] = r[u].y; }
@@ -440,7 +440,7 @@ void hf_output_kernel (const double* __restrict__ in, double* __restrict__ out, 
 			{
 			const int o = 2*q;
 			const double* src = Rg + o + (o >> 4);
-			dst[q] = make_double2 (src[0], src[1]);
+			gdsp_st2 (&dst[q], make_double2 (src[0], src[1]));
 			}
 		}
 	else

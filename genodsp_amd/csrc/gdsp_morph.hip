@@ -94,7 +94,7 @@ __device__ __forceinline__ void mo_stage (uint64_t* mask, const double* __restri
 			for (int u=0 ; u<MO_STAGE_UNROLL ; u++)
 				{
 				const int c = (c0+u < nchunks)? c0+u : nchunks-1;      // clamped: duplicates are harmless
-				d[u]  = *reinterpret_cast<const double2*> (in + g0 + 128*(int64_t) c + 2*lane);
+				d[u]  = gdsp_ld2 (reinterpret_cast<const double2*> (in + g0 + 128*(int64_t) c + 2*lane));
 				hx[u] = hy[u] = true;
 				}
 			}
@@ -240,7 +240,7 @@ void morph_kernel (const double* __restrict__ in, double* __restrict__ out, uint
 			const uint64_t word = answer[q >> 5];
 			const int      b    = (2*q) & 63;
 			const double   r0   = ((word >> b) & 1)? one : zero, r1 = ((word >> (b+1)) & 1)? one : zero;
-			if (g + 1 < (int64_t) n) *reinterpret_cast<double2*> (out + g) = make_double2 (r0, r1);
+			if (g + 1 < (int64_t) n) gdsp_st2 (reinterpret_cast<double2*> (out + g), make_double2 (r0, r1));
 			else                     out[g] = r0;
 			}
 		return;
@@ -260,7 +260,7 @@ void morph_kernel (const double* __restrict__ in, double* __restrict__ out, uint
 			                                    : (mo_next (tb, p - right) >  p + left);   // erode: first position outside S at or after p-right
 			r[u] = isOne? one : zero;
 			}
-		if (g + 1 < (int64_t) n) *reinterpret_cast<double2*> (out + g) = make_double2 (r[0], r[1]);
+		if (g + 1 < (int64_t) n) gdsp_st2 (reinterpret_cast<double2*> (out + g), make_double2 (r[0], r[1]));
 		else                     out[g] = r[0];
 		}
 	}
@@ -320,7 +320,7 @@ void morph_dilate_erode_kernel (const double* __restrict__ in, double* __restric
 		const int  p  = haloL + o;
 		const bool k0 = (mo_next (tb, p     - eRight) > p     + eLeft);
 		const bool k1 = (mo_next (tb, p + 1 - eRight) > p + 1 + eLeft);
-		if (g + 1 < (int64_t) n) *reinterpret_cast<double2*> (out + g) = make_double2 (k0? vOne : vZero, k1? vOne : vZero);
+		if (g + 1 < (int64_t) n) gdsp_st2 (reinterpret_cast<double2*> (out + g), make_double2 (k0? vOne : vZero, k1? vOne : vZero));
 		else                     out[g] = k0? vOne : vZero;
 		}
 	}
@@ -351,7 +351,7 @@ void mg_bits_kernel (const double* __restrict__ in, uint32_t n, double T, bool c
 		const int64_t g = 128 * (int64_t) c + 2*lane;
 		double x = 0.0, y = 0.0;
 		const bool hx = (g < (int64_t) n), hy = (g + 1 < (int64_t) n);
-		if (hy) { const double2 d = *reinterpret_cast<const double2*> (in + g);  x = d.x;  y = d.y; }
+		if (hy) { const double2 d = gdsp_ld2 (reinterpret_cast<const double2*> (in + g));  x = d.x;  y = d.y; }
 		else if (hx) x = in[g];
 		const uint64_t E = __ballot (hx && mo_member<OP> (x, T, g));
 		const uint64_t O = __ballot (hy && mo_member<OP> (y, T, g+1));
@@ -558,7 +558,7 @@ void mg_answer_kernel (MgTables tb, uint32_t n, long long left, long long right,
 		const unsigned long long word = answer[q >> 5];
 		const int    b  = (2*q) & 63;
 		const double r0 = ((word >> b) & 1)? one : zero, r1 = ((word >> (b+1)) & 1)? one : zero;
-		if (g + 1 < n) *reinterpret_cast<double2*> (out + g) = make_double2 (r0, r1);
+		if (g + 1 < n) gdsp_st2 (reinterpret_cast<double2*> (out + g), make_double2 (r0, r1));
 		else           out[g] = r0;
 		}
 	}

@@ -146,7 +146,7 @@ void pc_partition_kernel (const double* __restrict__ v, uint32_t n, uint32_t win
 			{
 			const double2* p = reinterpret_cast<const double2*> (v + base) + threadIdx.x;
 #pragma unroll
-			for (int u=0 ; u<8 ; u++) d[u] = p[u*PC_THREADS];
+			for (int u=0 ; u<8 ; u++) d[u] = gdsp_ld2 (&p[u*PC_THREADS]);
 			}
 		else
 			{

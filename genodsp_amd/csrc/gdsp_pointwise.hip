@@ -29,11 +29,11 @@ void pointwise_kernel (double* __restrict__ v, uint32_t n, uint32_t ntiles, F f)
 		double2* p = reinterpret_cast<double2*> (v + base) + threadIdx.x;
 		double2  d[PW_UNROLL];
 #pragma unroll
-		for (int u=0 ; u<PW_UNROLL ; u++) d[u] = p[u*PW_THREADS];
+		for (int u=0 ; u<PW_UNROLL ; u++) d[u] = gdsp_ld2 (&p[u*PW_THREADS]);
 #pragma unroll
 		for (int u=0 ; u<PW_UNROLL ; u++) { d[u].x = f (d[u].x);  d[u].y = f (d[u].y); }
 #pragma unroll
-		for (int u=0 ; u<PW_UNROLL ; u++) p[u*PW_THREADS] = d[u];
+		for (int u=0 ; u<PW_UNROLL ; u++) gdsp_st2 (&p[u*PW_THREADS], d[u]);
 		}
 	else
 		{
@@ -170,7 +170,7 @@ void minmax_dense_kernel (const double* __restrict__ v, uint32_t n, double lo, d
 			const double2* p = reinterpret_cast<const double2*> (v + base) + threadIdx.x;
 			double2 d[PW_UNROLL];
 #pragma unroll
-			for (int u=0 ; u<PW_UNROLL ; u++) d[u] = p[u*PW_THREADS];
+			for (int u=0 ; u<PW_UNROLL ; u++) d[u] = gdsp_ld2 (&p[u*PW_THREADS]);
 #pragma unroll
 			for (int u=0 ; u<PW_UNROLL ; u++) { take (d[u].x);  take (d[u].y); }
 			}
@@ -251,11 +251,11 @@ void map_kernel (double* __restrict__ v, uint32_t n, uint32_t ntiles,
 		double2* p = reinterpret_cast<double2*> (v + base) + threadIdx.x;
 		double2  d[PW_UNROLL];
 #pragma unroll
-		for (int u=0 ; u<PW_UNROLL ; u++) d[u] = p[u*PW_THREADS];
+		for (int u=0 ; u<PW_UNROLL ; u++) d[u] = gdsp_ld2 (&p[u*PW_THREADS]);
 #pragma unroll
 		for (int u=0 ; u<PW_UNROLL ; u++) { d[u].x = mapOne (d[u].x);  d[u].y = mapOne (d[u].y); }
 #pragma unroll
-		for (int u=0 ; u<PW_UNROLL ; u++) p[u*PW_THREADS] = d[u];
+		for (int u=0 ; u<PW_UNROLL ; u++) gdsp_st2 (&p[u*PW_THREADS], d[u]);
 		}
 	else
 		{

@@ -83,7 +83,7 @@ void sliding_sum_kernel (const double* __restrict__ in, double* __restrict__ out
 		if (g >= (int64_t) n) break;
 		double s0 = (P[o + W]     - P[o])     / denom;
 		double s1 = (P[o + 1 + W] - P[o + 1]) / denom;
-		if (g + 1 < (int64_t) n) *reinterpret_cast<double2*> (out + g) = make_double2 (s0, s1);
+		if (g + 1 < (int64_t) n) gdsp_st2 (reinterpret_cast<double2*> (out + g), make_double2 (s0, s1));
 		else                     out[g] = s0;
 		}
 	}
@@ -124,7 +124,7 @@ void sliding_blocks_kernel (const double* __restrict__ in, double* __restrict__ 
 		const double2* src = reinterpret_cast<const double2*> (in + e0);
 		double2 r[SLB_G/2];
 #pragma unroll
-		for (int u=0 ; u<SLB_G/2 ; u++) r[u] = src[u*SLB_THREADS + p];
+		for (int u=0 ; u<SLB_G/2 ; u++) r[u] = gdsp_ld2 (&src[u*SLB_THREADS + p]);
 #pragma unroll
 		for (int u=0 ; u<SLB_G/2 ; u++)
 			{
@@ -195,7 +195,7 @@ void sliding_blocks_kernel (const double* __restrict__ in, double* __restrict__ 
 		for (int q=p ; q<outs/2 ; q+=SLB_THREADS)
 			{
 			const int o = 2*q + sh, o1 = o + 1;
-			dst[q] = make_double2 (lds[o + (o >> 4)], lds[o1 + (o1 >> 4)]);
+			gdsp_st2 (&dst[q], make_double2 (lds[o + (o >> 4)], lds[o1 + (o1 >> 4)]));
 			}
 		}
 	else
@@ -243,7 +243,7 @@ void window_sum_tile_kernel (double* __restrict__ v, uint32_t n, uint32_t W, uin
 			double2 x[8];
 #pragma unroll
 			for (int u=0 ; u<8 ; u++)
-				{ const uint32_t q = q0 + u*SU_THREADS;  x[u] = src[(q < np)? q : np-1]; }
+				{ const uint32_t q = q0 + u*SU_THREADS;  x[u] = gdsp_ld2 (&src[(q < np)? q : np-1]); }
 #pragma unroll
 			for (int u=0 ; u<8 ; u++)
 				{
@@ -363,7 +363,7 @@ void window_sum_tile_kernel (double* __restrict__ v, uint32_t n, uint32_t W, uin
 			{
 			const double a = (c2 == 0)? res[r2] : zeroVal;
 			const double b = (c2 + 1 == W)? res[r2 + 1] : zeroVal;   // (the next window starts on the odd base)
-			dst[q] = make_double2 (a, b);
+			gdsp_st2 (&dst[q], make_double2 (a, b));
 			r2 += dR2;  c2 += dC2;
 			if (c2 >= W) { c2 -= W;  r2++; }
 			}
@@ -418,7 +418,7 @@ void window_sum_exact_kernel (double* __restrict__ v, uint32_t n, uint32_t W, ui
 		for (int u=0 ; u<WX_BATCH ; u++)
 			{
 			const uint64_t q = p + 64*u;
-			x[u] = words[(q < p1)? q : p1 - 1];                     // (p1 > p0 here; clamped, the extra copies are not added)
+			x[u] = gdsp_ld2 (&words[(q < p1)? q : p1 - 1]);                     // (p1 > p0 here; clamped, the extra copies are not added)
 			}
 #pragma unroll
 		for (int u=0 ; u<WX_BATCH ; u++)
@@ -434,7 +434,7 @@ void window_sum_exact_kernel (double* __restrict__ v, uint32_t n, uint32_t W, ui
 	if ((lane == 0) && (s & 1)) v[s]   = val;
 	if ((lane == 1) && (e & 1)) v[e-1] = (e - 1 == s)? val : zeroVal;
 	for (uint64_t q=p0+lane ; q<p1 ; q+=64)
-		words[q] = make_double2 ((2*q == s)? val : zeroVal, zeroVal);
+		gdsp_st2 (&words[q], make_double2 ((2*q == s)? val : zeroVal, zeroVal));
 	if (lane == 0) done[w] = 1;
 	}
 
@@ -603,7 +603,7 @@ void cumsum_totals_kernel (const double* __restrict__ v, uint32_t n, uint32_t nc
 		const double2* p = reinterpret_cast<const double2*> (v + s) + threadIdx.x;
 		double2 d[CS_PER/2];
 #pragma unroll
-		for (int u=0 ; u<CS_PER/2 ; u++) d[u] = p[u*SU_THREADS];
+		for (int u=0 ; u<CS_PER/2 ; u++) d[u] = gdsp_ld2 (&p[u*SU_THREADS]);
 #pragma unroll
 		for (int u=0 ; u<CS_PER/2 ; u++) acc += d[u].x + d[u].y;
 		}
@@ -681,7 +681,7 @@ void cumsum_apply_kernel (double* __restrict__ v, uint32_t n, uint32_t nchunks, 
 			{
 			double2 d = src[threadIdx.x + u*SU_THREADS];
 			d.x = off + d.x;  d.y = off + d.y;
-			dst[threadIdx.x + u*SU_THREADS] = d;
+			gdsp_st2 (&dst[threadIdx.x + u*SU_THREADS], d);
 			}
 		}
 	else
