@@ -54,7 +54,7 @@ __device__ __forceinline__ void cl_stage_vals (double* turn, const double* __res
 		const double2* src = reinterpret_cast<const double2*> (v + k0);
 		double2 r[CL_PER/2];
 #pragma unroll
-		for (int u=0 ; u<CL_PER/2 ; u++) r[u] = src[u*CL_THREADS + threadIdx.x];
+		for (int u=0 ; u<CL_PER/2 ; u++) r[u] = gdsp_ld2 (&src[u*CL_THREADS + threadIdx.x]);
 #pragma unroll
 		for (int u=0 ; u<CL_PER/2 ; u++)
 			{
@@ -277,7 +277,7 @@ void clump_suffix_max_kernel (const double* __restrict__ v, size_t n, double avg
 			{
 			const int e = 2 * (u*CL_THREADS + (int) threadIdx.x);
 			const double* src = turn + e + (e >> 4);
-			dst[u*CL_THREADS + threadIdx.x] = make_double2 (src[0], src[1]);
+			gdsp_st2 (&dst[u*CL_THREADS + threadIdx.x], make_double2 (src[0], src[1]));
 			}
 		}
 	else
@@ -321,7 +321,7 @@ void clump_flags_kernel (const double* __restrict__ v, size_t n, double avg, int
 		const double2* src = reinterpret_cast<const double2*> (R + rBase);
 #pragma unroll
 		for (int u=0 ; u<CL_AHEAD ; u++)
-			{ const int q = u*CL_THREADS + (int) threadIdx.x;  ahead[u] = src[(q < CL_CHUNK/2 + 2)? q : CL_CHUNK/2 + 1]; }
+			{ const int q = u*CL_THREADS + (int) threadIdx.x;  ahead[u] = gdsp_ld2 (&src[(q < CL_CHUNK/2 + 2)? q : CL_CHUNK/2 + 1]); }
 		}
 	cl_stage_vals (turn, v, n, k0, avg, above);
 
@@ -572,7 +572,7 @@ void clump_write_kernel (const unsigned long long* __restrict__ mBits, const uns
 			{
 			const unsigned long long word = outWord[q >> 5];
 			const int b = (2*q) & 63;
-			dst[q] = make_double2 (((word >> b) & 1)? one : zero, ((word >> (b+1)) & 1)? one : zero);
+			gdsp_st2 (&dst[q], make_double2 (((word >> b) & 1)? one : zero, ((word >> (b+1)) & 1)? one : zero));
 			}
 		}
 	else
