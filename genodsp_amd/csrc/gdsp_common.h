@@ -55,7 +55,9 @@ static inline hipStream_t gdsp_stream (void* s) { return (hipStream_t) s; }
 __host__ __device__ static inline bool gdsp_aligned16 (const void* p) { return (((uintptr_t) p) & 15) == 0; }
 
 // 16-byte accesses of data this kernel touches once: non-temporal, so the streams do not sweep the L2 for each other
-// (measured on hann_blocks_kernel<101>: 383 -> 400 Gbases/s with both; loads alone +2.5 %, stores alone +0 %).
+// (measured on hann_blocks_kernel<101>: 383 -> 400 Gbases/s with both; loads alone +2.5 %, stores alone +0 %).  Only for
+// accesses where the lanes of a wave cover whole lines between them: a lane that walks a strip of its own (the select
+// histogram, the report's count pass) needs the rest of each line to wait in the cache -- non-temporal loads there cost 1.7-3x.
 // GDSP_STREAMING=0 builds the plain accesses (A/B).
 #ifndef GDSP_STREAMING
 #define GDSP_STREAMING 1

@@ -36,11 +36,11 @@ __device__ __forceinline__ RpFlags rp_flags (const double* __restrict__ v, uint3
 		{
 		// aligned interior: nine 16-byte loads starting at first-2
 		const double2* p = reinterpret_cast<const double2*> (v + first - 2);
-		double2 d = gdsp_ld2 (&p[0]);
+		double2 d = p[0];                                       // (plain loads: a lane walks its own strip, the rest of each line has to wait in the cache)
 		x[0] = d.y;
 #pragma unroll
-		for (int k=0 ; k<RP_PER/2 ; k++) { d = gdsp_ld2 (&p[k+1]);  x[1+2*k] = d.x;  x[2+2*k] = d.y; }
-		d = gdsp_ld2 (&p[RP_PER/2 + 1]);
+		for (int k=0 ; k<RP_PER/2 ; k++) { d = p[k+1];  x[1+2*k] = d.x;  x[2+2*k] = d.y; }
+		d = p[RP_PER/2 + 1];
 		x[RP_PER+1] = d.x;
 		}
 	else

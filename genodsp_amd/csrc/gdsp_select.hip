@@ -127,7 +127,7 @@ void select_hist_dense_kernel (const double* __restrict__ v, uint32_t n, double 
 			{
 			const double2* p = reinterpret_cast<const double2*> (v + g);
 #pragma unroll
-			for (int i=0 ; i<SE_PER/2 ; i++) { double2 d = gdsp_ld2 (&p[i]);  x[2*i] = d.x;  x[2*i+1] = d.y; }
+			for (int i=0 ; i<SE_PER/2 ; i++) { double2 d = p[i];  x[2*i] = d.x;  x[2*i+1] = d.y; }   // (plain loads: a lane walks its own strip, the rest of each line has to wait in the cache)
 			}
 		else
 			{
