@@ -34,6 +34,8 @@ OPS = {
     "close": (None, lambda: gd.close(depth, 1001, out=b, stream=s)),
     "open": (None, lambda: gd.open_(depth, 1001, out=b, stream=s)),
     "close100": (None, lambda: gd.close(depth, 100, out=b, stream=s)),
+    "localmax3": (None, lambda: gd.localmax(real, 3, out=b, stream=s)),
+    "bestmax33": (None, lambda: gd.best_extrema(real, 33, True, out=b, stream=s)),
     "localmax11": (None, lambda: gd.localmax(real, 11, out=b, stream=s)),
     "bestmax1001": (None, lambda: gd.best_extrema(real, 1001, True, out=b, stream=s)),
     "binarize": (cp, lambda: gd.binarize(a, 30.0, stream=s)),
