@@ -24,6 +24,9 @@ OPS = {
     "sum1000": (cp, lambda: gd.window_sum(a, 1000, stream=s)),
     "sum2000": (cp, lambda: gd.window_sum(a, 2000, stream=s)),
     "sum500": (cp, lambda: gd.window_sum(a, 500, stream=s)),
+    "sum600": (cp, lambda: gd.window_sum(a, 600, stream=s)),
+    "sum600real": (lambda: gd.call("gdsp_memcpy_d2d", a.ptr, real.ptr, n * 8, gd._sp(s)), lambda: gd.window_sum(a, 600, stream=s)),
+    "sum400real": (lambda: gd.call("gdsp_memcpy_d2d", a.ptr, real.ptr, n * 8, gd._sp(s)), lambda: gd.window_sum(a, 400, stream=s)),
     "sum300": (cp, lambda: gd.window_sum(a, 300, stream=s)),
     "sum1000real": (lambda: gd.call("gdsp_memcpy_d2d", a.ptr, real.ptr, n * 8, gd._sp(s)), lambda: gd.window_sum(a, 1000, stream=s)),
     "sum2000real": (lambda: gd.call("gdsp_memcpy_d2d", a.ptr, real.ptr, n * 8, gd._sp(s)), lambda: gd.window_sum(a, 2000, stream=s)),
