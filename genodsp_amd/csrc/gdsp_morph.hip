@@ -690,6 +690,7 @@ int gdsp_dilate_erode (const double* d_in, double* d_out, uint32_t n,
 		}
 	uint64_t tile = 4 * (haloL + haloR);
 	if (tile < MO_MIN_TILE) tile = MO_MIN_TILE;
+	if (getenv ("GDSP_MORPH_TILE") != NULL) tile = (uint64_t) atoll (getenv ("GDSP_MORPH_TILE"));   // (tuning experiments)
 	if (tile + haloL + haloR > MO_MAX_STAGE/2) tile = MO_MAX_STAGE/2 - haloL - haloR;
 	tile = (tile / 512) * 512;
 	const int      nwords = (int) ((haloL + tile + haloR) / 64);
