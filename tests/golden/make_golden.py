@@ -291,13 +291,15 @@ cli_case("cli_anticlump_show", APPENDIX_C_CH, ["--novalue", "--uncovered:show", 
 import hashlib  # noqa: E402
 
 
-def random_cli_case(k):
+def random_cli_case(k, scale=1):
+    """scale > 1 (tools/cli_campaign.py): chromosomes and interval counts that many times larger, so that the kernels'
+    tiles, the ingest batches and the report's chunks all meet their seams; the committed cases are scale 1"""
     r = np.random.default_rng(SEED + 7000 + k)
-    lens = [int(r.integers(6000, 9000)), int(r.integers(4000, 6000))]
+    lens = [int(r.integers(6000 * scale, 9000 * scale)), int(r.integers(4000 * scale, 6000 * scale))]
     chroms_text = "".join("chr%s %d\n" % ("RQ"[i], n) for i, n in enumerate(lens))
     lines = []
     for i, n in enumerate(lens):
-        for _ in range(int(r.integers(30, 90))):
+        for _ in range(int(r.integers(30 * scale, 90 * scale))):
             a = int(r.integers(1500, n - 1800))
             b = a + int(r.integers(1, 260))
             lines.append("chr%s\t%d\t%d\t%d" % ("RQ"[i], a, b, int(r.integers(1, 7))))
