@@ -75,6 +75,10 @@ def main():
                     help="chromosomes = whole chromosomes dealt longest-first over the ranks (BASELINE's sharding, the "
                          "default); bases = every rank takes an equal stretch of the concatenated genome, chromosomes "
                          "cut where needed and each piece carrying the half window of neighbours it needs (smooth only)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams the independent chromosomes of a rank alternate over (default 1: launches follow one "
+                         "another, which is what the committed rocprofv3 per-kernel durations describe; 3 hides the drain "
+                         "between kernels, +3..5 %% on the HBM-bound workloads)")
     ap.add_argument("--workload", choices=["smooth", "peaks", "morph", "percentile"], default="smooth",
                     help="smooth = BASELINE configs[1] (the metric); the others are configs[2..4], "
                          "reported in the same shape for DESIGN.md, never the driver's number")
@@ -131,9 +135,14 @@ def main():
         gd.synth_coverage(SEED, pieces[k][0], held[k][0], held[k][1] - held[k][0], mode=1, out=vin[k], stream=stream.handle)
     stream.sync()
 
+    # chromosomes are independent: with --streams N they alternate over N streams (all joined to the first one around
+    # the timed region)
+    lanes = [stream] + [gd.Stream() for _ in range(max(1, args.streams) - 1)]
+    lane_of = {k: lanes[j % len(lanes)] for j, k in enumerate(mine)}
+
     def step(mode):
         for i in mine:
-            gd.smooth(vin[i], WINDOW, out=vout[i], mode=mode, stream=stream.handle)
+            gd.smooth(vin[i], WINDOW, out=vout[i], mode=mode, stream=lane_of[i].handle)
 
     def timed(mode, steps, warmup, step=step):
         for _ in range(warmup):
@@ -144,8 +153,14 @@ def main():
         e0, e1 = gd.Event(), gd.Event()
         t0 = time.perf_counter()
         e0.record(stream.handle)
+        for lane in lanes[1:]:
+            lane.wait_event(e0)
         for _ in range(steps):
             step(mode)
+        for lane in lanes[1:]:                   # the first stream ends after all of them
+            done = gd.Event()
+            done.record(lane.handle)
+            stream.wait_event(done)
         e1.record(stream.handle)
         torch.cuda.synchronize()
         barrier()
@@ -160,7 +175,7 @@ def main():
 
     if args.workload != "smooth":
         other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_bases, vin, vout, stream,
-                       timed_fn=timed, reduce_device=reduce_device)
+                       timed_fn=timed, reduce_device=reduce_device, lane_of=lane_of)
         barrier()
         if dist is not None:
             dist.destroy_process_group()
@@ -212,7 +227,7 @@ def main():
                                + ARITHMETIC[args.mode] + "; the other two arithmetics are in other_modes",
                    "window": WINDOW, "chromosomes": len(GENOME), "bases": total_bases,
                    "fir_mode": args.mode, "library": gd.lib().gdsp_version().decode(),
-                   "sharding": "whole chromosomes, LPT over ranks" if args.sharding == "chromosomes"
+                   "streams": args.streams, "sharding": "whole chromosomes, LPT over ranks" if args.sharding == "chromosomes"
                                else "equal stretches of the concatenated genome, pieces with a half-window halo",
                    "signal": "read-depth-like x U(0.5,1.5), seed %d" % SEED},
         "roofline": roofline(args.mode, dev_ms),
@@ -269,7 +284,7 @@ def piece_extent(piece, lengths):
     return max(0, a - half), min(lengths[c], b + half)
 
 
-def other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_bases, vin, vout, stream, timed_fn,
+def other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_bases, vin, vout, stream, timed_fn, lane_of,
                    reduce_device="cuda"):
     """BASELINE configs[2..4] in the bench harness: same signal, same timing discipline."""
     S = stream.handle
@@ -283,10 +298,10 @@ def other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_base
         def step(_):
             for i in mine:
                 if args.nofuse:
-                    gd.smooth(vin[i], WINDOW, out=vout[i], mode=mode, stream=S)
-                    gd.localmax(vout[i], 11, out=tmp[i], stream=S)
+                    gd.smooth(vin[i], WINDOW, out=vout[i], mode=mode, stream=lane_of[i].handle)
+                    gd.localmax(vout[i], 11, out=tmp[i], stream=lane_of[i].handle)
                 else:
-                    gd.smooth_local_extrema(vin[i], WINDOW, 11, True, 0.0, out=tmp[i], mode=mode, stream=S)
+                    gd.smooth_local_extrema(vin[i], WINDOW, 11, True, 0.0, out=tmp[i], mode=mode, stream=lane_of[i].handle)
     elif args.workload == "morph":        # configs[3]: dilate 1001 = erode 1001 = binarize
         name, bytes_per_base = "dilate 1001 = erode 1001 = binarize", 48
         left, right = gd.split_length(1001)
@@ -294,11 +309,11 @@ def other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_base
         def step(_):
             for i in mine:
                 if args.nofuse:
-                    gd.dilate(vin[i], left, right, out=vout[i], stream=S)
-                    gd.erode(vout[i], left, right, out=tmp[i], stream=S)
-                    gd.binarize(tmp[i], 0.0, stream=S)
+                    gd.dilate(vin[i], left, right, out=vout[i], stream=lane_of[i].handle)
+                    gd.erode(vout[i], left, right, out=tmp[i], stream=lane_of[i].handle)
+                    gd.binarize(tmp[i], 0.0, stream=lane_of[i].handle)
                 else:
-                    gd.dilate_erode(vin[i], left, right, left, right, binarize=(0.0, False, 1.0, 0.0), out=tmp[i], stream=S)
+                    gd.dilate_erode(vin[i], left, right, left, right, binarize=(0.0, False, 1.0, 0.0), out=tmp[i], stream=lane_of[i].handle)
     else:                                 # configs[4]: percentile 99 = binarize --threshold=percentile99
         name, bytes_per_base = "percentile 99 = binarize --threshold=percentile99", 24
         for i in mine:
@@ -336,7 +351,7 @@ def other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_base
             extra["percentile_route"] = {gd.SELECT_RADIX: "radix", gd.SELECT_BRACKET: "bracket"}.get(st["route"])
             extra["percentile_stats"] = st
             for i in mine:
-                gd.binarize(tmp[i], vals[0], stream=S)
+                gd.binarize(tmp[i], vals[0], stream=lane_of[i].handle)
     wall_ms, dev_ms = timed_fn(None, args.steps, args.warmup, step=step)
     bases_rank = max(sum(lengths[i] for i in sh) for sh in gd.lpt_shards(lengths, world))
     moved_per_base = 16 if (args.workload in ("peaks", "morph") and not args.nofuse) else bytes_per_base
@@ -356,7 +371,7 @@ def other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_base
                          "library": gd.lib().gdsp_version().decode(),
                          "collectives": (None if dist is None else "gloo, host copy (one-GPU rehearsal)" if reduce_device == "cpu"
                                          else "rccl (torch.distributed nccl backend), device words"),
-                         "sharding": "whole chromosomes, LPT over ranks"},
+                         "streams": args.streams, "sharding": "whole chromosomes, LPT over ranks"},
               "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(achieved / HBM_PEAK_GBS, 4),
                            "traffic": measured_traffic(kernels[0], moved_per_base * bases_rank / max(1, len(mine))),

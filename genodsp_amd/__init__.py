@@ -51,6 +51,10 @@ class Stream:
     def sync(self):
         call("gdsp_stream_sync", C.c_void_p(self.handle))
 
+    def wait_event(self, event):
+        """what is queued on this stream from now on starts after `event`"""
+        call("gdsp_stream_wait_event", C.c_void_p(self.handle), C.c_void_p(event.handle))
+
     def close(self):
         if self.handle:
             call("gdsp_stream_destroy", C.c_void_p(self.handle))

@@ -51,6 +51,7 @@ SIGNATURES = {
     "gdsp_event_create": (_int, [C.POINTER(_vp)]),
     "gdsp_event_destroy": (_int, [_vp]),
     "gdsp_event_record": (_int, [_vp, _vp]),
+    "gdsp_stream_wait_event": (_int, [_vp, _vp]),
     "gdsp_event_elapsed_ms": (_int, [_vp, _vp, _pf]),
     "gdsp_fill": (_int, [_vp, _u32, _f64, _vp]),
     "gdsp_hann_taps": (_int, [_u32, _vp]),

@@ -154,6 +154,12 @@ int gdsp_event_record (void* event, void* stream)
 	return GDSP_OK;
 	}
 
+int gdsp_stream_wait_event (void* stream, void* event)
+	{
+	GDSP_HIP_TRY (hipStreamWaitEvent (gdsp_stream (stream), (hipEvent_t) event, 0));
+	return GDSP_OK;
+	}
+
 int gdsp_event_elapsed_ms (void* start, void* stop, float* ms)
 	{
 	GDSP_REQUIRE (ms != NULL, "ms is NULL");
