@@ -33,6 +33,9 @@ void gdsp_set_error (const char* fmt, ...);
 // gdsp_hann.hip: `smooth` through block sums of the Hann window's constant and cosine parts
 bool gdsp_hann_blocks_available (uint32_t W);
 int  gdsp_hann_blocks_apply (const double* d_in, double* d_out, uint32_t n, uint32_t W, void* stream);
+bool gdsp_hann_blocks_batch_available (uint32_t W);                   // (the W=101 kernel has a one-launch-per-device form)
+int  gdsp_hann_blocks_apply_batch (const gdsp_batch_item* items, int nitems, uint32_t W, void* stream);
+int  gdsp_batch_check (const gdsp_batch_item* items, int nitems, bool inPlace);   // gdsp_fir.hip: argument checks shared by the *_batch calls
 // ... and `smooth W=101 = localmax|localmin N` with the block sums as a filter in front of the exact evaluation (bit-identical to
 // it; opt-in, see gdsp_smooth_local_extrema)
 int  gdsp_hann_extrema_apply (const double* d_in, double* d_out, uint32_t n, uint32_t W, const double* h_taps, int fma,
@@ -93,6 +96,60 @@ __device__ __forceinline__ uint32_t gdsp_xcd_tile (uint32_t b, uint32_t nblocks)
 	uint32_t even = per * GDSP_NUM_XCD;
 	if (b >= even) return b;                       // ragged tail keeps its id
 	return (b % GDSP_NUM_XCD) * per + (b / GDSP_NUM_XCD);
+	}
+
+// ---- one launch for many vectors (genodsp.c:909-921 applies an operator chromosome by chromosome; a device that owns
+// several chromosomes, or several stretches, gets ONE grid over all of them: no ramp and drain between 24 launches).
+// The table travels in the kernarg segment (no device allocation, no copy to wait for): vector s owns the tiles
+// [tile0[s], tile0[s+1]) of the grid.  A block finds its vector by a short scalar search; XCD-contiguous tile order
+// is applied to the whole grid, so each XCD still walks one contiguous stretch of (concatenated) tiles.
+#define GDSP_BATCH_MAX 32
+struct GdspBatch
+	{
+	const double* in[GDSP_BATCH_MAX];
+	double*       out[GDSP_BATCH_MAX];
+	uint32_t      n[GDSP_BATCH_MAX];
+	uint32_t      tile0[GDSP_BATCH_MAX + 1];
+	uint32_t      nvec;
+	};
+
+// -> tile index inside the vector; in / out / n are set to the vector's
+__device__ __forceinline__ uint32_t gdsp_batch_tile (const GdspBatch& B, const double*& in, double*& out, uint32_t& n)
+	{
+	const uint32_t g = gdsp_xcd_tile (blockIdx.x, B.tile0[B.nvec]);
+	uint32_t lo = 0, hi = B.nvec;                  // invariant: tile0[lo] <= g < tile0[hi]
+	while (hi - lo > 1)
+		{
+		const uint32_t mid = (lo + hi) >> 1;
+		if (B.tile0[mid] <= g) lo = mid;  else hi = mid;
+		}
+	in = B.in[lo];  out = B.out[lo];  n = B.n[lo];
+	return g - B.tile0[lo];
+	}
+
+// host: launch(B, tiles) over tables of up to GDSP_BATCH_MAX vectors each until every item has been covered (empty
+// vectors are skipped).  tilesOf(n) = tiles the kernel needs for a vector of n elements.
+template <typename TilesOf, typename Launch>
+static inline void gdsp_batch_run (const gdsp_batch_item* items, int nitems, TilesOf tilesOf, Launch launch)
+	{
+	int i = 0;
+	while (i < nitems)
+		{
+		GdspBatch B;
+		int k = 0;
+		B.tile0[0] = 0;
+		for ( ; (i<nitems) && (k<GDSP_BATCH_MAX) ; i++)
+			{
+			if (items[i].n == 0) continue;
+			const uint64_t t = (uint64_t) B.tile0[k] + tilesOf (items[i].n);
+			if ((t > 0x7FFFFFFFull) && (k > 0)) break;             // grid limit: the rest goes into the next launch
+			B.in[k] = items[i].d_in;  B.out[k] = items[i].d_out;  B.n[k] = items[i].n;
+			B.tile0[++k] = (uint32_t) t;
+			}
+		for (int j=k ; j<GDSP_BATCH_MAX ; j++) { B.in[j] = NULL;  B.out[j] = NULL;  B.n[j] = 0;  B.tile0[j+1] = B.tile0[k]; }
+		B.nvec = (uint32_t) k;
+		if (k > 0) launch (B, B.tile0[k]);
+		}
 	}
 
 // Stage v[g0 .. g0+L) into LDS (zero / `pad` outside [0,n)).  g0 and L are even and v is

@@ -79,9 +79,8 @@ __device__ __forceinline__ void fir_store_tile (double* lds, const double (&acc)
 
 // ---------------------------------------------------- compile-time W kernel ----
 template <int W, int R, bool FMA>
-__global__ __launch_bounds__(FIR_THREADS)
-void fir_fixed_kernel (const double* __restrict__ in, double* __restrict__ out,
-                       uint32_t n, uint32_t ntiles, FirTaps<W> taps)
+__device__ __forceinline__ void fir_fixed_tile (const double* __restrict__ in, double* __restrict__ out,
+                                                uint32_t n, uint32_t tile, const FirTaps<W>& taps)
 	{
 	constexpr int H  = (W - 1) / 2;
 	constexpr int T  = FIR_THREADS * R;
@@ -90,7 +89,6 @@ void fir_fixed_kernel (const double* __restrict__ in, double* __restrict__ out,
 	constexpr int LP = (L + 1) & ~1;
 	__shared__ __attribute__((aligned(16))) double lds[LP];
 
-	const uint32_t tile      = gdsp_xcd_tile (blockIdx.x, ntiles);
 	const int64_t  tileStart = (int64_t) tile * T;
 	const int64_t  g0        = tileStart - H - SH;
 
@@ -142,6 +140,21 @@ void fir_fixed_kernel (const double* __restrict__ in, double* __restrict__ out,
 	fir_store_tile<R> (lds, acc, out, tileStart, n);
 	}
 
+template <int W, int R, bool FMA>
+__global__ __launch_bounds__(FIR_THREADS)
+void fir_fixed_kernel (const double* __restrict__ in, double* __restrict__ out,
+                       uint32_t n, uint32_t ntiles, FirTaps<W> taps)
+	{ fir_fixed_tile<W, R, FMA> (in, out, n, gdsp_xcd_tile (blockIdx.x, ntiles), taps); }
+
+template <int W, int R, bool FMA>                        // one grid over every vector of the table (gdsp_common.h)
+__global__ __launch_bounds__(FIR_THREADS)
+void fir_fixed_batch_kernel (GdspBatch B, FirTaps<W> taps)
+	{
+	const double* in;  double* out;  uint32_t n;
+	const uint32_t tile = gdsp_batch_tile (B, in, out, n);
+	fir_fixed_tile<W, R, FMA> (in, out, n, tile, taps);
+	}
+
 // ------------------------------------------- fixed W fused with localmin/localmax ----
 // `= smooth W=101 = localmax N=11` (BASELINE configs[2]) in one pass: the smoothed tile is
 // already in LDS on its way out, so the neighbourhood test runs there and only the peaks
@@ -152,9 +165,8 @@ void fir_fixed_kernel (const double* __restrict__ in, double* __restrict__ out,
 // kernels, so the result is bit-identical to running them one after the other.
 #define FIR_FUSE_MAX_HALF 64
 template <int W, int R, bool FMA, bool MAX>
-__global__ __launch_bounds__(FIR_THREADS)
-void fir_fixed_extrema_kernel (const double* __restrict__ in, double* __restrict__ out,
-                               uint32_t n, uint32_t ntiles, FirTaps<W> taps, int h, double fill)
+__device__ __forceinline__ void fir_fixed_extrema_tile (const double* __restrict__ in, double* __restrict__ out,
+                                                        uint32_t n, uint32_t tile, const FirTaps<W>& taps, int h, double fill)
 	{
 	constexpr int H  = (W - 1) / 2;
 	constexpr int T  = FIR_THREADS * R;
@@ -163,7 +175,6 @@ void fir_fixed_extrema_kernel (const double* __restrict__ in, double* __restrict
 
 	const int      sh        = (h + H) & 1;                // keeps the first staged index even
 	const int      stride    = T - 2*h;                    // outputs kept per tile (even)
-	const uint32_t tile      = gdsp_xcd_tile (blockIdx.x, ntiles);
 	const int64_t  keepStart = (int64_t) tile * stride;    // first output this tile stores
 	const int64_t  compStart = keepStart - h;              // first smoothed value it computes
 	const int64_t  g0        = compStart - H - sh;
@@ -220,20 +231,33 @@ void fir_fixed_extrema_kernel (const double* __restrict__ in, double* __restrict
 		}
 	}
 
+template <int W, int R, bool FMA, bool MAX>
+__global__ __launch_bounds__(FIR_THREADS)
+void fir_fixed_extrema_kernel (const double* __restrict__ in, double* __restrict__ out,
+                               uint32_t n, uint32_t ntiles, FirTaps<W> taps, int h, double fill)
+	{ fir_fixed_extrema_tile<W, R, FMA, MAX> (in, out, n, gdsp_xcd_tile (blockIdx.x, ntiles), taps, h, fill); }
+
+template <int W, int R, bool FMA, bool MAX>
+__global__ __launch_bounds__(FIR_THREADS)
+void fir_fixed_extrema_batch_kernel (GdspBatch B, FirTaps<W> taps, int h, double fill)
+	{
+	const double* in;  double* out;  uint32_t n;
+	const uint32_t tile = gdsp_batch_tile (B, in, out, n);
+	fir_fixed_extrema_tile<W, R, FMA, MAX> (in, out, n, tile, taps, h, fill);
+	}
+
 // --------------------------------------------------------- run-time W kernel ----
 // Any odd W (up to the reference's 50001, sum.c:478).  Taps are walked in stages
 // of at most KC so the LDS image stays small; the accumulators live in registers
 // across stages, so every output still sums its taps in ascending order.
 template <int R, bool FMA>
-__global__ __launch_bounds__(FIR_THREADS)
-void fir_generic_kernel (const double* __restrict__ in, double* __restrict__ out,
-                         uint32_t n, uint32_t ntiles,
-                         const double* __restrict__ taps, uint32_t W, uint32_t KC)
+__device__ __forceinline__ void fir_generic_tile (const double* __restrict__ in, double* __restrict__ out,
+                                                  uint32_t n, uint32_t tile,
+                                                  const double* __restrict__ taps, uint32_t W, uint32_t KC)
 	{
 	extern __shared__ __attribute__((aligned(16))) double ldsDyn[];
 	constexpr int T = FIR_THREADS * R;
 
-	const uint32_t tile      = gdsp_xcd_tile (blockIdx.x, ntiles);
 	const int64_t  tileStart = (int64_t) tile * T;
 	const int64_t  H         = (W - 1) / 2;
 
@@ -284,6 +308,22 @@ void fir_generic_kernel (const double* __restrict__ in, double* __restrict__ out
 
 	__syncthreads ();
 	fir_store_tile<R> (ldsDyn, acc, out, tileStart, n);
+	}
+
+template <int R, bool FMA>
+__global__ __launch_bounds__(FIR_THREADS)
+void fir_generic_kernel (const double* __restrict__ in, double* __restrict__ out,
+                         uint32_t n, uint32_t ntiles,
+                         const double* __restrict__ taps, uint32_t W, uint32_t KC)
+	{ fir_generic_tile<R, FMA> (in, out, n, gdsp_xcd_tile (blockIdx.x, ntiles), taps, W, KC); }
+
+template <int R, bool FMA>
+__global__ __launch_bounds__(FIR_THREADS)
+void fir_generic_batch_kernel (GdspBatch B, const double* __restrict__ taps, uint32_t W, uint32_t KC)
+	{
+	const double* in;  double* out;  uint32_t n;
+	const uint32_t tile = gdsp_batch_tile (B, in, out, n);
+	fir_generic_tile<R, FMA> (in, out, n, tile, taps, W, KC);
 	}
 
 // ------------------------------------------------------------------- host ----
@@ -471,6 +511,121 @@ int gdsp_smooth (const double* d_in, double* d_out, uint32_t n, uint32_t W, int 
 	if (rc != GDSP_OK) return rc;
 	return gdsp_fir_apply (plan, d_in, d_out, n, mode, stream);
 	}
+
+} // extern "C"
+
+// every vector of a batch: non-NULL, distinct input and output, 16-byte aligned
+static int batch_check (const gdsp_batch_item* items, int nitems, bool inPlace)
+	{
+	GDSP_REQUIRE ((nitems == 0) || (items != NULL), "items is NULL");
+	GDSP_REQUIRE (nitems >= 0, "negative item count");
+	for (int i=0 ; i<nitems ; i++)
+		{
+		if (items[i].n == 0) continue;
+		GDSP_REQUIRE (items[i].d_out != NULL, "NULL vector");
+		GDSP_REQUIRE (gdsp_aligned16 (items[i].d_out), "vectors must be 16-byte aligned");
+		if (inPlace) continue;
+		GDSP_REQUIRE ((items[i].d_in != NULL) && (items[i].d_in != items[i].d_out), "vectors must be distinct and non-NULL");
+		GDSP_REQUIRE (gdsp_aligned16 (items[i].d_in), "vectors must be 16-byte aligned");
+		}
+	return GDSP_OK;
+	}
+int gdsp_batch_check (const gdsp_batch_item* items, int nitems, bool inPlace) { return batch_check (items, nitems, inPlace); }
+
+// gdsp_smooth for every vector of a device in one launch (sum.c:616-676 applied per chromosome by genodsp.c:909-921)
+extern "C" int gdsp_smooth_batch (const gdsp_batch_item* items, int nitems, uint32_t W, int mode, void* stream)
+	{
+	GDSP_REQUIRE ((W >= 3) && (W & 1), "W must be odd and >= 3");
+	GDSP_REQUIRE (W <= 50001, "W exceeds 50001");
+	int rc = batch_check (items, nitems, false);
+	if (rc != GDSP_OK) return rc;
+	if (mode == GDSP_FIR_HANN)
+		{
+		if (gdsp_hann_blocks_batch_available (W)) return gdsp_hann_blocks_apply_batch (items, nitems, W, stream);
+		if (gdsp_hann_blocks_available (W) || gdsp_hann_far_available (W))
+			{
+			for (int i=0 ; i<nitems ; i++)
+				{ rc = gdsp_smooth (items[i].d_in, items[i].d_out, items[i].n, W, mode, stream);  if (rc != GDSP_OK) return rc; }
+			return GDSP_OK;
+			}
+		mode = GDSP_FIR_FMA;
+		}
+	GDSP_REQUIRE ((mode == GDSP_FIR_EXACT) || (mode == GDSP_FIR_FMA), "unknown mode");
+	gdsp_fir_plan* plan = NULL;
+	rc = smooth_plan (W, &plan);
+	if (rc != GDSP_OK) return rc;
+	constexpr int T = FIR_THREADS * FIR_R;
+	hipStream_t   s = gdsp_stream (stream);
+	auto tilesOf = [] (uint32_t n) { return ((uint64_t) n + T - 1) / T; };
+	if (W == 101)
+		{
+		FirTaps<101> taps;
+		memcpy (taps.w, plan->h_taps, sizeof(taps.w));
+		gdsp_batch_run (items, nitems, tilesOf, [&] (const GdspBatch& B, uint32_t tiles)
+			{
+			if (mode == GDSP_FIR_FMA) hipLaunchKernelGGL ((fir_fixed_batch_kernel<101, FIR_R, true>),  dim3(tiles), dim3(FIR_THREADS), 0, s, B, taps);
+			else                      hipLaunchKernelGGL ((fir_fixed_batch_kernel<101, FIR_R, false>), dim3(tiles), dim3(FIR_THREADS), 0, s, B, taps);
+			});
+		}
+	else
+		{
+		uint32_t KC = ((W + FIR_R - 1) / FIR_R) * FIR_R;
+		if (KC > FIR_KC_MAX) KC = FIR_KC_MAX;
+		const size_t ldsBytes = ((size_t) T + KC + 2*FIR_R + 4) * sizeof(double);
+		gdsp_batch_run (items, nitems, tilesOf, [&] (const GdspBatch& B, uint32_t tiles)
+			{
+			if (mode == GDSP_FIR_FMA) hipLaunchKernelGGL ((fir_generic_batch_kernel<FIR_R, true>),  dim3(tiles), dim3(FIR_THREADS), ldsBytes, s, B, plan->d_taps, W, KC);
+			else                      hipLaunchKernelGGL ((fir_generic_batch_kernel<FIR_R, false>), dim3(tiles), dim3(FIR_THREADS), ldsBytes, s, B, plan->d_taps, W, KC);
+			});
+		}
+	GDSP_LAUNCH_CHECK ();
+	return GDSP_OK;
+	}
+
+template <bool FMA, bool MAX>
+static void fir_extrema_batch_launch (const gdsp_batch_item* items, int nitems, const double* h_taps, int h, double fill, hipStream_t s)
+	{
+	FirTaps<101> taps;
+	memcpy (taps.w, h_taps, sizeof(taps.w));
+	const int stride = FIR_THREADS*FIR_R - 2*h;
+	gdsp_batch_run (items, nitems, [=] (uint32_t n) { return ((uint64_t) n + stride - 1) / stride; },
+		[&] (const GdspBatch& B, uint32_t tiles)
+			{ hipLaunchKernelGGL ((fir_fixed_extrema_batch_kernel<101, FIR_R, FMA, MAX>), dim3(tiles), dim3(FIR_THREADS), 0, s, B, taps, h, fill); });
+	}
+
+extern "C" int gdsp_smooth_local_extrema_batch (const gdsp_batch_item* items, int nitems, uint32_t W, int mode,
+                                                uint32_t N, int wantMax, double fill, void* stream)
+	{
+	GDSP_REQUIRE (gdsp_smooth_local_extrema_fusable (W, N), "no fused kernel for this window/neighborhood");
+	if (mode == GDSP_FIR_HANN) mode = GDSP_FIR_FMA;
+	GDSP_REQUIRE ((mode == GDSP_FIR_EXACT) || (mode == GDSP_FIR_FMA), "unknown mode");
+	int rc = batch_check (items, nitems, false);
+	if (rc != GDSP_OK) return rc;
+	gdsp_fir_plan* plan = NULL;
+	rc = smooth_plan (W, &plan);
+	if (rc != GDSP_OK) return rc;
+	const int   h = (int) ((N - 1) / 2);
+	hipStream_t s = gdsp_stream (stream);
+	if ((mode == GDSP_FIR_EXACT) && (getenv ("GDSP_PEAKS_FILTER") != NULL) && (strcmp (getenv ("GDSP_PEAKS_FILTER"), "1") == 0))
+		{
+		for (int i=0 ; i<nitems ; i++)
+			{
+			rc = gdsp_smooth_local_extrema (items[i].d_in, items[i].d_out, items[i].n, W, mode, N, wantMax, fill, stream);
+			if (rc != GDSP_OK) return rc;
+			}
+		return GDSP_OK;
+		}
+	if (mode == GDSP_FIR_FMA)
+		{ if (wantMax) fir_extrema_batch_launch<true, true>  (items, nitems, plan->h_taps, h, fill, s);
+		  else         fir_extrema_batch_launch<true, false> (items, nitems, plan->h_taps, h, fill, s); }
+	else
+		{ if (wantMax) fir_extrema_batch_launch<false, true>  (items, nitems, plan->h_taps, h, fill, s);
+		  else         fir_extrema_batch_launch<false, false> (items, nitems, plan->h_taps, h, fill, s); }
+	GDSP_LAUNCH_CHECK ();
+	return GDSP_OK;
+	}
+
+extern "C" {
 
 static int smooth_plan (uint32_t W, gdsp_fir_plan** out)
 	{

@@ -284,16 +284,14 @@ __device__ __forceinline__ bool hann_tile_sums (double* lds, double (*tot)[HN_TH
 	}
 
 template <int W>
-__global__ __launch_bounds__(HN_THREADS)
-void hann_blocks_kernel (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t ntiles,
-                         HannConsts<W> K, const double* __restrict__ taps)
+__device__ __forceinline__ void hann_blocks_tile (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t tile,
+                                                  const HannConsts<W>& K, const double* __restrict__ taps)
 	{
 	typedef HannGeom<W> G;
 	__shared__ __attribute__((aligned(16))) double lds[HN_THREADS * HN_PITCH];
 	__shared__ double tot[3][HN_THREADS];
 	__shared__ __attribute__((aligned(16))) uint32_t huge[HN_THREADS/64];
 
-	const uint32_t tile = gdsp_xcd_tile (blockIdx.x, ntiles);
 	const int64_t  out0 = (int64_t) tile * G::OUT;
 	const int64_t  e0   = out0 - G::LEAD;                         // first staged element (even)
 	const int      p    = threadIdx.x;
@@ -336,6 +334,21 @@ void hann_blocks_kernel (const double* __restrict__ in, double* __restrict__ out
 		for (int o=p ; o<G::OUT ; o+=HN_THREADS)
 			{ if (out0 + o < (int64_t) n) out[out0 + o] = lds[o + (o >> 4)]; }
 		}
+	}
+
+template <int W>
+__global__ __launch_bounds__(HN_THREADS)
+void hann_blocks_kernel (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t ntiles,
+                         HannConsts<W> K, const double* __restrict__ taps)
+	{ hann_blocks_tile<W> (in, out, n, gdsp_xcd_tile (blockIdx.x, ntiles), K, taps); }
+
+template <int W>                                                  // one grid over every vector of the table (gdsp_common.h)
+__global__ __launch_bounds__(HN_THREADS)
+void hann_blocks_batch_kernel (GdspBatch B, HannConsts<W> K, const double* __restrict__ taps)
+	{
+	const double* in;  double* out;  uint32_t n;
+	const uint32_t tile = gdsp_batch_tile (B, in, out, n);
+	hann_blocks_tile<W> (in, out, n, tile, K, taps);
 	}
 
 template <int W>
@@ -974,6 +987,27 @@ static int hann_plan_rt (uint32_t W, HannPlanRT** out)
 	GDSP_HIP_TRY (hipMemcpy (pl->d_rot, h_rot, sizeof(h_rot), hipMemcpyHostToDevice));
 	hannPlanLen++;
 	*out = pl;
+	return GDSP_OK;
+	}
+
+bool gdsp_hann_blocks_batch_available (uint32_t W) { return W == 101; }
+
+int gdsp_hann_blocks_apply_batch (const gdsp_batch_item* items, int nitems, uint32_t W, void* stream)
+	{
+	GDSP_REQUIRE (gdsp_hann_blocks_batch_available (W), "no one-launch block-sum kernel for this window");
+	int rc = gdsp_batch_check (items, nitems, false);
+	if (rc != GDSP_OK) return rc;
+	const double* d_taps = NULL;
+	rc = gdsp_smooth_taps_device (W, &d_taps);
+	if (rc != GDSP_OK) return rc;
+	typedef HannGeom<101> G;
+	HannConsts<101> K;
+	hann_consts<101> (K);
+	hipStream_t s = gdsp_stream (stream);
+	gdsp_batch_run (items, nitems, [] (uint32_t n) { return ((uint64_t) n + G::OUT - 1) / G::OUT; },
+		[&] (const GdspBatch& B, uint32_t tiles)
+			{ hipLaunchKernelGGL ((hann_blocks_batch_kernel<101>), dim3(tiles), dim3(HN_THREADS), 0, s, B, K, d_taps); });
+	GDSP_LAUNCH_CHECK ();
 	return GDSP_OK;
 	}
 

@@ -23,6 +23,7 @@
 #include <string.h>
 #include <stdarg.h>
 #include <float.h>
+#include <time.h>
 #include "genodsp_interface.h"
 #include "genodsp_hip.h"
 #include "utilities.h"
@@ -130,6 +131,8 @@ static int fuseChains     = true;                /* --nofuse: one kernel per ope
 enum { reduce_auto, reduce_rccl, reduce_host };
 static int reduceHow      = reduce_auto;         /* --reduce=rccl|host: how whole-genome operators combine the devices */
 static gdsp_comm* deviceComm = NULL;             /* RCCL communicator over the devices in use (NULL: host sums)        */
+static u64 intervalsRead  = 0, linesWritten = 0; /* (what --report=gpu prints beside the times of ingest and output) */
+static int reportGpu      = false;               /* --report=gpu: per-operator device time, Gbases/s and GB/s on stderr */
 
 /* a chromosome as the driver sees it: the public spec first, device state after */
 typedef struct xspec
@@ -221,6 +224,8 @@ static void usage (void)
 	"                            values either way; auto brackets them from a subsample\n"
 	"                            when the genome is large)\n"
 	"  --help[=<operator>]  ?  ?<operator>   operator help\n"
+	"  --report=gpu              after the run, print what each operator cost on the GPU(s): calls, HIP-event\n"
+	"                            milliseconds (slowest device), Gbases/s and the GB/s of SURVEY 8d's bytes per base\n"
 	"  --report=comments  --progress=input:<n>  --progress=operations  --version\n\n"
 	"Overlapping input intervals are summed. Input comes from stdin unless the first\n"
 	"operator is \"input\". Operations have the form  = <operator> [arguments].\n", programName);
@@ -540,9 +545,14 @@ void sync_all_devices (void)
  * gdsp_comm_create) and the all-reduces run in HBM on each device's stream.  --reduce=host keeps the sums on the
  * host instead; that is also what happens when shards share a GPU (GDSP_OVERSUBSCRIBE_GPUS: RCCL wants one
  * rank per GPU) and, by default, with a single device (nothing to reduce; --reduce=rccl still goes through a
- * one-rank communicator, which is how the one-GPU test box exercises this path). */
-static void create_device_comm (void)
+ * one-rank communicator, which is how the one-GPU test box exercises this path).  The communicator is made on the
+ * first percentile / invert, so pipelines without them never load RCCL; when RCCL cannot be loaded or initialised the
+ * default (--reduce not given) falls back to host sums with a warning, an explicit --reduce=rccl stops. */
+static void ensure_device_comm (void)
 	{
+	static int tried = false;
+	if (tried) return;                               /* made on the first percentile / invert: a pipeline without them never loads RCCL */
+	tried = true;
 	int wantRccl = (reduceHow == reduce_rccl) || ((reduceHow == reduce_auto) && (numDevices > 1));
 	if (!wantRccl) return;
 	if (numDevices > physicalDevices)
@@ -553,7 +563,16 @@ static void create_device_comm (void)
 		}
 	int devices[64];
 	for (int d=0 ; d<numDevices ; d++) devices[d] = d % physicalDevices;
-	check_gdsp (gdsp_comm_create (&deviceComm, devices, numDevices), "create the RCCL communicator");
+	int rc = gdsp_comm_create (&deviceComm, devices, numDevices);
+	if ((rc != GDSP_OK) && (reduceHow == reduce_auto))
+		{
+		/* no loadable RCCL, or its initialisation failed: the counts are a few KiB, the host can add them */
+		fprintf (stderr, "[%s] warning: RCCL is not usable (%s); percentile / invert add their counts on the host (--reduce=host)\n",
+		         programName, gdsp_last_error ());
+		deviceComm = NULL;
+		return;
+		}
+	check_gdsp (rc, "create the RCCL communicator");
 	check_gdsp (gdsp_percentiles_use_comm (deviceComm), "hand the communicator to percentile");
 	if (trackOperations)
 		{
@@ -563,7 +582,7 @@ static void create_device_comm (void)
 		}
 	}
 
-gdsp_reduce_fn reduce_over_devices (void** ctx) { *ctx = NULL;  return NULL; }   /* (the communicator, when there is one, is inside the library) */
+gdsp_reduce_fn reduce_over_devices (void** ctx) { ensure_device_comm ();  *ctx = NULL;  return NULL; }   /* (the communicator, when there is one, is inside the library) */
 
 /* smallest and largest value of the whole genome (invert, add.c:909-923): every device folds its chromosomes into
  * three doubles of its own, the devices' results meet in an RCCL all-reduce (min / max) or on the host */
@@ -572,6 +591,7 @@ void genome_extremes (valtype* lo, valtype* hi)
 	static valtype* acc[64];
 	valtype*        accs[64];
 	void*           streams[64];
+	ensure_device_comm ();
 	for (int d=0 ; d<numDevices ; d++)
 		{
 		check_gdsp (use_device (d), "select device");
@@ -930,6 +950,7 @@ void ib_add (spec* s, u32 start, u32 end, valtype val)
 	p->start[p->count] = start;  p->end[p->count] = end;  p->val[p->count] = val;
 	p->count++;
 	pendTotal++;
+	intervalsRead++;
 	}
 
 u64 ib_pending (void) { return pendTotal; }
@@ -1192,6 +1213,7 @@ static void out_line (FILE* f, const char* chrom, int start, int end, int withVa
 	else if (withVal) { *(p++) = '\t';  p = put_fixed (p, v, precision); }
 	*(p++) = '\n';
 	outAt = p;
+	linesWritten++;
 	if (outAt - outBuf > OUTBUF_BYTES) out_flush (f);
 	}
 
@@ -1299,6 +1321,110 @@ void read_all_chromosomes (char* filename)
 	read_intervals (f, /*value column*/ 4-1, /*origin one*/ false, ri_overlapSum, /*clear*/ true, 0.0);
 	trackOperations = saveTrack;
 	fclose (f);
+	}
+
+/* ------------------------------------------------ --report=gpu: what each step cost ---- */
+/* per-operator HIP-event time and the rates that follow from it, from the product binary itself.
+ * A per-chromosome operator (or fused chain) is bracketed by two events on its chromosome's stream; its time is the
+ * sum over its calls on the slowest device (devices work side by side).  Whole-genome steps -- ingest, file-driven
+ * operators, percentile, output -- mix host and device work and are timed on the wall clock with the devices
+ * drained.  GB/s credits SURVEY 8d's algorithmic bytes: 16 per base and operator, 8 for percentile and the report. */
+typedef struct phase
+	{
+	char   label[160];
+	dspop* op;  int nops;
+	u32    calls;  u64 units;  const char* unitName;
+	double bytesPerBase, wallMs, devMs[64];
+	int    onWall;
+	} phase;
+typedef struct span { int phase, device;  void *ev0, *ev1; } span;
+static phase  phases[512];
+static int    numPhases = 0;
+static span*  spans = NULL;
+static u32    numSpans = 0, capSpans = 0;
+
+static double now_ms (void)
+	{ struct timespec t;  clock_gettime (CLOCK_MONOTONIC, &t);  return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
+
+static int phase_for (dspop* op, int nops, const char* fixedLabel)
+	{
+	for (int i=0 ; i<numPhases ; i++)
+		{ if ((op != NULL) && (phases[i].op == op) && (phases[i].nops == nops)) return i; }
+	if (numPhases == (int) (sizeof(phases)/sizeof(phases[0]))) return numPhases-1;
+	phase* ph = &phases[numPhases];
+	memset (ph, 0, sizeof(*ph));
+	ph->op = op;  ph->nops = nops;  ph->unitName = "bases";
+	if (fixedLabel != NULL) snprintf (ph->label, sizeof(ph->label), "%s", fixedLabel);
+	else
+		{
+		size_t at = 0;
+		dspop* o = op;
+		for (int k=0 ; (k<nops) && (o!=NULL) && (at+2<sizeof(ph->label)) ; k++, o=o->next)
+			at += (size_t) snprintf (ph->label + at, sizeof(ph->label) - at, "%s%s", (k == 0)? "" : "=", o->name);
+		}
+	ph->bytesPerBase = 16.0 * ((nops < 1)? 1 : nops);
+	return numPhases++;
+	}
+
+static u32 span_open (void)                      /* on the current device's operator stream */
+	{
+	if (numSpans == capSpans)
+		{
+		capSpans = (capSpans == 0)? 1024 : 2*capSpans;
+		spans = (span*) realloc (spans, capSpans * sizeof(span));
+		if (spans == NULL) { fprintf (stderr, "out of memory\n");  exit (EXIT_FAILURE); }
+		}
+	span* sp = &spans[numSpans];
+	sp->phase = -1;  sp->device = currentDevice;
+	check_gdsp (gdsp_event_create (&sp->ev0), "create event");
+	check_gdsp (gdsp_event_create (&sp->ev1), "create event");
+	check_gdsp (gdsp_event_record (sp->ev0, op_stream ()), "record event");
+	return numSpans++;
+	}
+
+static void span_close (u32 ix, dspop* op, int nops, u64 bases)
+	{
+	span* sp = &spans[ix];
+	check_gdsp (gdsp_event_record (sp->ev1, op_stream ()), "record event");
+	sp->phase = phase_for (op, nops, NULL);
+	phases[sp->phase].calls++;
+	phases[sp->phase].units += bases;
+	}
+
+static void wall_phase (dspop* op, const char* label, double ms, u64 units, const char* unitName, double bytesPerBase)
+	{
+	int i = phase_for (op, 1, label);
+	phases[i].onWall = true;  phases[i].calls++;  phases[i].wallMs += ms;  phases[i].units += units;
+	phases[i].unitName = unitName;  phases[i].bytesPerBase = bytesPerBase;
+	}
+
+static void report_gpu_times (void)
+	{
+	sync_all_devices ();
+	for (u32 i=0 ; i<numSpans ; i++)
+		{
+		float ms = 0;
+		check_gdsp (use_device (spans[i].device), "select device");
+		check_gdsp (gdsp_event_elapsed_ms (spans[i].ev0, spans[i].ev1, &ms), "event time");
+		if (spans[i].phase >= 0) phases[spans[i].phase].devMs[spans[i].device] += ms;
+		gdsp_event_destroy (spans[i].ev0);  gdsp_event_destroy (spans[i].ev1);
+		}
+	check_gdsp (use_device (currentDevice), "select device");
+	fprintf (stderr, "[%s] --report=gpu: %d device%s (%s); event = HIP-event ms summed over a step's calls on the slowest device,\n"
+	                 "  wall = host clock with the devices drained (steps that mix host and device work)\n",
+	         programName, numDevices, (numDevices == 1)? "" : "s", gdsp_version ());
+	fprintf (stderr, "  %-34s %6s %16s %-9s %10s %5s %10s %9s %6s\n", "step", "calls", "units", "", "ms", "clock", "Gbases/s", "GB/s", "B/base");
+	for (int i=0 ; i<numPhases ; i++)
+		{
+		phase* ph = &phases[i];
+		double ms = ph->wallMs;
+		if (!ph->onWall) { for (int d=0 ; d<numDevices ; d++) { if (ph->devMs[d] > ms) ms = ph->devMs[d]; } }
+		fprintf (stderr, "  %-34s %6u %16llu %-9s %10.3f %5s", ph->label, ph->calls, (unsigned long long) ph->units, ph->unitName,
+		         ms, ph->onWall? "wall" : "event");
+		if ((strcmp (ph->unitName, "bases") == 0) && (ms > 0))
+			fprintf (stderr, " %10.2f %9.1f %6.0f", ph->units / ms * 1e-6, ph->units * ph->bytesPerBase / ms * 1e-6, ph->bytesPerBase);
+		fprintf (stderr, "\n");
+		}
 	}
 
 /* ------------------------------------------------------------- option parsing */
@@ -1466,6 +1592,8 @@ static void parse_options (int _argc, char** _argv)            /* genodsp.c:284-
 			}
 		if ((strcmp (arg, "--report=comments") == 0) || (strcmp (arg, "--report:comments") == 0))
 			{ reportComments = true;  continue; }
+		if ((strcmp (arg, "--report=gpu") == 0) || (strcmp (arg, "--report:gpu") == 0))
+			{ reportGpu = true;  continue; }
 		if ((strcmp_prefix (arg, "--progress=input:") == 0) || (strcmp_prefix (arg, "--progress:input=") == 0)
 		 || (strcmp_prefix (arg, "--progress:input:") == 0))
 			{
@@ -1531,16 +1659,22 @@ int main (int argc, char** argv)
 		return EXIT_FAILURE;
 		}
 
+	if ((reduceHow == reduce_rccl) && (numDevices > physicalDevices))
+		{ fprintf (stderr, "[%s] --reduce=rccl needs one GPU per shard (%d shards, %d GPUs)\n", programName, numDevices, physicalDevices);  return EXIT_FAILURE; }
+
 	sort_chromosomes_by_length ();
 	deal_chromosomes ();
 	if (shardBases) plan_pieces ();                            /* (before allocation: stretches count towards scratch sizes) */
 	allocate_vectors ();
 	if (shardBases) allocate_pieces ();
-	create_device_comm ();
 
 	/* stdin is the signal unless the first operator is `input` (genodsp.c:891-893) */
 	if ((pipeline == NULL) || (strcmp (pipeline->name, "input") != 0))
+		{
+		double t0 = now_ms ();
 		read_intervals (stdin, valColumn, originOne, ri_overlapSum, /*clear*/ false, 0.0);
+		if (reportGpu) { sync_all_devices ();  wall_phase (NULL, "input (stdin: parse, stage, apply)", now_ms () - t0, intervalsRead, "intervals", 0); }
+		}
 
 	/* batching loop, genodsp.c:900-936: maximal runs of per-chromosome operators go
 	 * chromosome by chromosome (longest first); whole-genome operators get one call */
@@ -1569,8 +1703,11 @@ int main (int argc, char** argv)
 				for (dspop* op=firstOp ; op!=stopOp ; op=op->next)
 					{
 					if (trackOperations) fprintf (stderr, "%s(%s)\n", op->name, where);
+					dspop* first = op;
+					u32 sp = reportGpu? span_open () : 0;
 					int fused = fuseChains? try_fused_apply (op, stopOp, s) : 0;
-					if (fused == 0) { (*op->funcApply) (op, s->chrom, s->length, s->valVector);  continue; }
+					if (fused == 0) (*op->funcApply) (op, s->chrom, s->length, s->valVector);
+					if (reportGpu) span_close (sp, first, (fused == 0)? 1 : fused, s->length);
 					for ( ; fused > 1 ; fused--)           /* the chain ran as one kernel */
 						{
 						op = op->next;
@@ -1588,14 +1725,38 @@ int main (int argc, char** argv)
 			if ((stopOp->funcApply != op_percentile_apply) && (stopOp->funcApply != op_invert_apply)
 			 && (stopOp->funcApply != op_show_variables_apply))
 				to_whole ();                                   /* file-driven operators address whole chromosomes */
+			double t0 = now_ms ();
+			u64 ivBefore = intervalsRead;
+			if (reportGpu) sync_all_devices ();
 			(*stopOp->funcApply) (stopOp, "*", maxLength, NULL);
+			if (reportGpu)
+				{
+				u64 total = 0;
+				for (int i=0 ; chromsSorted[i]!=NULL ; i++) total += chromsSorted[i]->length;
+				sync_all_devices ();
+				if (stopOp->funcApply == op_show_variables_apply) ;
+				else if ((intervalsRead != ivBefore) && (stopOp->funcApply != op_percentile_apply))
+					{
+					char label[160];
+					snprintf (label, sizeof(label), "%s (file: parse, stage, apply)", stopOp->name);
+					wall_phase (stopOp, label, now_ms () - t0, intervalsRead - ivBefore, "intervals", 0);
+					}
+				else wall_phase (stopOp, stopOp->name, now_ms () - t0, total, "bases", (stopOp->funcApply == op_percentile_apply)? 8 : 16);
+				}
 			firstOp = stopOp->next;
 			}
 		}
 
 	if (!inhibitOutput)
+		{
+		double t0 = now_ms ();
+		u64 linesBefore = linesWritten;
+		if (reportGpu) sync_all_devices ();
 		report_intervals (stdout, valPrecision, noOutputValues, collapseRuns, showUncovered, originOne);
+		if (reportGpu) { fflush (stdout);  wall_phase (NULL, "output (find runs, fetch, format)", now_ms () - t0, linesWritten - linesBefore, "lines", 0); }
+		}
 	sync_all_devices ();
+	if (reportGpu) report_gpu_times ();
 
 	for (dspop* op=pipeline, *next ; op!=NULL ; op=next)
 		{ next = op->next;  free (op->name);  (*op->funcFree) (op); }

@@ -162,6 +162,36 @@ int gdsp_close_any  (const double* d_in, double* d_out, uint32_t n, double closi
 int gdsp_open_any   (const double* d_in, double* d_out, uint32_t n, double openingLength,
                      double T, double one, double zero, void* d_work, size_t workBytes, void* stream);
 
+/* ---- one launch per operator per device (replaces the chromosome loop of genodsp.c:909-921) ----------------------
+ * The reference applies an operator to one chromosome after the other.  On the GPU every launch ramps up and drains
+ * (10-15 % of a short kernel's time), so a device that holds several chromosomes -- or several stretches of them --
+ * is given ONE grid that covers all of its vectors: items[i] = (input, output, length) of vector i, all on the current
+ * device, all 16-byte aligned, outputs distinct from inputs for the out-of-place operators (in-place operators use
+ * d_out only).  Results are those of the single-vector calls bit for bit (the same kernels; only the block-to-tile
+ * map differs).  Any number of items; tables of 32 vectors travel in the kernel arguments. */
+typedef struct gdsp_batch_item { const double* d_in;  double* d_out;  uint32_t n; } gdsp_batch_item;
+int gdsp_smooth_batch               (const gdsp_batch_item* items, int nitems, uint32_t W, int mode, void* stream);
+int gdsp_smooth_local_extrema_batch (const gdsp_batch_item* items, int nitems, uint32_t W, int mode,
+                                     uint32_t N, int wantMax, double fill, void* stream);
+int gdsp_local_extrema_batch        (const gdsp_batch_item* items, int nitems, uint32_t N, int wantMax, double fill, void* stream);
+int gdsp_best_extrema_batch         (const gdsp_batch_item* items, int nitems, uint32_t W, int wantMax, void* stream);
+int gdsp_dilate_batch               (const gdsp_batch_item* items, int nitems, uint32_t left, uint32_t right,
+                                     double T, double one, double zero, void* stream);
+int gdsp_erode_batch                (const gdsp_batch_item* items, int nitems, uint32_t left, uint32_t right,
+                                     double T, double one, double zero, void* stream);
+int gdsp_dilate_erode_batch         (const gdsp_batch_item* items, int nitems,
+                                     uint32_t dLeft, uint32_t dRight, double dT, double dOne, double dZero,
+                                     uint32_t eLeft, uint32_t eRight, double eT, double eOne, double eZero,
+                                     int binarize, double bT, int bTiesAbove, double bOne, double bZero, void* stream);
+int gdsp_binarize_batch             (const gdsp_batch_item* items, int nitems, double T, int tiesAbove, double one, double zero, void* stream);
+int gdsp_clip_batch                 (const gdsp_batch_item* items, int nitems, int haveMin, double minVal, int haveMax, double maxVal, void* stream);
+int gdsp_erase_batch                (const gdsp_batch_item* items, int nitems, int haveMin, double minVal, int haveMax, double maxVal,
+                                     int keepInside, double zero, void* stream);
+int gdsp_add_constant_batch         (const gdsp_batch_item* items, int nitems, double c, void* stream);
+int gdsp_abs_batch                  (const gdsp_batch_item* items, int nitems, void* stream);
+/* GDSP_EINVAL from a *_batch call whose parameters the single-vector call would also refuse, or for which no tiled
+ * kernel exists (the caller then loops over the vectors with the single-vector / *_any forms). */
+
 /* ---- logical.c, mask.c, add.c (in place) ---------------------------------------- */
 int gdsp_binarize     (double* d_v, uint32_t n, double T, int tiesAbove, double one, double zero,
                        void* stream);                                 /* logical.c:216-268 */

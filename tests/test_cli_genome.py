@@ -1,0 +1,72 @@
+"""GPU: the drop-in itself at the size the contract names -- `genodsp_hip` (the C driver, not the Python binding) on
+BASELINE configs[1..4] over the 24-chromosome 3 088 269 832-base genome, against what the unmodified reference printed
+for the same input (tests/golden/genome_cli.json, recorded by tools/make_genome_golden.py in the build container:
+sha256, line and byte counts, first and last lines of stdout, the percentile line of stderr).
+
+The 12 M-read input is not committed: tools/genome_reads.c regenerates it here (seeded) and its digest is checked
+first.  Each pipeline runs with whole chromosomes on one device and again as three stretches-of-bases shards sharing
+the GPU (`--gpus=3 --sharding=bases`, GDSP_OVERSUBSCRIBE_GPUS=1).  Reference: genodsp.c:822-990 end to end
+(read_intervals :1187-1350, the batching loop :900-936, report_intervals :1561-1691).
+
+GDSP_GENOME_REPORT=<file>: append each run's `--report=gpu` table and wall time there (profiles/r03_cli_genome.txt).
+"""
+import json
+import os
+import subprocess
+
+import pytest
+
+import genome_cli as gc
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+BIN = os.path.join(ROOT, "genodsp_amd", "genodsp_hip")
+
+
+@pytest.fixture(scope="module")
+def genome():
+    if not os.path.exists(gc.GOLDEN):
+        pytest.skip("tests/golden/genome_cli.json has not been recorded")
+    gold = json.load(open(gc.GOLDEN))
+    if not os.path.exists(BIN):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "genodsp_amd", "host")])
+    chroms, reads, sha, lines = gc.make_input(gold["seed"])
+    assert (sha, lines) == (gold["input_sha256"], gold["input_lines"]), "the regenerated read file differs from the recorded one"
+    return gold, chroms, reads
+
+
+SHARDINGS = {"chromosomes": [], "bases_3_shards": ["--gpus=3", "--sharding=bases"]}
+
+
+@pytest.mark.parametrize("sharding", list(SHARDINGS))
+@pytest.mark.parametrize("name", list(gc.PIPELINES))
+def test_genome_scale_pipeline_prints_what_the_reference_prints(name, sharding, genome):
+    gold, chroms, reads = genome
+    if name not in gold["runs"]:
+        pytest.skip("no recorded reference run for " + name)
+    want = gold["runs"][name]
+    assert want["returncode"] == 0
+    preserve = os.path.join(gc.workdir(), "preserve.hip.dat")
+    env = dict(os.environ, GDSP_OVERSUBSCRIBE_GPUS="1")
+    args = gc.args_for(name, chroms, preserve)
+    cmd = [BIN, args[0], "--report=gpu"] + SHARDINGS[sharding] + args[1:]
+    got = gc.digest_run(cmd, reads, env=env)
+    if os.path.exists(preserve):
+        os.remove(preserve)
+    report = os.environ.get("GDSP_GENOME_REPORT")
+    if report:
+        with open(report, "a") as f:
+            f.write("== %s, sharding %s: genodsp_hip %.2f s wall (ingest of %d lines, operators, %d output lines), reference %.2f s "
+                    "wall in the build container; stdout %s\n   %s\n%s\n" %
+                    (name, sharding, got["wall_s"], gold["input_lines"], got["lines"], want["wall_s"],
+                     "identical (sha256 %s)" % got["sha256"][:16] if got["sha256"] == want["sha256"] else "DIFFERS",
+                     " ".join(cmd[2:]), got["stderr"]))
+    assert got["returncode"] == 0, got["stderr"][-2000:]
+    assert got["head"] == want["head"]
+    assert got["tail"] == want["tail"]
+    assert (got["lines"], got["bytes"]) == (want["lines"], want["bytes"])
+    assert got["sha256"] == want["sha256"]
+    for line in want["stderr"].splitlines():                      # "percentile 99.000 is ..."
+        assert line in got["stderr"].splitlines()
+    assert "--report=gpu" in got["stderr"]
