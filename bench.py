@@ -52,6 +52,11 @@ KERNELS = {"hann": "hann_blocks_kernel<101>", "fma": "fir_fixed_kernel<101,9,tru
            "exact": "fir_fixed_kernel<101,9,false>"}
 
 
+def batch_name(kernel):
+    """the one-launch-per-device form of a kernel (gdsp_*_batch): same tile code, the grid covers every vector of the rank"""
+    return kernel.replace("_kernel", "_batch_kernel", 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,6 +84,9 @@ def main():
                     help="HIP streams the independent chromosomes of a rank alternate over (default 1: launches follow one "
                          "another, which is what the committed rocprofv3 per-kernel durations describe; 3 hides the drain "
                          "between kernels, +3..5 %% on the HBM-bound workloads)")
+    ap.add_argument("--launch", choices=["batch", "chromosome"], default="batch",
+                    help="batch = one launch per operator covers every chromosome of the rank (gdsp_*_batch, what genodsp_hip "
+                         "does by default); chromosome = one launch per chromosome, one after the other (--nobatch of the driver)")
     ap.add_argument("--workload", choices=["smooth", "peaks", "morph", "percentile"], default="smooth",
                     help="smooth = BASELINE configs[1] (the metric); the others are configs[2..4], "
                          "reported in the same shape for DESIGN.md, never the driver's number")
@@ -140,7 +148,13 @@ def main():
     lanes = [stream] + [gd.Stream() for _ in range(max(1, args.streams) - 1)]
     lane_of = {k: lanes[j % len(lanes)] for j, k in enumerate(mine)}
 
+    batch = args.launch == "batch"
+    items_io = gd.batch_items([vin[i] for i in mine], [vout[i] for i in mine])          # the rank's vectors as one table
+
     def step(mode):
+        if batch:
+            gd.call("gdsp_smooth_batch", items_io, len(mine), WINDOW, mode, stream.handle)
+            return
         for i in mine:
             gd.smooth(vin[i], WINDOW, out=vout[i], mode=mode, stream=lane_of[i].handle)
 
@@ -195,10 +209,10 @@ def main():
         owned = [sum(b - a for _, _, a, b in sh) for sh in shards]
         busiest = max(range(world), key=lambda r: owned[r])
         bases_rank = owned[busiest]
-        launches = max(1, len(shards[busiest]))
+        launches = 1 if batch else max(1, len(shards[busiest]))
         avg_launch_ms = dev_ms_per_step / launches
         achieved = BYTES_PER_BASE * bases_rank / (dev_ms_per_step * 1e-3) / 1e9
-        kernel = KERNELS[mode]
+        kernel = batch_name(KERNELS[mode]) if batch else KERNELS[mode]
         r = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(achieved / HBM_PEAK_GBS, 4),
              "traffic": measured_traffic(kernel, BYTES_PER_BASE * bases_rank / launches),
@@ -227,7 +241,9 @@ def main():
                                + ARITHMETIC[args.mode] + "; the other two arithmetics are in other_modes",
                    "window": WINDOW, "chromosomes": len(GENOME), "bases": total_bases,
                    "fir_mode": args.mode, "library": gd.lib().gdsp_version().decode(),
-                   "streams": args.streams, "sharding": "whole chromosomes, LPT over ranks" if args.sharding == "chromosomes"
+                   "streams": args.streams, "launch": "one launch per step covers every chromosome of the rank" if batch
+                               else "one launch per chromosome",
+                   "sharding": "whole chromosomes, LPT over ranks" if args.sharding == "chromosomes"
                                else "equal stretches of the concatenated genome, pieces with a half-window halo",
                    "signal": "read-depth-like x U(0.5,1.5), seed %d" % SEED},
         "roofline": roofline(args.mode, dev_ms),
@@ -289,6 +305,12 @@ def other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_base
     """BASELINE configs[2..4] in the bench harness: same signal, same timing discipline."""
     S = stream.handle
     tmp = {i: gd.DeviceVector(lengths[i]) for i in mine}
+    batch = args.launch == "batch"
+    n_mine = len(mine)
+    io_in_out = gd.batch_items([vin[i] for i in mine], [vout[i] for i in mine])
+    io_in_tmp = gd.batch_items([vin[i] for i in mine], [tmp[i] for i in mine])
+    io_out_tmp = gd.batch_items([vout[i] for i in mine], [tmp[i] for i in mine])
+    io_tmp = gd.batch_items(None, [tmp[i] for i in mine])
     # index outputs follow strict comparisons of the smoothed values: direct taps only (hann -> fma)
     mode = gd.FIR_EXACT if args.mode == "exact" else gd.FIR_FMA
     extra = {}
@@ -296,6 +318,13 @@ def other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_base
         name, bytes_per_base = "smooth W=101 = localmax N=11", 32
 
         def step(_):
+            if batch and args.nofuse:
+                gd.call("gdsp_smooth_batch", io_in_out, n_mine, WINDOW, mode, S)
+                gd.call("gdsp_local_extrema_batch", io_out_tmp, n_mine, 11, 1, 0.0, S)
+                return
+            if batch:
+                gd.call("gdsp_smooth_local_extrema_batch", io_in_tmp, n_mine, WINDOW, mode, 11, 1, 0.0, S)
+                return
             for i in mine:
                 if args.nofuse:
                     gd.smooth(vin[i], WINDOW, out=vout[i], mode=mode, stream=lane_of[i].handle)
@@ -307,6 +336,15 @@ def other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_base
         left, right = gd.split_length(1001)
 
         def step(_):
+            if batch and args.nofuse:
+                gd.call("gdsp_dilate_batch", io_in_out, n_mine, left, right, 0.0, 1.0, 0.0, S)
+                gd.call("gdsp_erode_batch", io_out_tmp, n_mine, left, right, 0.0, 1.0, 0.0, S)
+                gd.call("gdsp_binarize_batch", io_tmp, n_mine, 0.0, 0, 1.0, 0.0, S)
+                return
+            if batch:
+                gd.call("gdsp_dilate_erode_batch", io_in_tmp, n_mine, left, right, 0.0, 1.0, 0.0, left, right, 0.0, 1.0, 0.0,
+                        1, 0.0, 0, 1.0, 0.0, S)
+                return
             for i in mine:
                 if args.nofuse:
                     gd.dilate(vin[i], left, right, out=vout[i], stream=lane_of[i].handle)
@@ -350,6 +388,9 @@ def other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_base
             st = gd.percentile_stats()
             extra["percentile_route"] = {gd.SELECT_RADIX: "radix", gd.SELECT_BRACKET: "bracket"}.get(st["route"])
             extra["percentile_stats"] = st
+            if batch:
+                gd.call("gdsp_binarize_batch", io_tmp, n_mine, float(vals[0]), 0, 1.0, 0.0, S)
+                return
             for i in mine:
                 gd.binarize(tmp[i], vals[0], stream=lane_of[i].handle)
     wall_ms, dev_ms = timed_fn(None, args.steps, args.warmup, step=step)
@@ -362,6 +403,8 @@ def other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_base
         kernels = [k.replace("FMA", "false" if args.mode == "exact" else "true") for k in kernels]
         if args.mode == "exact" and not args.nofuse and os.environ.get("GDSP_PEAKS_FILTER") == "1":
             kernels = ["hann_extrema_kernel<101, false, true, 5>"]     # opt-in: block sums as a filter, tap-by-tap only where needed
+    if batch:
+        kernels = [k if k.startswith(("pc_", "hann_extrema")) else batch_name(k) for k in kernels]
     result = {"metric": "Gbases/sec on %s over 3.1 Gbp" % name, "value": round(total_bases / (wall_ms * 1e-3) / 1e9, 2),
               "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
               "ms_per_step": round(wall_ms, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -371,10 +414,12 @@ def other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_base
                          "library": gd.lib().gdsp_version().decode(),
                          "collectives": (None if dist is None else "gloo, host copy (one-GPU rehearsal)" if reduce_device == "cpu"
                                          else "rccl (torch.distributed nccl backend), device words"),
-                         "streams": args.streams, "sharding": "whole chromosomes, LPT over ranks"},
+                         "streams": args.streams, "launch": "one launch per operator covers every chromosome of the rank" if batch
+                                    else "one launch per operator and chromosome",
+                         "sharding": "whole chromosomes, LPT over ranks"},
               "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(achieved / HBM_PEAK_GBS, 4),
-                           "traffic": measured_traffic(kernels[0], moved_per_base * bases_rank / max(1, len(mine))),
+                           "traffic": measured_traffic(kernels[0], moved_per_base * bases_rank / (1 if batch else max(1, len(mine)))),
                            "traffic_measured": traffic_source(kernels[0]),
                            "kernels": kernels,
                            "hbm_bytes_per_base_moved": moved_per_base,

@@ -661,6 +661,86 @@ def report_runs(v, collapse=True, uncovered=0, stream=None):
             x.download(np.float64, n, stream=stream))
 
 
+# ------------------------- one launch per operator per device (gdsp_*_batch) ------
+
+class BatchItem(C.Structure):
+    _fields_ = [("d_in", C.c_void_p), ("d_out", C.c_void_p), ("n", C.c_uint32)]
+
+
+def batch_items(ins, outs):
+    """Table for the gdsp_*_batch calls: vector i is read from ins[i] and written to outs[i] (in-place operators use
+    outs only; pass ins=None)."""
+    items = (BatchItem * max(len(outs), 1))()
+    for i, o in enumerate(outs):
+        items[i].d_in = ins[i].ptr.value if ins is not None else None
+        items[i].d_out = o.ptr.value
+        items[i].n = o.n
+    return items
+
+
+def _batch(name, vecs, outs, *params, stream=None, in_place=False):
+    outs = outs if outs is not None else ([v for v in vecs] if in_place else [v.like() for v in vecs])
+    items = batch_items(None if in_place else vecs, outs)
+    call(name, items, len(outs), *params, _sp(stream))
+    return outs
+
+
+def smooth_batch(vecs, W=101, outs=None, mode=FIR_EXACT, stream=None):
+    return _batch("gdsp_smooth_batch", vecs, outs, int(W), int(mode), stream=stream)
+
+
+def smooth_local_extrema_batch(vecs, W, N, want_max, fill, outs=None, mode=FIR_EXACT, stream=None):
+    return _batch("gdsp_smooth_local_extrema_batch", vecs, outs, int(W), int(mode), int(N), int(want_max), float(fill),
+                  stream=stream)
+
+
+def local_extrema_batch(vecs, N, want_max, fill, outs=None, stream=None):
+    return _batch("gdsp_local_extrema_batch", vecs, outs, int(N), int(want_max), float(fill), stream=stream)
+
+
+def best_extrema_batch(vecs, W, want_max, outs=None, stream=None):
+    return _batch("gdsp_best_extrema_batch", vecs, outs, int(W), int(want_max), stream=stream)
+
+
+def dilate_batch(vecs, left, right, T=0.0, one=1.0, zero=0.0, outs=None, stream=None):
+    return _batch("gdsp_dilate_batch", vecs, outs, left, right, float(T), float(one), float(zero), stream=stream)
+
+
+def erode_batch(vecs, left, right, T=0.0, one=1.0, zero=0.0, outs=None, stream=None):
+    return _batch("gdsp_erode_batch", vecs, outs, left, right, float(T), float(one), float(zero), stream=stream)
+
+
+def dilate_erode_batch(vecs, d_left, d_right, e_left, e_right, d_T=0.0, d_one=1.0, d_zero=0.0, e_T=0.0, e_one=1.0,
+                       e_zero=0.0, binarize=None, outs=None, stream=None):
+    b = binarize if binarize is not None else (0.0, False, 1.0, 0.0)
+    return _batch("gdsp_dilate_erode_batch", vecs, outs, d_left, d_right, float(d_T), float(d_one), float(d_zero),
+                  e_left, e_right, float(e_T), float(e_one), float(e_zero), int(binarize is not None),
+                  float(b[0]), int(b[1]), float(b[2]), float(b[3]), stream=stream)
+
+
+def binarize_batch(vecs, T=0.0, ties_above=False, one=1.0, zero=0.0, stream=None):
+    return _batch("gdsp_binarize_batch", vecs, None, float(T), int(ties_above), float(one), float(zero), stream=stream,
+                  in_place=True)
+
+
+def clip_batch(vecs, lo=None, hi=None, stream=None):
+    return _batch("gdsp_clip_batch", vecs, None, int(lo is not None), float(lo or 0.0), int(hi is not None), float(hi or 0.0),
+                  stream=stream, in_place=True)
+
+
+def erase_batch(vecs, lo=None, hi=None, keep_inside=False, zero=0.0, stream=None):
+    return _batch("gdsp_erase_batch", vecs, None, int(lo is not None), float(lo or 0.0), int(hi is not None), float(hi or 0.0),
+                  int(keep_inside), float(zero), stream=stream, in_place=True)
+
+
+def add_constant_batch(vecs, c, stream=None):
+    return _batch("gdsp_add_constant_batch", vecs, None, float(c), stream=stream, in_place=True)
+
+
+def abs_batch(vecs, stream=None):
+    return _batch("gdsp_abs_batch", vecs, None, stream=stream, in_place=True)
+
+
 def synth_coverage(seed, chrom_index, start, count, mode=0, out=None, stream=None):
     out = out if out is not None else DeviceVector(count)
     call("gdsp_synth_coverage", out.ptr, C.c_uint64(seed), chrom_index, start, count, mode, _sp(stream))

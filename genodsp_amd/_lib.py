@@ -75,6 +75,7 @@ SIGNATURES = {
     "gdsp_erode": (_int, [_vp, _vp, _u32, _u32, _u32, _f64, _f64, _f64, _vp]),
     "gdsp_dilate_erode": (_int, [_vp, _vp, _u32, _u32, _u32, _f64, _f64, _f64, _u32, _u32, _f64, _f64, _f64,
                                  _int, _f64, _int, _f64, _f64, _vp]),
+    "gdsp_dilate_erode_fusable": (_int, [_u32, _u32, _u32, _u32]),
     "gdsp_close": (_int, [_vp, _vp, _u32, _f64, _f64, _f64, _f64, _vp]),
     "gdsp_open": (_int, [_vp, _vp, _u32, _f64, _f64, _f64, _f64, _vp]),
     "gdsp_dilate_any": (_int, [_vp, _vp, _u32, _u32, _u32, _f64, _f64, _f64, _vp, _sz, _vp]),
@@ -119,10 +120,24 @@ SIGNATURES = {
     "gdsp_report_runs_work": (_sz, [_u32]),
     "gdsp_report_runs": (_int, [_vp, _u32, _int, _int, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
     "gdsp_synth_coverage": (_int, [_vp, _u64, _u32, _u32, _u32, _int, _vp]),
+    # one launch per operator per device: (items, nitems, <the single-vector call's parameters>, stream)
+    "gdsp_smooth_batch": (_int, [_vp, _int, _u32, _int, _vp]),
+    "gdsp_smooth_local_extrema_batch": (_int, [_vp, _int, _u32, _int, _u32, _int, _f64, _vp]),
+    "gdsp_local_extrema_batch": (_int, [_vp, _int, _u32, _int, _f64, _vp]),
+    "gdsp_best_extrema_batch": (_int, [_vp, _int, _u32, _int, _vp]),
+    "gdsp_dilate_batch": (_int, [_vp, _int, _u32, _u32, _f64, _f64, _f64, _vp]),
+    "gdsp_erode_batch": (_int, [_vp, _int, _u32, _u32, _f64, _f64, _f64, _vp]),
+    "gdsp_dilate_erode_batch": (_int, [_vp, _int, _u32, _u32, _f64, _f64, _f64, _u32, _u32, _f64, _f64, _f64,
+                                       _int, _f64, _int, _f64, _f64, _vp]),
+    "gdsp_binarize_batch": (_int, [_vp, _int, _f64, _int, _f64, _f64, _vp]),
+    "gdsp_clip_batch": (_int, [_vp, _int, _int, _f64, _int, _f64, _vp]),
+    "gdsp_erase_batch": (_int, [_vp, _int, _int, _f64, _int, _f64, _int, _f64, _vp]),
+    "gdsp_add_constant_batch": (_int, [_vp, _int, _f64, _vp]),
+    "gdsp_abs_batch": (_int, [_vp, _int, _vp]),
 }
 
 # functions whose int return is a status code
-_STATUS = {k for k, (r, _) in SIGNATURES.items() if r is _int} - {"gdsp_smooth_local_extrema_fusable", "gdsp_comm_size",
+_STATUS = {k for k, (r, _) in SIGNATURES.items() if r is _int} - {"gdsp_smooth_local_extrema_fusable", "gdsp_dilate_erode_fusable", "gdsp_comm_size",
                                                                   "gdsp_comm_device"}
 
 

@@ -53,6 +53,9 @@ bool gdsp_morph_blocks_available (uint32_t left, uint32_t right);
 void gdsp_morph_blocks (const double* d_in, double* d_out, uint32_t n, uint32_t left, uint32_t right, int erode,
                         double T, double one, double zero, void* stream);
 
+bool gdsp_morph_blocks_batch (const gdsp_batch_item* items, int nitems, uint32_t left, uint32_t right, int erode,
+                              double T, double one, double zero, void* stream);      // false: some vector needs another kernel
+
 static inline hipStream_t gdsp_stream (void* s) { return (hipStream_t) s; }
 
 __host__ __device__ static inline bool gdsp_aligned16 (const void* p) { return (((uintptr_t) p) & 15) == 0; }

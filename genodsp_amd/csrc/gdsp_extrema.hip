@@ -216,9 +216,9 @@ __device__ __forceinline__ double exb_staged (double x, int64_t g, double T)
 	}
 
 template <bool MAX, bool LOCAL, int G, int SET>
-__global__ __launch_bounds__(EXB_THREADS)
-void extrema_blocks_kernel (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t ntiles,
-                            int rgt, int dq, int dr, int level, int sh, double fill, ExbSet set)
+__device__ __forceinline__
+void extrema_blocks_tile (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t tile,
+                          int rgt, int dq, int dr, int level, int sh, double fill, const ExbSet& set)
 	{
 	constexpr int PITCH = G + 1;
 	constexpr int ELEMS = EXB_THREADS * G;
@@ -231,7 +231,6 @@ void extrema_blocks_kernel (const double* __restrict__ in, double* __restrict__ 
 	const int    outs  = (EXB_THREADS - haloL) * G - 2*sh;    // outputs stored per tile (even)
 	const int    nt    = dq - 1;                              // whole blocks always between
 	const int    lead  = haloL * G - rgt + sh;                // staged elements before output 0 of the tile (even)
-	const uint32_t tile = gdsp_xcd_tile (blockIdx.x, ntiles);
 	const int64_t  out0 = (int64_t) tile * outs;
 	const int64_t  e0   = out0 - lead;
 	const int      p    = threadIdx.x;
@@ -342,6 +341,40 @@ void extrema_blocks_kernel (const double* __restrict__ in, double* __restrict__ 
 		}
 	}
 
+template <bool MAX, bool LOCAL, int G, int SET>
+__global__ __launch_bounds__(EXB_THREADS)
+void extrema_blocks_kernel (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t ntiles,
+                            int rgt, int dq, int dr, int level, int sh, double fill, ExbSet set)
+	{ extrema_blocks_tile<MAX, LOCAL, G, SET> (in, out, n, gdsp_xcd_tile (blockIdx.x, ntiles), rgt, dq, dr, level, sh, fill, set); }
+
+template <bool MAX, bool LOCAL, int G, int SET>                   // one grid over every vector of the table (gdsp_common.h)
+__global__ __launch_bounds__(EXB_THREADS)
+void extrema_blocks_batch_kernel (GdspBatch B, int rgt, int dq, int dr, int level, int sh, double fill, ExbSet set)
+	{
+	const double* in;  double* out;  uint32_t n;
+	const uint32_t tile = gdsp_batch_tile (B, in, out, n);
+	extrema_blocks_tile<MAX, LOCAL, G, SET> (in, out, n, tile, rgt, dq, dr, level, sh, fill, set);
+	}
+
+template <bool MAX, bool LOCAL, int G, int SET = EXB_VALUES>
+static void extrema_blocks_batch_launch (const gdsp_batch_item* items, int nitems, uint32_t lft, uint32_t rgt, double fill,
+                                         hipStream_t s, ExbSet set = ExbSet ())
+	{
+	const int d  = (int) (lft + rgt);
+	const int dq = d / G, dr = d % G;
+	const int nt = dq - 1;
+	int level = 0;
+	while ((2 << level) <= nt) level++;
+	const int sh   = ((dq + 1) * G - (int) rgt) & 1;
+	const int outs = (EXB_THREADS - (dq + 1)) * G - 2*sh;
+	gdsp_batch_run (items, nitems, [=] (uint32_t n) { return ((uint64_t) n + outs - 1) / outs; },
+		[&] (const GdspBatch& B, uint32_t tiles)
+			{
+			hipLaunchKernelGGL ((extrema_blocks_batch_kernel<MAX, LOCAL, G, SET>), dim3(tiles), dim3(EXB_THREADS), 0, s,
+			                    B, (int) rgt, dq, dr, level, sh, fill, set);
+			});
+	}
+
 template <bool MAX, bool LOCAL, int G, int SET = EXB_VALUES>
 static void extrema_blocks_launch (const double* d_in, double* d_out, uint32_t n, uint32_t lft, uint32_t rgt, double fill,
                                    hipStream_t s, ExbSet set = ExbSet ())
@@ -427,7 +460,60 @@ static int extrema_launch (const double* d_in, double* d_out, uint32_t n, uint32
 	return GDSP_OK;
 	}
 
+// every vector of a device in one launch where the block form applies to all of them; vector by vector otherwise
+template <bool MAX, bool LOCAL>
+static int extrema_batch (const gdsp_batch_item* items, int nitems, uint32_t lft, uint32_t rgt, double fill, void* stream)
+	{
+	int rc = gdsp_batch_check (items, nitems, false);
+	if (rc != GDSP_OK) return rc;
+	const uint64_t span = (uint64_t) lft + rgt + 1;
+	bool blocks = (span >= EXB_MIN_SPAN) && (span <= EXB_MAX_SPAN);
+	for (int i=0 ; i<nitems ; i++)
+		{ if ((items[i].n != 0) && ((items[i].n < lft) || (items[i].n < rgt))) blocks = false; }   // (the single form clamps the window to the vector)
+	if (!blocks)
+		{
+		for (int i=0 ; i<nitems ; i++)
+			{ rc = extrema_launch<MAX, LOCAL> (items[i].d_in, items[i].d_out, items[i].n, lft, rgt, fill, stream);  if (rc != GDSP_OK) return rc; }
+		return GDSP_OK;
+		}
+	hipStream_t s = gdsp_stream (stream);
+	if      (span >= 17) extrema_blocks_batch_launch<MAX, LOCAL, 16> (items, nitems, lft, rgt, fill, s);
+	else if (span >= 9)  extrema_blocks_batch_launch<MAX, LOCAL, 8>  (items, nitems, lft, rgt, fill, s);
+	else                 extrema_blocks_batch_launch<MAX, LOCAL, 4>  (items, nitems, lft, rgt, fill, s);
+	GDSP_LAUNCH_CHECK ();
+	return GDSP_OK;
+	}
+
+// dilate / erode over a batch in the block form; false when some vector needs another kernel
+bool gdsp_morph_blocks_batch (const gdsp_batch_item* items, int nitems, uint32_t left, uint32_t right, int erode,
+                              double T, double one, double zero, void* stream)
+	{
+	if (!gdsp_morph_blocks_available (left, right)) return false;
+	for (int i=0 ; i<nitems ; i++)
+		{ if ((items[i].n != 0) && ((items[i].n < left) || (items[i].n < right))) return false; }
+	ExbSet set = { T, one, zero };
+	if (erode) extrema_blocks_batch_launch<false, false, 16, EXB_ERODE>  (items, nitems, right, left, 0.0, gdsp_stream (stream), set);
+	else       extrema_blocks_batch_launch<true,  false, 16, EXB_DILATE> (items, nitems, right, left, 0.0, gdsp_stream (stream), set);
+	return true;
+	}
+
 extern "C" {
+
+int gdsp_local_extrema_batch (const gdsp_batch_item* items, int nitems, uint32_t N, int wantMax, double fill, void* stream)
+	{
+	GDSP_REQUIRE (N >= 1, "neighborhood must be >= 1");
+	const uint32_t hOff = (N - 1) / 2;
+	if (wantMax) return extrema_batch<true,  true> (items, nitems, hOff, hOff, fill, stream);
+	return              extrema_batch<false, true> (items, nitems, hOff, hOff, fill, stream);
+	}
+
+int gdsp_best_extrema_batch (const gdsp_batch_item* items, int nitems, uint32_t W, int wantMax, void* stream)
+	{
+	GDSP_REQUIRE (W >= 1, "window must be >= 1");
+	const uint32_t lft = (W - 1) / 2, rgt = (W - 1) - lft;
+	if (wantMax) return extrema_batch<true,  false> (items, nitems, lft, rgt, 0.0, stream);
+	return              extrema_batch<false, false> (items, nitems, lft, rgt, 0.0, stream);
+	}
 
 int gdsp_local_extrema (const double* d_in, double* d_out, uint32_t n, uint32_t N,
                         int wantMax, double fill, void* stream)

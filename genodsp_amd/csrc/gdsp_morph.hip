@@ -273,10 +273,10 @@ void morph_kernel (const double* __restrict__ in, double* __restrict__ out, uint
 // to running them one after the other.
 //   dMemberOne / dMemberZero: whether dilate's `one` / `zero` output value counts as "in" for
 //   erode's own threshold; vOne / vZero: erode's outputs already passed through binarize.
-__global__ __launch_bounds__(MO_THREADS)
-void morph_dilate_erode_kernel (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t ntiles,
-                                int tile, int haloL, int nwords, int dLeft, int dRight, int eLeft, int eRight,
-                                double T, int dMemberOne, int dMemberZero, double vOne, double vZero)
+__device__ __forceinline__
+void morph_dilate_erode_tile (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t t,
+                              int tile, int haloL, int nwords, int dLeft, int dRight, int eLeft, int eRight,
+                              double T, int dMemberOne, int dMemberZero, double vOne, double vZero)
 	{
 	extern __shared__ __attribute__((aligned(16))) uint64_t moLds[];
 	uint64_t* mask     = moLds;                                    // nwords: S, the input set
@@ -285,7 +285,6 @@ void morph_dilate_erode_kernel (const double* __restrict__ in, double* __restric
 	int*      prevTo   = nextFrom + nwords + 1;                    // nwords
 	__shared__ int scanA[MO_THREADS], scanB[MO_THREADS];
 
-	const uint32_t t         = gdsp_xcd_tile (blockIdx.x, ntiles);
 	const int64_t  tileStart = (int64_t) t * tile;
 	const int64_t  g0        = tileStart - haloL;
 	const int      lane      = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -323,6 +322,24 @@ void morph_dilate_erode_kernel (const double* __restrict__ in, double* __restric
 		if (g + 1 < (int64_t) n) gdsp_st2 (reinterpret_cast<double2*> (out + g), make_double2 (k0? vOne : vZero, k1? vOne : vZero));
 		else                     out[g] = k0? vOne : vZero;
 		}
+	}
+
+__global__ __launch_bounds__(MO_THREADS)
+void morph_dilate_erode_kernel (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t ntiles,
+                                int tile, int haloL, int nwords, int dLeft, int dRight, int eLeft, int eRight,
+                                double T, int dMemberOne, int dMemberZero, double vOne, double vZero)
+	{
+	morph_dilate_erode_tile (in, out, n, gdsp_xcd_tile (blockIdx.x, ntiles), tile, haloL, nwords, dLeft, dRight, eLeft, eRight,
+	                         T, dMemberOne, dMemberZero, vOne, vZero);
+	}
+
+__global__ __launch_bounds__(MO_THREADS)                          // one grid over every vector of the table (gdsp_common.h)
+void morph_dilate_erode_batch_kernel (GdspBatch B, int tile, int haloL, int nwords, int dLeft, int dRight, int eLeft, int eRight,
+                                      double T, int dMemberOne, int dMemberZero, double vOne, double vZero)
+	{
+	const double* in;  double* out;  uint32_t n;
+	const uint32_t t = gdsp_batch_tile (B, in, out, n);
+	morph_dilate_erode_tile (in, out, n, t, tile, haloL, nwords, dLeft, dRight, eLeft, eRight, T, dMemberOne, dMemberZero, vOne, vZero);
 	}
 
 // ------------------------------------------------------------ any reach: the set as bits in HBM ----
@@ -600,6 +617,19 @@ static int morph_any (const double* d_in, double* d_out, uint32_t n, uint64_t le
 	return GDSP_OK;
 	}
 
+// GDSP_MORPH_TILE=<bases>: tile size for tuning experiments; read once, values a tile cannot have are ignored
+static uint64_t mo_tile_override (void)
+	{
+	static const uint64_t value = [] () -> uint64_t
+		{
+		const char* e = getenv ("GDSP_MORPH_TILE");
+		if (e == NULL) return 0;
+		const long long v = atoll (e);
+		return ((v >= 512) && (v <= MO_MAX_STAGE))? (uint64_t) v : 0;
+		} ();
+	return value;
+	}
+
 template <int OP>
 static int morph_launch (const double* d_in, double* d_out, uint32_t n, uint64_t left, uint64_t right,
                          double length, double T, double one, double zero, void* stream)
@@ -642,7 +672,7 @@ static int morph_launch (const double* d_in, double* d_out, uint32_t n, uint64_t
 		}
 	uint64_t tile = 4 * (haloL + haloR);
 	if (tile < MO_MIN_TILE) tile = MO_MIN_TILE;
-	if (getenv ("GDSP_MORPH_TILE") != NULL) tile = (uint64_t) atoll (getenv ("GDSP_MORPH_TILE"));   // (tuning experiments)
+	if (mo_tile_override () != 0) tile = mo_tile_override ();          // (tuning experiments)
 	if (tile + haloL + haloR > MO_MAX_STAGE) tile = MO_MAX_STAGE - haloL - haloR;
 	tile = (tile / 512) * 512;
 	const int      nwords = (int) ((haloL + tile + haloR) / 64);
@@ -666,20 +696,39 @@ int gdsp_erode (const double* d_in, double* d_out, uint32_t n, uint32_t left, ui
                 double T, double one, double zero, void* stream)
 	{ return morph_launch<MO_ERODE> (d_in, d_out, n, left, right, 0.0, T, one, zero, stream); }
 
+/* every vector of a device in one launch when the block form of gdsp_extrema.hip serves them all (windows of 17..3584
+ * bases); vector by vector otherwise */
+int gdsp_dilate_batch (const gdsp_batch_item* items, int nitems, uint32_t left, uint32_t right,
+                       double T, double one, double zero, void* stream)
+	{
+	int rc = gdsp_batch_check (items, nitems, false);
+	if (rc != GDSP_OK) return rc;
+	if (gdsp_morph_blocks_batch (items, nitems, left, right, 0, T, one, zero, stream)) { GDSP_LAUNCH_CHECK ();  return GDSP_OK; }
+	for (int i=0 ; i<nitems ; i++)
+		{ rc = gdsp_dilate (items[i].d_in, items[i].d_out, items[i].n, left, right, T, one, zero, stream);  if (rc != GDSP_OK) return rc; }
+	return GDSP_OK;
+	}
+
+int gdsp_erode_batch (const gdsp_batch_item* items, int nitems, uint32_t left, uint32_t right,
+                      double T, double one, double zero, void* stream)
+	{
+	int rc = gdsp_batch_check (items, nitems, false);
+	if (rc != GDSP_OK) return rc;
+	if (gdsp_morph_blocks_batch (items, nitems, left, right, 1, T, one, zero, stream)) { GDSP_LAUNCH_CHECK ();  return GDSP_OK; }
+	for (int i=0 ; i<nitems ; i++)
+		{ rc = gdsp_erode (items[i].d_in, items[i].d_out, items[i].n, left, right, T, one, zero, stream);  if (rc != GDSP_OK) return rc; }
+	return GDSP_OK;
+	}
+
 /* `= dilate = erode [= binarize]` fused (see morph_dilate_erode_kernel).  Each stage keeps its
  * own threshold and output values, exactly as the three operators would apply them. */
-int gdsp_dilate_erode (const double* d_in, double* d_out, uint32_t n,
-                       uint32_t dLeft, uint32_t dRight, double dT, double dOne, double dZero,
-                       uint32_t eLeft, uint32_t eRight, double eT, double eOne, double eZero,
-                       int binarize, double bT, int bTiesAbove, double bOne, double bZero, void* stream)
+struct MoFusedGeom { int tile, haloL, nwords;  size_t bytes;  uint32_t dLeft, dRight, eLeft, eRight; };
+static int mo_fused_geom (uint32_t nmax, uint32_t dLeft, uint32_t dRight, uint32_t eLeft, uint32_t eRight, MoFusedGeom* g)
 	{
-	if (n == 0) return GDSP_OK;
-	GDSP_REQUIRE ((d_in != NULL) && (d_out != NULL) && (d_in != d_out), "vectors must be distinct and non-NULL");
-	GDSP_REQUIRE (gdsp_aligned16 (d_in) && gdsp_aligned16 (d_out), "vectors must be 16-byte aligned");
-	if (dLeft > n) dLeft = n;
-	if (dRight > n) dRight = n;
-	if (eLeft > n) eLeft = n;
-	if (eRight > n) eRight = n;
+	if (dLeft > nmax) dLeft = nmax;                                    // (nothing beyond the vector matters: keeps the arithmetic in int)
+	if (dRight > nmax) dRight = nmax;
+	if (eLeft > nmax) eLeft = nmax;
+	if (eRight > nmax) eRight = nmax;
 	const uint64_t reachL = (uint64_t) dRight + eRight, reachR = (uint64_t) dLeft + eLeft + 1;
 	const uint64_t haloL = ((reachL + 127) / 128) * 128, haloR = ((reachR + 127) / 128) * 128;
 	if (haloL + haloR + 512 > MO_MAX_STAGE/2)
@@ -690,12 +739,35 @@ int gdsp_dilate_erode (const double* d_in, double* d_out, uint32_t n,
 		}
 	uint64_t tile = 4 * (haloL + haloR);
 	if (tile < MO_MIN_TILE) tile = MO_MIN_TILE;
-	if (getenv ("GDSP_MORPH_TILE") != NULL) tile = (uint64_t) atoll (getenv ("GDSP_MORPH_TILE"));   // (tuning experiments)
+	if (mo_tile_override () != 0) tile = mo_tile_override ();          // (tuning experiments)
 	if (tile + haloL + haloR > MO_MAX_STAGE/2) tile = MO_MAX_STAGE/2 - haloL - haloR;
 	tile = (tile / 512) * 512;
-	const int      nwords = (int) ((haloL + tile + haloR) / 64);
-	const uint32_t ntiles = (uint32_t) (((uint64_t) n + tile - 1) / tile);
-	const size_t   bytes  = (size_t) nwords * 16 + ((size_t) 2*nwords + 2) * 4;
+	g->tile = (int) tile;  g->haloL = (int) haloL;  g->nwords = (int) ((haloL + tile + haloR) / 64);
+	g->bytes = (size_t) g->nwords * 16 + ((size_t) 2*g->nwords + 2) * 4;
+	g->dLeft = dLeft;  g->dRight = dRight;  g->eLeft = eLeft;  g->eRight = eRight;
+	return GDSP_OK;
+	}
+
+/* 1 when the chain has a fused kernel whatever the vectors' lengths (the combined reach fits one LDS tile) */
+int gdsp_dilate_erode_fusable (uint32_t dLeft, uint32_t dRight, uint32_t eLeft, uint32_t eRight)
+	{
+	const uint64_t reachL = (uint64_t) dRight + eRight, reachR = (uint64_t) dLeft + eLeft + 1;
+	const uint64_t haloL = ((reachL + 127) / 128) * 128, haloR = ((reachR + 127) / 128) * 128;
+	return haloL + haloR + 512 <= MO_MAX_STAGE/2;
+	}
+
+int gdsp_dilate_erode (const double* d_in, double* d_out, uint32_t n,
+                       uint32_t dLeft, uint32_t dRight, double dT, double dOne, double dZero,
+                       uint32_t eLeft, uint32_t eRight, double eT, double eOne, double eZero,
+                       int binarize, double bT, int bTiesAbove, double bOne, double bZero, void* stream)
+	{
+	if (n == 0) return GDSP_OK;
+	GDSP_REQUIRE ((d_in != NULL) && (d_out != NULL) && (d_in != d_out), "vectors must be distinct and non-NULL");
+	GDSP_REQUIRE (gdsp_aligned16 (d_in) && gdsp_aligned16 (d_out), "vectors must be 16-byte aligned");
+	MoFusedGeom g;
+	int rc = mo_fused_geom (n, dLeft, dRight, eLeft, eRight, &g);
+	if (rc != GDSP_OK) return rc;
+	const uint32_t ntiles = (uint32_t) (((uint64_t) n + g.tile - 1) / g.tile);
 
 	double vOne = eOne, vZero = eZero;
 	if (binarize)
@@ -703,10 +775,43 @@ int gdsp_dilate_erode (const double* d_in, double* d_out, uint32_t n,
 		vOne  = (bTiesAbove? (eOne  >= bT) : (eOne  > bT))? bOne : bZero;     // logical.c:247-257
 		vZero = (bTiesAbove? (eZero >= bT) : (eZero > bT))? bOne : bZero;
 		}
-	hipLaunchKernelGGL (morph_dilate_erode_kernel, dim3(ntiles), dim3(MO_THREADS), bytes, gdsp_stream (stream),
-	                    d_in, d_out, n, ntiles, (int) tile, (int) haloL, nwords,
-	                    (int) dLeft, (int) dRight, (int) eLeft, (int) eRight,
+	hipLaunchKernelGGL (morph_dilate_erode_kernel, dim3(ntiles), dim3(MO_THREADS), g.bytes, gdsp_stream (stream),
+	                    d_in, d_out, n, ntiles, g.tile, g.haloL, g.nwords,
+	                    (int) g.dLeft, (int) g.dRight, (int) g.eLeft, (int) g.eRight,
 	                    dT, (int) (dOne > eT), (int) (dZero > eT), vOne, vZero);       // erode membership: v > T
+	GDSP_LAUNCH_CHECK ();
+	return GDSP_OK;
+	}
+
+/* the same for every vector of a device in one launch (gdsp_common.h: GdspBatch) */
+int gdsp_dilate_erode_batch (const gdsp_batch_item* items, int nitems,
+                             uint32_t dLeft, uint32_t dRight, double dT, double dOne, double dZero,
+                             uint32_t eLeft, uint32_t eRight, double eT, double eOne, double eZero,
+                             int binarize, double bT, int bTiesAbove, double bOne, double bZero, void* stream)
+	{
+	int rc = gdsp_batch_check (items, nitems, false);
+	if (rc != GDSP_OK) return rc;
+	uint32_t nmax = 0;
+	for (int i=0 ; i<nitems ; i++) { if (items[i].n > nmax) nmax = items[i].n; }
+	if (nmax == 0) return GDSP_OK;
+	MoFusedGeom g;
+	rc = mo_fused_geom (nmax, dLeft, dRight, eLeft, eRight, &g);
+	if (rc != GDSP_OK) return rc;
+	double vOne = eOne, vZero = eZero;
+	if (binarize)
+		{
+		vOne  = (bTiesAbove? (eOne  >= bT) : (eOne  > bT))? bOne : bZero;
+		vZero = (bTiesAbove? (eZero >= bT) : (eZero > bT))? bOne : bZero;
+		}
+	hipStream_t s = gdsp_stream (stream);
+	const int tile = g.tile;
+	gdsp_batch_run (items, nitems, [=] (uint32_t n) { return ((uint64_t) n + tile - 1) / tile; },
+		[&] (const GdspBatch& B, uint32_t tiles)
+			{
+			hipLaunchKernelGGL (morph_dilate_erode_batch_kernel, dim3(tiles), dim3(MO_THREADS), g.bytes, s,
+			                    B, g.tile, g.haloL, g.nwords, (int) g.dLeft, (int) g.dRight, (int) g.eLeft, (int) g.eRight,
+			                    dT, (int) (dOne > eT), (int) (dZero > eT), vOne, vZero);
+			});
 	GDSP_LAUNCH_CHECK ();
 	return GDSP_OK;
 	}

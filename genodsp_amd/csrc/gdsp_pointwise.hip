@@ -19,10 +19,8 @@
 // (gdsp_xcd_tile).  Measured on MI355X this streams ~25 % faster than a grid-stride loop over
 // the same vector (profiles/r01_ops_throughput.txt).
 template <class F>
-__global__ __launch_bounds__(PW_THREADS)
-void pointwise_kernel (double* __restrict__ v, uint32_t n, uint32_t ntiles, F f)
+__device__ __forceinline__ void pointwise_tile (double* __restrict__ v, uint32_t n, uint32_t tile, const F& f)
 	{
-	const uint32_t tile = gdsp_xcd_tile (blockIdx.x, ntiles);
 	const size_t   base = (size_t) tile * PW_TILE;
 	if (base + PW_TILE <= (size_t) n)
 		{
@@ -39,6 +37,33 @@ void pointwise_kernel (double* __restrict__ v, uint32_t n, uint32_t ntiles, F f)
 		{
 		for (size_t i = base + threadIdx.x ; i < (size_t) n ; i += PW_THREADS) v[i] = f (v[i]);
 		}
+	}
+
+template <class F>
+__global__ __launch_bounds__(PW_THREADS)
+void pointwise_kernel (double* __restrict__ v, uint32_t n, uint32_t ntiles, F f)
+	{ pointwise_tile (v, n, gdsp_xcd_tile (blockIdx.x, ntiles), f); }
+
+template <class F>                                    // one grid over every vector of the table (gdsp_common.h), in place on B.out
+__global__ __launch_bounds__(PW_THREADS)
+void pointwise_batch_kernel (GdspBatch B, F f)
+	{
+	const double* in;  double* v;  uint32_t n;
+	const uint32_t tile = gdsp_batch_tile (B, in, v, n);
+	pointwise_tile (v, n, tile, f);
+	}
+
+template <class F>
+static int pointwise_batch_launch (const gdsp_batch_item* items, int nitems, F f, void* stream)
+	{
+	int rc = gdsp_batch_check (items, nitems, true);
+	if (rc != GDSP_OK) return rc;
+	hipStream_t s = gdsp_stream (stream);
+	gdsp_batch_run (items, nitems, [] (uint32_t n) { return ((uint64_t) n + PW_TILE - 1) / PW_TILE; },
+		[&] (const GdspBatch& B, uint32_t tiles)
+			{ hipLaunchKernelGGL ((pointwise_batch_kernel<F>), dim3(tiles), dim3(PW_THREADS), 0, s, B, f); });
+	GDSP_LAUNCH_CHECK ();
+	return GDSP_OK;
 	}
 
 template <class F>
@@ -285,6 +310,44 @@ int gdsp_binarize (double* d_v, uint32_t n, double T, int tiesAbove, double one,
 	if (tiesAbove) return pointwise_launch (d_v, n, BinarizeAbove {T, one, zero}, stream);
 	return pointwise_launch (d_v, n, BinarizeBelow {T, one, zero}, stream);
 	}
+
+int gdsp_binarize_batch (const gdsp_batch_item* items, int nitems, double T, int tiesAbove, double one, double zero, void* stream)
+	{
+	if (tiesAbove) return pointwise_batch_launch (items, nitems, BinarizeAbove {T, one, zero}, stream);
+	return pointwise_batch_launch (items, nitems, BinarizeBelow {T, one, zero}, stream);
+	}
+
+int gdsp_clip_batch (const gdsp_batch_item* items, int nitems, int haveMin, double minVal, int haveMax, double maxVal, void* stream)
+	{
+	GDSP_REQUIRE (haveMin || haveMax, "clip needs a minimum or a maximum");
+	if (!haveMax) return pointwise_batch_launch (items, nitems, ClipMin {minVal}, stream);
+	if (!haveMin) return pointwise_batch_launch (items, nitems, ClipMax {maxVal}, stream);
+	return pointwise_batch_launch (items, nitems, ClipBoth {minVal, maxVal}, stream);
+	}
+
+int gdsp_erase_batch (const gdsp_batch_item* items, int nitems, int haveMin, double minVal, int haveMax, double maxVal,
+                      int keepInside, double zero, void* stream)
+	{
+	GDSP_REQUIRE (haveMin || haveMax, "erase needs a minimum or a maximum");
+	if (keepInside)
+		{
+		if (!haveMax) return pointwise_batch_launch (items, nitems, Erase<0> {minVal, maxVal, zero}, stream);
+		if (!haveMin) return pointwise_batch_launch (items, nitems, Erase<1> {minVal, maxVal, zero}, stream);
+		return pointwise_batch_launch (items, nitems, Erase<2> {minVal, maxVal, zero}, stream);
+		}
+	if (!haveMax) return pointwise_batch_launch (items, nitems, Erase<3> {minVal, maxVal, zero}, stream);
+	if (!haveMin) return pointwise_batch_launch (items, nitems, Erase<4> {minVal, maxVal, zero}, stream);
+	return pointwise_batch_launch (items, nitems, Erase<5> {minVal, maxVal, zero}, stream);
+	}
+
+int gdsp_add_constant_batch (const gdsp_batch_item* items, int nitems, double c, void* stream)
+	{
+	if (c == 0.0) return GDSP_OK;                       // add.c:736
+	return pointwise_batch_launch (items, nitems, AddConst {c}, stream);
+	}
+
+int gdsp_abs_batch (const gdsp_batch_item* items, int nitems, void* stream)
+	{ return pointwise_batch_launch (items, nitems, AbsVal {}, stream); }
 
 int gdsp_clip (double* d_v, uint32_t n, int haveMin, double minVal, int haveMax, double maxVal, void* stream)
 	{

@@ -128,6 +128,7 @@ static int numDevices     = 1;
 int        firMode        = GDSP_FIR_EXACT;      /* --smooth=exact|fma|hann (see ops_sum.c) */
 int        selectStrategy = GDSP_SELECT_AUTO;    /* --percentile=auto|radix|bracket (see ops_percentile.c) */
 static int fuseChains     = true;                /* --nofuse: one kernel per operator          */
+static int batchLaunches  = true;                /* --nobatch: one launch per operator and chromosome, chromosome by chromosome */
 enum { reduce_auto, reduce_rccl, reduce_host };
 static int reduceHow      = reduce_auto;         /* --reduce=rccl|host: how whole-genome operators combine the devices */
 static gdsp_comm* deviceComm = NULL;             /* RCCL communicator over the devices in use (NULL: host sums)        */
@@ -213,6 +214,8 @@ static void usage (void)
 	"  --shards=show             print which device gets what (and the makespan efficiency) and stop\n"
 	"  --reduce=rccl|host        how percentile / invert combine the GPUs' counts: an RCCL all-reduce in\n"
 	"                            HBM (default with --gpus > 1) or sums on the host\n"
+	"  --nobatch                 apply operators chromosome by chromosome, one launch each, in the reference's order\n"
+	"                            (default: an operator covers all the chromosomes of a device in one launch)\n"
 	"  --nofuse                  run every operator as its own kernel (default: the chains\n"
 	"                            smooth=localmax|localmin and dilate=erode[=binarize] are fused)\n"
 	"  --smooth=exact|fma|hann   arithmetic of `smooth`: exact = bit-identical to genodsp\n"
@@ -444,6 +447,11 @@ void flip_vector (char* vName)
 	if (s == NULL) return;
 	valtype* t = s->valVector;  s->valVector = ((xspec*) s)->partner;  ((xspec*) s)->partner = t;
 	}
+
+valtype* partner_of (spec* s) { return ((xspec*) s)->partner; }
+
+void flip_spec (spec* s)
+	{ valtype* t = s->valVector;  s->valVector = ((xspec*) s)->partner;  ((xspec*) s)->partner = t; }
 
 valtype* get_scratch_vector (void)                        /* genodsp.c:1904-1940, on the current device */
 	{
@@ -1561,6 +1569,7 @@ static void parse_options (int _argc, char** _argv)            /* genodsp.c:284-
 			continue;
 			}
 		if (strcmp (arg, "--nofuse") == 0) { fuseChains = false;  continue; }
+		if (strcmp (arg, "--nobatch") == 0) { batchLaunches = false;  continue; }
 		if (strcmp (arg, "--shards=show") == 0)          { showShards = true;   continue; }
 		if (strcmp (arg, "--sharding=bases") == 0)       { shardBases = true;   continue; }
 		if (strcmp (arg, "--sharding=chromosomes") == 0) { shardBases = false;  continue; }
@@ -1629,6 +1638,25 @@ static void parse_options (int _argc, char** _argv)            /* genodsp.c:284-
 	if (chromsOfInterest == NULL) chastise ("gotta give me some chromosome names\n");
 	}
 
+/* what --progress=operations calls a unit of work: the chromosome, or chromosome:start-end for a stretch */
+static int runSharded = false;
+static const char* unit_label (spec* s)
+	{
+	static char where[200];
+	if (!runSharded) return s->chrom;
+	piece* p = (piece*) s;                                     /* (a stretch's spec is the first member of its piece) */
+	snprintf (where, sizeof(where), "%.100s:%u-%u", s->chrom, p->ownStart, p->ownEnd);
+	return where;
+	}
+
+void apply_to_unit (dspop* op, spec* s)
+	{
+	select_device_of (s);
+	activeSpec = runSharded? s : NULL;
+	(*op->funcApply) (op, s->chrom, s->length, s->valVector);
+	activeSpec = NULL;
+	}
+
 /* ----------------------------------------------------------------------- main */
 int main (int argc, char** argv)
 	{
@@ -1692,30 +1720,69 @@ int main (int argc, char** argv)
 			int nunits = 0;
 			if (sharded) { to_pieces ();  if ((reachL | reachR) != 0) refresh_halos ();  nunits = numPieces; }
 			else         { to_whole ();  while (chromsSorted[nunits] != NULL) nunits++; }
-			for (int i=0 ; i<nunits ; i++)
+			spec** units = (spec**) malloc ((nunits + 1) * sizeof(spec*));
+			if (units == NULL) { fprintf (stderr, "out of memory\n");  exit (EXIT_FAILURE); }
+			for (int i=0 ; i<nunits ; i++) units[i] = sharded? &pieces[i].x.pub : chromsSorted[i];
+			runSharded = sharded;
+			/* the run as stretches of operators: those with a one-launch-per-device form go operator by operator, each
+			 * covering all the units of a device at once; the others chromosome by chromosome as in genodsp.c:909-921
+			 * (chromosomes are independent for every operator of a run, so the order cannot matter) */
+			for (dspop* op=firstOp ; op!=stopOp ; )
 				{
-				spec* s = sharded? &pieces[i].x.pub : chromsSorted[i];
-				char  where[200];
-				if (sharded) snprintf (where, sizeof(where), "%.100s:%u-%u", s->chrom, pieces[i].ownStart, pieces[i].ownEnd);
-				else         snprintf (where, sizeof(where), "%.100s", s->chrom);
-				select_device_of (s);
-				activeSpec = sharded? s : NULL;
-				for (dspop* op=firstOp ; op!=stopOp ; op=op->next)
+				if (batchLaunches && op_batchable (op))
 					{
-					if (trackOperations) fprintf (stderr, "%s(%s)\n", op->name, where);
-					dspop* first = op;
-					u32 sp = reportGpu? span_open () : 0;
-					int fused = fuseChains? try_fused_apply (op, stopOp, s) : 0;
-					if (fused == 0) (*op->funcApply) (op, s->chrom, s->length, s->valVector);
-					if (reportGpu) span_close (sp, first, (fused == 0)? 1 : fused, s->length);
-					for ( ; fused > 1 ; fused--)           /* the chain ran as one kernel */
+					int consumed = 1;
+					for (int d=0 ; d<numDevices ; d++)
 						{
-						op = op->next;
-						if (trackOperations) fprintf (stderr, "%s(%s)\n", op->name, where);
+						int     m = 0;
+						u64     bases = 0;
+						spec**  mine = (spec**) malloc ((nunits + 1) * sizeof(spec*));
+						if (mine == NULL) { fprintf (stderr, "out of memory\n");  exit (EXIT_FAILURE); }
+						for (int i=0 ; i<nunits ; i++)
+							{ if (((xspec*) units[i])->device == d) { mine[m++] = units[i];  bases += units[i]->length; } }
+						if (m > 0)
+							{
+							select_device_of (mine[0]);
+							u32 sp = reportGpu? span_open () : 0;
+							consumed = batch_apply_on_device (op, stopOp, mine, m, fuseChains);
+							if (reportGpu) span_close (sp, op, consumed, bases);
+							}
+						free (mine);
 						}
+					for (int k=0 ; k<consumed ; k++, op=op->next)
+						{
+						if (!trackOperations) continue;
+						for (int i=0 ; i<nunits ; i++) fprintf (stderr, "%s(%s)\n", op->name, unit_label (units[i]));
+						}
+					continue;
 					}
-				activeSpec = NULL;
+				dspop* runEnd = op;
+				while ((runEnd != stopOp) && !(batchLaunches && op_batchable (runEnd))) runEnd = runEnd->next;
+				for (int i=0 ; i<nunits ; i++)
+					{
+					spec* s = units[i];
+					const char* where = unit_label (s);
+					select_device_of (s);
+					activeSpec = sharded? s : NULL;
+					for (dspop* o=op ; o!=runEnd ; o=o->next)
+						{
+						if (trackOperations) fprintf (stderr, "%s(%s)\n", o->name, where);
+						dspop* first = o;
+						u32 sp = reportGpu? span_open () : 0;
+						int fused = fuseChains? try_fused_apply (o, runEnd, s) : 0;
+						if (fused == 0) (*o->funcApply) (o, s->chrom, s->length, s->valVector);
+						if (reportGpu) span_close (sp, first, (fused == 0)? 1 : fused, s->length);
+						for ( ; fused > 1 ; fused--)           /* the chain ran as one kernel */
+							{
+							o = o->next;
+							if (trackOperations) fprintf (stderr, "%s(%s)\n", o->name, where);
+							}
+						}
+					activeSpec = NULL;
+					}
+				op = runEnd;
 				}
+			free (units);
 			if (sharded && ((reachL | reachR) != 0)) halosFresh = false;     /* pointwise runs leave the halos right */
 			}
 		if (stopOp == NULL) firstOp = NULL;

@@ -47,6 +47,14 @@ void  resolve_variable  (dspop* op, char** varName, valtype* val, const char* ro
 /* ops_fused.c: run op (and the operators after it, up to stopOp) as one fused kernel when
  * the chain is one the device library fuses; returns how many operators were consumed (0 = none) */
 int   try_fused_apply   (dspop* op, dspop* stopOp, spec* s);
+/* one launch per operator per device (see ops_fused.c) */
+int   op_batchable          (dspop* op);
+int   batch_apply_on_device (dspop* op, dspop* stopOp, spec** units, int nunits, int allowFusion);
+valtype* partner_of    (spec* s);              /* the second HBM buffer of a chromosome or stretch */
+void     flip_spec     (spec* s);              /* swap vector and partner */
+void     apply_to_unit (dspop* op, spec* s);   /* the operator's own apply on one chromosome or stretch */
+void  op_limits_describe    (dspop* op, int* haveMin, valtype* lo, int* haveMax, valtype* hi, int* keepInside, valtype* zero);
+valtype op_add_constant_value (dspop* op);
 u32   op_smooth_window    (dspop* op);
 u32   op_best_window      (dspop* op);
 void  op_morph_reach      (dspop* op, u32* left, u32* right);

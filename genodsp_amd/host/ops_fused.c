@@ -73,3 +73,107 @@ int try_fused_apply (dspop* op, dspop* stopOp, spec* s)
 		}
 	return 0;
 	}
+
+/* ---- one launch per operator per device (gdsp_*_batch): the chromosome loop of genodsp.c:909-921 turned inside out.
+ * Chromosomes are independent for every per-chromosome operator, so "every operator of the run on chromosome 1, then
+ * on chromosome 2, ..." and "operator 1 on every chromosome, then operator 2, ..." give the same signal; the second
+ * order lets one grid cover all the vectors a device owns (no ramp and drain between 24 short kernels). */
+int op_batchable (dspop* op)
+	{
+	opfunc_apply f = op->funcApply;
+	return (f == op_smooth_apply) || (f == op_local_maxima_apply) || (f == op_local_minima_apply)
+	    || (f == op_best_local_max_apply) || (f == op_best_local_min_apply)
+	    || (f == op_dilate_apply) || (f == op_erode_apply)
+	    || (f == op_binarize_apply) || (f == op_clip_apply) || (f == op_erase_apply)
+	    || (f == op_add_constant_apply) || (f == op_absolute_value_apply);
+	}
+
+/* apply op -- and the operators fused behind it -- to units[0..nunits), all of them on the current device;
+ * returns how many operators were consumed (>= 1; op must be batchable) */
+int batch_apply_on_device (dspop* op, dspop* stopOp, spec** units, int nunits, int allowFusion)
+	{
+	opfunc_apply f = op->funcApply;
+	dspop* next = op->next;
+	if (next == stopOp) next = NULL;
+	gdsp_batch_item* items = (gdsp_batch_item*) calloc (nunits? nunits : 1, sizeof(gdsp_batch_item));
+	if (items == NULL) { fprintf (stderr, "out of memory\n");  exit (EXIT_FAILURE); }
+	for (int i=0 ; i<nunits ; i++)
+		{ items[i].d_in = units[i]->valVector;  items[i].d_out = partner_of (units[i]);  items[i].n = units[i]->length; }
+	void* st = op_stream ();
+	int   consumed = 1, outOfPlace = true, rc = GDSP_OK;
+
+	if (f == op_smooth_apply)
+		{
+		int mode = firMode;
+		int feedsLocal = (next != NULL) && ((next->funcApply == op_local_maxima_apply) || (next->funcApply == op_local_minima_apply));
+		if ((mode == GDSP_FIR_HANN) && feedsLocal) mode = GDSP_FIR_FMA;             /* as op_smooth_apply / try_fused_apply */
+		u32 N = 0;  int wantMax = 0;  valtype fill = 0;
+		if (feedsLocal) op_local_describe (next, &N, &wantMax, &fill);
+		if (allowFusion && feedsLocal && gdsp_smooth_local_extrema_fusable (op_smooth_window (op), N))
+			{ rc = gdsp_smooth_local_extrema_batch (items, nunits, op_smooth_window (op), mode, N, wantMax, fill, st);  consumed = 2; }
+		else rc = gdsp_smooth_batch (items, nunits, op_smooth_window (op), mode, st);
+		}
+	else if ((f == op_local_maxima_apply) || (f == op_local_minima_apply))
+		{
+		u32 N;  int wantMax;  valtype fill;
+		op_local_describe (op, &N, &wantMax, &fill);
+		rc = gdsp_local_extrema_batch (items, nunits, N, wantMax, fill, st);
+		}
+	else if ((f == op_best_local_max_apply) || (f == op_best_local_min_apply))
+		rc = gdsp_best_extrema_batch (items, nunits, op_best_window (op), f == op_best_local_max_apply, st);
+	else if ((f == op_dilate_apply) || (f == op_erode_apply))
+		{
+		u32 l, r;  valtype T, one, zero;
+		op_morph_describe (op, &l, &r, &T, &one, &zero);
+		rc = GDSP_EINVAL;
+		if (allowFusion && (f == op_dilate_apply) && (next != NULL) && (next->funcApply == op_erode_apply))
+			{
+			u32 el, er;  valtype eT, eOne, eZero, bT = 0, bOne = 1, bZero = 0;  int bTies = false, withBinarize = false;
+			op_morph_describe (next, &el, &er, &eT, &eOne, &eZero);
+			if (gdsp_dilate_erode_fusable (l, r, el, er))          /* (a property of the reaches alone: every device decides alike) */
+				{
+				dspop* third = next->next;
+				if ((third != NULL) && (third != stopOp) && (third->funcApply == op_binarize_apply))
+					{ op_binarize_describe (third, &bT, &bTies, &bOne, &bZero);  withBinarize = true; }
+				rc = gdsp_dilate_erode_batch (items, nunits, l, r, T, one, zero, el, er, eT, eOne, eZero,
+				                              withBinarize, bT, bTies, bOne, bZero, st);
+				consumed = withBinarize? 3 : 2;
+				}
+			}
+		if ((rc == GDSP_EINVAL) && (consumed == 1))           /* not fused (or the combined reach is beyond one tile) */
+			{
+			rc = (f == op_dilate_apply)? gdsp_dilate_batch (items, nunits, l, r, T, one, zero, st)
+			                           : gdsp_erode_batch  (items, nunits, l, r, T, one, zero, st);
+			if (rc == GDSP_EINVAL)                             /* reach beyond one LDS tile: the operator's own whole-vector route */
+				{
+				free (items);
+				for (int i=0 ; i<nunits ; i++) apply_to_unit (op, units[i]);
+				return 1;
+				}
+			}
+		}
+	else
+		{
+		outOfPlace = false;
+		for (int i=0 ; i<nunits ; i++) { items[i].d_in = NULL;  items[i].d_out = units[i]->valVector; }    /* in place */
+		if (f == op_binarize_apply)
+			{
+			valtype T, one, zero;  int ties;
+			op_binarize_describe (op, &T, &ties, &one, &zero);
+			rc = gdsp_binarize_batch (items, nunits, T, ties, one, zero, st);
+			}
+		else if ((f == op_clip_apply) || (f == op_erase_apply))
+			{
+			int haveMin, haveMax, keepInside;  valtype lo, hi, zero;
+			op_limits_describe (op, &haveMin, &lo, &haveMax, &hi, &keepInside, &zero);
+			rc = (f == op_clip_apply)? gdsp_clip_batch  (items, nunits, haveMin, lo, haveMax, hi, st)
+			                         : gdsp_erase_batch (items, nunits, haveMin, lo, haveMax, hi, keepInside, zero, st);
+			}
+		else if (f == op_add_constant_apply) rc = gdsp_add_constant_batch (items, nunits, op_add_constant_value (op), st);
+		else                                 rc = gdsp_abs_batch (items, nunits, st);
+		}
+	free (items);
+	check_gdsp (rc, op->name);
+	if (outOfPlace) { for (int i=0 ; i<nunits ; i++) flip_spec (units[i]); }
+	return consumed;
+	}

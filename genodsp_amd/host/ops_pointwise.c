@@ -126,6 +126,15 @@ void op_clip_usage (char* name, FILE* f, char* indent)
 dspop* op_clip_parse (char* name, int argc, char** argv) { return limits_parse (name, argc, argv, false); }
 void   op_clip_free  (dspop* op) { limits_free (op); }
 
+void op_limits_describe (dspop* _op, int* haveMin, valtype* lo, int* haveMax, valtype* hi, int* keepInside, valtype* zero)
+	{
+	dspop_limits* op = (dspop_limits*) _op;
+	resolve_variable (_op, &op->minValVarName, &op->minVal, "minimum limit");
+	resolve_variable (_op, &op->maxValVarName, &op->maxVal, "maximum limit");
+	*haveMin = op->haveMinVal;  *lo = op->minVal;  *haveMax = op->haveMaxVal;  *hi = op->maxVal;
+	*keepInside = op->keepInside;  *zero = op->zeroVal;
+	}
+
 void op_clip_apply (dspop* _op, arg_dont_complain(char* vName), u32 vLen, valtype* v)
 	{
 	dspop_limits* op = (dspop_limits*) _op;
@@ -186,6 +195,8 @@ dspop* op_add_constant_parse (char* name, int argc, char** argv)
 	}
 
 void op_add_constant_free (dspop* op) { free (op); }
+
+valtype op_add_constant_value (dspop* op) { return ((dspop_addconst*) op)->val; }
 
 void op_add_constant_apply (dspop* _op, arg_dont_complain(char* vName), u32 vLen, valtype* v)
 	{ check_gdsp (gdsp_add_constant (v, vLen, ((dspop_addconst*) _op)->val, op_stream ()), _op->name); }

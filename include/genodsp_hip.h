@@ -141,6 +141,7 @@ int gdsp_erode  (const double* d_in, double* d_out, uint32_t n, uint32_t left, u
 /* `= dilate = erode [= binarize]` in one pass (morphology.c:882-1072 -> :1331-1454 ->
  * logical.c:216-268): the dilated set stays in LDS as a bit mask.  Bit-identical to the
  * three calls in sequence; each stage keeps its own threshold and output values. */
+int gdsp_dilate_erode_fusable (uint32_t dLeft, uint32_t dRight, uint32_t eLeft, uint32_t eRight);   /* 1: fused for any vector length */
 int gdsp_dilate_erode (const double* d_in, double* d_out, uint32_t n,
                        uint32_t dLeft, uint32_t dRight, double dT, double dOne, double dZero,
                        uint32_t eLeft, uint32_t eRight, double eT, double eOne, double eZero,

@@ -9,8 +9,10 @@ import pytest
 from test_cli_hip import run
 
 pytestmark = pytest.mark.gpu
-PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "campaign.json")
-CASES = json.load(open(PATH))["cases"] if os.path.exists(PATH) else []
+import glob
+CASES = []
+for PATH in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "campaign*.json"))):
+    CASES += json.load(open(PATH))["cases"]
 
 
 @pytest.mark.skipif(not CASES, reason="no campaign drawn (tools/cli_campaign.py)")

@@ -2,7 +2,8 @@
 """A bigger draw from the random command-line generators of tests/golden/make_golden.py, as a one-off hunt: the
 reference binary's digests for seeds the committed fixtures do not hold go to tests/golden/campaign.json (not
 committed; .gitignore), and tests/test_cli_campaign.py compares the HIP driver with them when the file is there.
-usage (in the build container, where /root/reference exists): python3 tools/cli_campaign.py [first] [count] [scale]"""
+usage (in the build container, where /root/reference exists): python3 tools/cli_campaign.py [first] [count] [scale] [file]
+(file: name under tests/golden, default campaign.json; tests/test_cli_campaign.py reads every campaign*.json there)"""
 import importlib.util
 import json
 import os
@@ -21,6 +22,7 @@ for k in range(first, first + count):
     if scale == 1:
         mod.random_file_case(k)
 extra = [c for c in mod.cases[before:] if c["returncode"] == 0]
-with open(os.path.join(ROOT, "tests", "golden", "campaign.json"), "w") as f:
+out_name = sys.argv[4] if len(sys.argv) > 4 else "campaign.json"
+with open(os.path.join(ROOT, "tests", "golden", out_name), "w") as f:
     json.dump({"first": first, "count": count, "scale": scale, "cases": extra}, f)
 print("%d cases" % len(extra))
