@@ -116,18 +116,38 @@ struct GdspBatch
 	uint32_t      nvec;
 	};
 
-// -> tile index inside the vector; in / out / n are set to the vector's
+// -> tile index inside the vector; in / out / n are set to the vector's.  The whole offset table comes in with two
+// scalar loads issued together and the search runs on registers: five compares, each followed by selects that keep the
+// half of the table the answer lies in (31 s_cselect in all; unused entries hold the grid size, which no tile id
+// reaches) -- two scalar-load latencies per block instead of the seven of a search that loads as it goes, which cost the
+// hann kernel 6 % of its time.
 __device__ __forceinline__ uint32_t gdsp_batch_tile (const GdspBatch& B, const double*& in, double*& out, uint32_t& n)
 	{
-	const uint32_t g = gdsp_xcd_tile (blockIdx.x, B.tile0[B.nvec]);
-	uint32_t lo = 0, hi = B.nvec;                  // invariant: tile0[lo] <= g < tile0[hi]
-	while (hi - lo > 1)
+	static_assert (GDSP_BATCH_MAX == 32, "the search below is five levels deep");
+	const uint32_t g = gdsp_xcd_tile (blockIdx.x, B.tile0[GDSP_BATCH_MAX]);
+	uint32_t t32[32], t16[16], t8[8], t4[4], t2[2];
+#pragma unroll
+	for (int i=0 ; i<32 ; i++)
 		{
-		const uint32_t mid = (lo + hi) >> 1;
-		if (B.tile0[mid] <= g) lo = mid;  else hi = mid;
+		t32[i] = B.tile0[i];
+		asm ("" : "+s" (t32[i]));                              // the table is loaded whole (else the selects below turn into loads from selected addresses)
 		}
-	in = B.in[lo];  out = B.out[lo];  n = B.n[lo];
-	return g - B.tile0[lo];
+	const bool c16 = (t32[16] <= g);
+#pragma unroll
+	for (int i=0 ; i<16 ; i++) t16[i] = c16? t32[16+i] : t32[i];
+	const bool c8 = (t16[8] <= g);
+#pragma unroll
+	for (int i=0 ; i<8 ; i++) t8[i] = c8? t16[8+i] : t16[i];
+	const bool c4 = (t8[4] <= g);
+#pragma unroll
+	for (int i=0 ; i<4 ; i++) t4[i] = c4? t8[4+i] : t8[i];
+	const bool c2 = (t4[2] <= g);
+	t2[0] = c2? t4[2] : t4[0];  t2[1] = c2? t4[3] : t4[1];
+	const bool c1 = (t2[1] <= g);
+	const uint32_t first = c1? t2[1] : t2[0];                  // = tile0[v]
+	const uint32_t v = (c16? 16u : 0u) + (c8? 8u : 0u) + (c4? 4u : 0u) + (c2? 2u : 0u) + (c1? 1u : 0u);
+	in = B.in[v];  out = B.out[v];  n = B.n[v];
+	return g - first;
 	}
 
 // host: launch(B, tiles) over tables of up to GDSP_BATCH_MAX vectors each until every item has been covered (empty

@@ -55,233 +55,7 @@
 #include <vector>
 #include "gdsp_common.h"
 
-#define HN_THREADS 256
-#define HN_G       16
-#define HN_PITCH   17
-#define HN_ELEMS   (HN_THREADS * HN_G)
-#define HN_E       8                                     // direct taps at either end of the window
-
-// exponent field of 2^1017 = DBL_MAX/128 in the high word of a double (sign stripped): at or above it the
-// unweighted block sums could overflow; infinities and NaNs (exponent 0x7FF) are above it too
-#define HN_HUGE_HI 0x7F800000u
-
-__device__ __forceinline__ uint32_t hann_magnitude_hi (double x)
-	{ return ((uint32_t) (__double_as_longlong (x) >> 32)) & 0x7FFFFFFFu; }
-
-// A tile the block sums must not touch: out[o] = sum_k taps[k] * x[first + o + k], ascending k, one fused
-// multiply-add per tap (what fir_*_kernel<.., FMA> does).  Output o = p + 256*i; results go back into the
-// LDS image like the block-sum results.  Rare (a tile holding inf / NaN / |x| >= 2^1017), so not tuned.
-__device__ __noinline__ void hann_direct_tile (double* lds, const double* __restrict__ taps, int W, int first, int nout,
-                                               int nthreads = HN_THREADS)
-	{
-	const int p = threadIdx.x;
-	const int lastElem = nthreads * HN_G - 1;
-	double acc[HN_G];
-#pragma unroll
-	for (int i=0 ; i<HN_G ; i++) acc[i] = 0.0;
-	for (int k=0 ; k<W ; k++)
-		{
-		const double w = taps[k];
-#pragma unroll
-		for (int i=0 ; i<HN_G ; i++)
-			{
-			int e = first + p + nthreads*i + k;
-			if (e > lastElem) e = lastElem;                        // (outputs past nout are computed and dropped)
-			acc[i] = __builtin_fma (w, lds[e + (e >> 4)], acc[i]);
-			}
-		}
-	__syncthreads ();                                              // every read of the staged inputs is done
-#pragma unroll
-	for (int i=0 ; i<HN_G ; i++)
-		{
-		const int o = p + nthreads*i;
-		if (o < nout) lds[o + (o >> 4)] = acc[i];
-		}
-	__syncthreads ();
-	}
-
-template <int W> struct HannGeom
-	{
-	static constexpr int H      = (W - 1) / 2;
-	static constexpr int E      = HN_E;
-	static constexpr int DM     = W - 2*E - 1;           // a' = b' - DM: ends of the middle stretch
-	static constexpr int DQ     = DM / HN_G, DR = DM % HN_G;
-	static constexpr int BACK   = DM + E;                // first element of the window = b' - BACK
-	static constexpr int HALO_L = (BACK + HN_G - 1) / HN_G;   // leading blocks that only feed
-	static constexpr int HALO_R = (E + HN_G - 1) / HN_G;      // trailing ones
-	static constexpr int OUT    = (HN_THREADS - HALO_L - HALO_R) * HN_G;
-	static constexpr int NLEFT  = HN_G + DR;             // elements that hold the 16 left ends a'
-	static constexpr int NT     = DQ - 1;                // whole blocks always between
-	static constexpr int LO     = HALO_L * HN_G - BACK;  // offset of element b'-BACK in block p-HALO_L (s = 0)
-	static constexpr int LEAD   = HALO_L * HN_G - (H - E);    // staged elements before the first output
-	static constexpr int NEDGE  = HN_G + E - 1;          // inputs under the E direct taps of 16 outputs
-	static_assert (DQ >= 2, "window shorter than two blocks");
-	static_assert ((LEAD & 1) == 0, "tile start must stay 16-byte aligned");
-	static_assert (LO + NEDGE <= 2 * HN_G, "left edge spans more than two blocks");
-	};
-
-template <int W> struct HannConsts
-	{
-	double edge[HN_E];                                             // 1 - cos(w k),        k = 1..E
-	double ownC[HN_G], ownS[HN_G];                                 // exp(+j w u),         u = 0..15
-	double leftC[HannGeom<W>::NLEFT], leftS[HannGeom<W>::NLEFT];   // exp(+j w (u - DM)),  u = 0..NLEFT-1
-	double rotC[HannGeom<W>::NT], rotS[HannGeom<W>::NT];           // exp(-j w 16 d),      d = 1..NT
-	double demC[HN_G], demS[HN_G];                                 // exp(+j w (W-E - s)), s = 0..15
-	double scale;                                                  // c = 1 / (2 * sum of raw taps)
-	};
-
-// Staging and phases 0-2 for one tile whose first staged element is e0 (even): on return acc[u] of a live thread p holds
-// output (p - HALO_L)*16 + u of the tile, unless the tile must not go through the block sums (the return value: uniform
-// over the workgroup), and the staged inputs are still in the LDS image (no barrier after the last read).
-// With STATS, stats[wave] = { largest magnitude's high word, bit 0: a sign bit is set, bit 1: 0 < |x| < 2^-500 } of the wave's
-// 64 blocks (visible on return).
-template <int W, bool STATS = false>
-__device__ __forceinline__ bool hann_tile_sums (double* lds, double (*tot)[HN_THREADS], uint32_t* huge,
-                                                const double* __restrict__ in, uint32_t n, int64_t e0,
-                                                const HannConsts<W>& K, double (&acc)[HN_G], uint32_t (*stats)[2] = NULL)
-	{
-	typedef HannGeom<W> G;
-	const int  p    = threadIdx.x;
-	const bool live = (p >= G::HALO_L) && (p < HN_THREADS - G::HALO_R);
-
-	// ---- stage 4096 elements, zero outside the chromosome
-	if ((e0 >= 0) && (e0 + HN_ELEMS <= (int64_t) n))
-		{
-		const double2* src = reinterpret_cast<const double2*> (in + e0);
-		double2 r[HN_G/2];
-#pragma unroll
-		for (int u=0 ; u<HN_G/2 ; u++) r[u] = gdsp_ld2 (&src[u*HN_THREADS + p]);
-#pragma unroll
-		for (int u=0 ; u<HN_G/2 ; u++)
-			{
-			const int e = 2 * (u*HN_THREADS + p);
-			double* dst = lds + e + (e >> 4);
-			dst[0] = r[u].x;  dst[1] = r[u].y;
-			}
-		}
-	else
-		{
-		for (int e=p ; e<HN_ELEMS ; e+=HN_THREADS)
-			{
-			const int64_t g = e0 + e;
-			lds[e + (e >> 4)] = ((g >= 0) && (g < (int64_t) n))? in[g] : 0.0;
-			}
-		}
-	__syncthreads ();
-
-	// ---- phase 0: the E taps at either end of each of the 16 windows, directly
-#pragma unroll
-	for (int s=0 ; s<HN_G ; s++) acc[s] = 0.0;
-	if (live)
-		{
-		const double* xl = lds + (p - G::HALO_L) * HN_PITCH;        // element b'-BACK of s=0 is xl[LO]
-#pragma unroll
-		for (int j=0 ; j<G::NEDGE ; j++)                            // window s meets input j under tap k = j-s+1
-			{
-			const int    o = G::LO + j;
-			const double x = xl[o + (o >> 4)];
-#pragma unroll
-			for (int s=0 ; s<HN_G ; s++)
-				{ if ((j - s >= 0) && (j - s < G::E)) acc[s] = __builtin_fma (K.edge[j-s], x, acc[s]); }
-			}
-		const double* xr = lds + p * HN_PITCH;                      // element b'+m of window s is xr[s+m]
-#pragma unroll
-		for (int j=1 ; j<=G::NEDGE ; j++)                           // tap W+1-m = tap m from the far end
-			{
-			const double x = xr[j + (j >> 4)];
-#pragma unroll
-			for (int s=0 ; s<HN_G ; s++)
-				{ if ((j - s >= 1) && (j - s <= G::E)) acc[s] = __builtin_fma (K.edge[G::E - (j-s)], x, acc[s]); }
-			}
-		}
-
-	// ---- phase 1: prefix sums of the own block in the own phase
-	double P0[HN_G], Pr[HN_G], Pi[HN_G];
-		{
-		const double* xb = lds + p * HN_PITCH;
-		double a0 = 0.0, ar = 0.0, ai = 0.0;
-		uint32_t big = 0;                                          // largest exponent seen in the own block
-		uint32_t signs = 0;  bool tiny = false;
-#pragma unroll
-		for (int u=0 ; u<HN_G ; u++)
-			{
-			const double x = xb[u];
-			big = max (big, hann_magnitude_hi (x));
-			if (STATS)
-				{
-				const uint32_t hi = (uint32_t) (__double_as_longlong (x) >> 32), lo = (uint32_t) __double_as_longlong (x);
-				signs |= hi;
-				tiny = tiny || (((hi & 0x7FFFFFFFu) < 0x20B00000u) && (((hi & 0x7FFFFFFFu) | lo) != 0));
-				}
-			a0 += x;
-			ar  = __builtin_fma (x, K.ownC[u], ar);
-			ai  = __builtin_fma (x, K.ownS[u], ai);
-			P0[u] = a0;  Pr[u] = ar;  Pi[u] = ai;
-			}
-		tot[0][p] = a0;  tot[1][p] = ar;  tot[2][p] = ai;
-		const bool any = (__builtin_amdgcn_ballot_w64 (big >= HN_HUGE_HI) != 0);   // the 256 blocks are the whole tile
-		if ((p & 63) == 0) huge[p >> 6] = any? 1u : 0u;
-		if (STATS)
-			{
-			const uint32_t flags = ((__builtin_amdgcn_ballot_w64 ((signs >> 31) != 0) != 0)? 1u : 0u)
-			                     | ((__builtin_amdgcn_ballot_w64 (tiny) != 0)? 2u : 0u);
-			for (int off=32 ; off>0 ; off>>=1) big = max (big, (uint32_t) __shfl_xor ((int) big, off, 64));
-			if ((p & 63) == 0) { stats[p >> 6][0] = big;  stats[p >> 6][1] = flags; }
-			}
-		}
-	__syncthreads ();
-	const uint4 hg     = *reinterpret_cast<const uint4*> (huge);
-	const bool  direct = ((hg.x | hg.y | hg.z | hg.w) != 0);       // uniform over the workgroup
-
-	// ---- phase 2: the middle stretch of one window per left end
-	if (live && !direct)
-		{
-		double T0 = 0.0, Tr = 0.0, Ti = 0.0;                       // whole blocks p-NT .. p-1
-#pragma unroll
-		for (int d=G::NT ; d>=1 ; d--)
-			{
-			const double b0 = tot[0][p-d], br = tot[1][p-d], bi = tot[2][p-d];
-			T0 += b0;
-			Tr += __builtin_fma (br, K.rotC[d-1], -(bi * K.rotS[d-1]));
-			Ti += __builtin_fma (br, K.rotS[d-1],   bi * K.rotC[d-1]);
-			}
-		const double* lb = lds + (p - G::DQ) * HN_PITCH;            // block of the left ends of s >= DR
-		const double* la = lb - HN_PITCH + (HN_G - G::DR);          // last DR elements of the block before
-		double s0 = 0.0, sr = 0.0, si = 0.0;
-#pragma unroll
-		for (int u=G::NLEFT-1 ; u>=G::DR ; u--)
-			{
-			const double x = lb[u - G::DR];
-			s0 += x;
-			sr  = __builtin_fma (x, K.leftC[u], sr);
-			si  = __builtin_fma (x, K.leftS[u], si);
-			if (u < HN_G)                                           // left end of the stretch whose right end is own[u]
-				{
-				const double z0 = (s0 + T0) + P0[u];
-				const double zr = (sr + Tr) + Pr[u];
-				const double zi = (si + Ti) + Pi[u];
-				const double c  = __builtin_fma (K.demC[u], zr, -(K.demS[u] * zi));
-				acc[u] = K.scale * ((z0 - c) + acc[u]);
-				}
-			}
-		T0 += s0;  Tr += sr;  Ti += si;                            // that block is whole for the remaining windows
-		s0 = 0.0;  sr = 0.0;  si = 0.0;
-#pragma unroll
-		for (int u=G::DR-1 ; u>=0 ; u--)
-			{
-			const double x = la[u];
-			s0 += x;
-			sr  = __builtin_fma (x, K.leftC[u], sr);
-			si  = __builtin_fma (x, K.leftS[u], si);
-			const double z0 = (s0 + T0) + P0[u];
-			const double zr = (sr + Tr) + Pr[u];
-			const double zi = (si + Ti) + Pi[u];
-			const double c  = __builtin_fma (K.demC[u], zr, -(K.demS[u] * zi));
-			acc[u] = K.scale * ((z0 - c) + acc[u]);
-			}
-		}
-	return direct;
-	}
+#include "gdsp_hann_tile.h"
 
 template <int W>
 __device__ __forceinline__ void hann_blocks_tile (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t tile,
@@ -349,32 +123,6 @@ void hann_blocks_batch_kernel (GdspBatch B, HannConsts<W> K, const double* __res
 	const double* in;  double* out;  uint32_t n;
 	const uint32_t tile = gdsp_batch_tile (B, in, out, n);
 	hann_blocks_tile<W> (in, out, n, tile, K, taps);
-	}
-
-template <int W>
-static void hann_consts (HannConsts<W>& K)
-	{
-	typedef HannGeom<W> G;
-	const double pi = 3.14159265358979323846264;
-	const int    M  = W + 1;                                       // the window's period
-	auto cs = [&] (long m, double* c, double* sn)                   // exp(j*2*pi*m/M), argument reduced first
-		{
-		long r = ((m % M) + M) % M;
-		double x = r / (double) M;
-		*c = cos (2*pi*x);  *sn = sin (2*pi*x);
-		};
-	for (int k=1 ; k<=G::E ; k++)    { double c, sn;  cs (k, &c, &sn);  K.edge[k-1] = 1 - c; }
-	for (int u=0 ; u<HN_G ; u++)     cs (u, &K.ownC[u], &K.ownS[u]);
-	for (int u=0 ; u<G::NLEFT ; u++) cs ((long) u - G::DM, &K.leftC[u], &K.leftS[u]);
-	for (int d=1 ; d<=G::NT ; d++)   cs (-(long) HN_G * d, &K.rotC[d-1], &K.rotS[d-1]);
-	for (int u=0 ; u<HN_G ; u++)     cs ((long) W - G::E - u, &K.demC[u], &K.demS[u]);
-	double total = 0.0;                                            // as gdsp_hann_taps sums it (sum.c:632-645)
-	for (int k=0 ; k<W ; k++)
-		{
-		const int kk = (k <= G::H)? k : W-1-k;
-		total += (1 - cos (2*pi*((kk+1) / (double) M))) / 2;
-		}
-	K.scale = 0.5 / total;
 	}
 
 template <int W>

@@ -998,9 +998,12 @@ static void stage_chromosome (int ci, staging** out)
 		}
 	grow ((void**) &st->h_off, (void**) &st->d_off, &st->offCap, (size_t) ntiles + 1, sizeof(u32));
 
-	memcpy (st->h_start, p->start, (size_t) p->count * sizeof(u32));
-	memcpy (st->h_end,   p->end,   (size_t) p->count * sizeof(u32));
-	memcpy (st->h_val,   p->val,   (size_t) p->count * sizeof(valtype));
+	if (p->count != 0)                                     /* (a chromosome no interval has named has no arrays yet) */
+		{
+		memcpy (st->h_start, p->start, (size_t) p->count * sizeof(u32));
+		memcpy (st->h_end,   p->end,   (size_t) p->count * sizeof(u32));
+		memcpy (st->h_val,   p->val,   (size_t) p->count * sizeof(valtype));
+		}
 	check_gdsp (gdsp_bin_intervals (s->length, st->h_start, st->h_end, p->count, st->h_off, NULL, &listLen), "bin intervals");
 	grow ((void**) &st->h_list, (void**) &st->d_list, &st->listCap, (size_t) listLen + 1, sizeof(u32));
 	check_gdsp (gdsp_bin_intervals (s->length, st->h_start, st->h_end, p->count, st->h_off, st->h_list, &listLen), "bin intervals");
@@ -1208,7 +1211,7 @@ static char* put_fixed (char* p, valtype v, int precision)              /* %.*f 
 			return p;
 			}
 		}
-	return p + snprintf (p, 400, valtypeFmtPrec, precision, v);
+	return NULL;                                       /* not a case for the fast path: the caller prints through printf */
 	}
 
 static void out_line (FILE* f, const char* chrom, int start, int end, int withVal, valtype v, int precision, int na)
@@ -1218,7 +1221,22 @@ static void out_line (FILE* f, const char* chrom, int start, int end, int withVa
 	p = put_int (p, start);   *(p++) = '\t';
 	p = put_int (p, end);
 	if (na)           { *(p++) = '\t';  *(p++) = 'N';  *(p++) = 'A'; }
-	else if (withVal) { *(p++) = '\t';  p = put_fixed (p, v, precision); }
+	else if (withVal)
+		{
+		*(p++) = '\t';
+		char* q = put_fixed (p, v, precision);
+		if (q == NULL)
+			{
+			/* huge values, precisions beyond nine digits, NaN: any length (--precision=400 prints 400 digits), so not
+			 * through the buffer's fixed slack -- what is pending goes out, then the value through printf itself */
+			outAt = p;
+			out_flush (f);
+			fprintf (f, valtypeFmtPrec "\n", precision, v);
+			linesWritten++;
+			return;
+			}
+		p = q;
+		}
 	*(p++) = '\n';
 	outAt = p;
 	linesWritten++;

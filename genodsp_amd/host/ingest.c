@@ -32,6 +32,7 @@ typedef struct record
 	u64     line;                              /* local to the stretch until the block is stitched */
 	char*   problem;                           /* malloc'ed message: print, exit */
 	int     numbered;                          /* the message starts with "problem at line <n>" */
+	int     lineIsGlobal;                      /* `line` is owedLine, not a stretch-local number */
 	} record;
 
 typedef struct stretch
@@ -40,6 +41,8 @@ typedef struct stretch
 	int     valCol;
 	record* recs;  size_t count, cap;
 	u64     lines;
+	int     owesAtStart, owesAtEnd;            /* a line without its '\n' before / at the end of this stretch (see parse_stretch) */
+	u64     owedAt;
 	} stretch;
 
 typedef struct stream
@@ -54,6 +57,12 @@ typedef struct stream
 static stream* open_streams[8];
 static u64     lineNumber = 0;                 /* lines handed out so far, all files (reference: a static) */
 static int     missingEol = false;             /* serial reader only */
+
+/* the complaints of read_interval, word for word (genodsp.c:1511-1533) */
+#define NO_CHROM "line contains no chromosome or begins with whitespace"
+#define NO_START "line contains no interval start\n(expected \"chromosome start end ...\", but there are fewer than 2 fields)"
+#define NO_END   "line contains no interval end\n(expected \"chromosome start end ...\", but there are fewer than 3 fields)"
+#define NO_VALUE "line contains no interval value\n(expected \"chromosome start end value\", but there are fewer than 4 fields)"
 
 static char* format_problem (const char* fmt, const char* a)
 	{
@@ -94,15 +103,15 @@ static void parse_line (stretch* st, char* s, u64 line)
 	if ((*scan == 0) || (*scan == '#')) return;
 
 	char* chrom = scan = s;
-	if (*scan == ' ') { line_problem (st, line, "line contains no chromosome or begins with whitespace");  return; }
+	if (*scan == ' ') { line_problem (st, line, NO_CHROM);  return; }
 	mark = skip_darkspace (scan);  scan = skip_whitespace (mark);  if (*mark != 0) *mark = 0;
-	if (*scan == 0) { line_problem (st, line, "line contains no interval start");  return; }
+	if (*scan == 0) { line_problem (st, line, NO_START);  return; }
 	field = scan;
 	mark = skip_darkspace (scan);  scan = skip_whitespace (mark);  if (*mark != 0) *mark = 0;
 	u32 start, end;
 	if (!try_string_to_u32 (field, &start))
 		{ record* r = new_record (st);  r->line = line;  r->problem = format_problem ("\"%s\" is not an unsigned integer\n", field);  return; }
-	if (*scan == 0) { line_problem (st, line, "line contains no interval end");  return; }
+	if (*scan == 0) { line_problem (st, line, NO_END);  return; }
 	field = scan;
 	mark = skip_darkspace (scan);  scan = skip_whitespace (mark);  if (*mark != 0) *mark = 0;
 	if (!try_string_to_u32 (field, &end))
@@ -113,7 +122,7 @@ static void parse_line (stretch* st, char* s, u64 line)
 		{
 		for (int col=3 ; col<=st->valCol ; col++)
 			{
-			if (*scan == 0) { line_problem (st, line, "line contains no interval value");  return; }
+			if (*scan == 0) { line_problem (st, line, NO_VALUE);  return; }
 			field = scan;
 			mark = skip_darkspace (scan);  scan = skip_whitespace (mark);
 			}
@@ -125,10 +134,20 @@ static void parse_line (stretch* st, char* s, u64 line)
 	r->chrom = chrom;  r->start = start;  r->end = end;  r->val = val;  r->line = line;
 	}
 
+/* The reference reads with fgets into char[1001] and takes a line's length from strlen (genodsp.c:1407-1419): a line
+ * whose visible text does not end in '\n' -- 1000 characters or more, or cut short by a NUL byte -- is parsed as it
+ * stands, and the NEXT read, if there is one, stops with "line is longer than internal buffer" under this line's
+ * number.  `owed` carries that debt from one line to the next (across blocks too; a block holding a NUL byte is
+ * parsed by one thread so that the debt always has one owner). */
+static int owedEol  = false;
+static u64 owedLine = 0;                                  /* global line number of the line that owes its '\n' */
+
 static void* parse_stretch (void* arg)
 	{
 	stretch* st = (stretch*) arg;
 	char* s = st->from;
+	int  owed = st->owesAtStart;
+	u64  owedAt = 0;                                          /* local line number; 0 = the debt came in from the previous block */
 	st->count = 0;  st->lines = 0;
 	while (s < st->to)
 		{
@@ -136,23 +155,33 @@ static void* parse_stretch (void* arg)
 		char* end = (nl != NULL)? nl : st->to;             /* the line's characters are [s,end) */
 		size_t len = (size_t) (end - s);
 		st->lines++;
+		if (owed)
+			{
+			record* r = new_record (st);
+			r->numbered = true;  r->problem = format_problem ("%s", "line is longer than internal buffer");
+			r->line = owedAt;  r->lineIsGlobal = (owedAt == 0);
+			owed = false;
+			}
+		size_t chunk   = (len >= LINE_LIMIT)? LINE_LIMIT : len;        /* what fgets hands over first */
+		size_t visible = strnlen (s, chunk);
+		char   keep    = s[chunk];
+		s[chunk] = 0;                                        /* (the byte after the last stretch belongs to the buffer) */
+		parse_line (st, s, st->lines);
+		s[chunk] = keep;
 		if (len >= LINE_LIMIT)
 			{
-			/* fgets hands the reference the first 1000 characters as a line; the next call stops */
-			char keep = s[LINE_LIMIT];
-			s[LINE_LIMIT] = 0;
-			parse_line (st, s, st->lines);
-			s[LINE_LIMIT] = keep;
-			if ((st->count == 0) || (st->recs[st->count-1].problem == NULL) || (st->recs[st->count-1].line != st->lines))
-				line_problem (st, st->lines, "line is longer than internal buffer");
+			/* the rest of the line (or its '\n') is the next read, unless the file ends right here */
+			if ((len > LINE_LIMIT) || (nl != NULL))
+				{
+				if ((st->count == 0) || (st->recs[st->count-1].problem == NULL) || (st->recs[st->count-1].line != st->lines))
+					line_problem (st, st->lines, "line is longer than internal buffer");
+				}
 			}
-		else
-			{
-			*end = 0;                                        /* (the byte after the last stretch belongs to the buffer) */
-			parse_line (st, s, st->lines);
-			}
+		else if ((visible < chunk) && (visible != 0))       /* cut short by a NUL byte: strlen sees no '\n' */
+			{ owed = true;  owedAt = st->lines; }
 		s = end + 1;
 		}
+	st->owesAtEnd = owed;  st->owedAt = owedAt;
 	return NULL;
 	}
 
@@ -194,6 +223,7 @@ static int next_block (stream* sm, int valCol)
 
 	int T = team_size ();
 	if (use < (size_t) T * 65536) T = 1;
+	if (memchr (sm->block, 0, use) != NULL) T = 1;             /* NUL bytes change what the reference takes for a line: one owner */
 	sm->parts = 0;
 	char* at = sm->block;  char* stop = sm->block + use;
 	for (int t=0 ; (t<T) && (at<stop) ; t++)
@@ -208,6 +238,7 @@ static int next_block (stream* sm, int valCol)
 			}
 		stretch* st = &sm->part[sm->parts++];
 		st->from = at;  st->to = to;  st->valCol = valCol;
+		st->owesAtStart = (t == 0)? owedEol : false;
 		at = to;
 		}
 	pthread_t tid[MAX_THREADS];
@@ -225,7 +256,12 @@ static int next_block (stream* sm, int valCol)
 	for (int t=0 ; t<sm->parts ; t++)
 		{
 		stretch* st = &sm->part[t];
-		for (size_t i=0 ; i<st->count ; i++) st->recs[i].line += base;
+		for (size_t i=0 ; i<st->count ; i++)
+			{
+			if (st->recs[i].lineIsGlobal) st->recs[i].line = owedLine;
+			else                          st->recs[i].line += base;
+			}
+		if (t == sm->parts-1) { owedEol = st->owesAtEnd;  if (owedEol && (st->owedAt != 0)) owedLine = base + st->owedAt; }
 		base += st->lines;
 		}
 	lineNumber = base;
@@ -327,15 +363,15 @@ static int read_interval_serial (FILE* f, char* buffer, int bufferLen, int valCo
 
 	char* chrom = scan = buffer;
 	if (*scan == ' ')
-		{ fprintf (stderr, "problem at line %s, line contains no chromosome or begins with whitespace\n", ucommatize (lineNumber));  exit (EXIT_FAILURE); }
+		{ fprintf (stderr, "problem at line %s, " NO_CHROM "\n", ucommatize (lineNumber));  exit (EXIT_FAILURE); }
 	mark = skip_darkspace (scan);  scan = skip_whitespace (mark);  if (*mark != 0) *mark = 0;
 	if (*scan == 0)
-		{ fprintf (stderr, "problem at line %s, line contains no interval start\n", ucommatize (lineNumber));  exit (EXIT_FAILURE); }
+		{ fprintf (stderr, "problem at line %s, " NO_START "\n", ucommatize (lineNumber));  exit (EXIT_FAILURE); }
 	field = scan;
 	mark = skip_darkspace (scan);  scan = skip_whitespace (mark);  if (*mark != 0) *mark = 0;
 	u32 start = (u32) string_to_u32 (field);
 	if (*scan == 0)
-		{ fprintf (stderr, "problem at line %s, line contains no interval end\n", ucommatize (lineNumber));  exit (EXIT_FAILURE); }
+		{ fprintf (stderr, "problem at line %s, " NO_END "\n", ucommatize (lineNumber));  exit (EXIT_FAILURE); }
 	field = scan;
 	mark = skip_darkspace (scan);  scan = skip_whitespace (mark);  if (*mark != 0) *mark = 0;
 	u32 end = (u32) string_to_u32 (field);
@@ -346,7 +382,7 @@ static int read_interval_serial (FILE* f, char* buffer, int bufferLen, int valCo
 		for (int col=3 ; col<=valCol ; col++)
 			{
 			if (*scan == 0)
-				{ fprintf (stderr, "problem at line %s, line contains no interval value\n", ucommatize (lineNumber));  exit (EXIT_FAILURE); }
+				{ fprintf (stderr, "problem at line %s, " NO_VALUE "\n", ucommatize (lineNumber));  exit (EXIT_FAILURE); }
 			field = scan;
 			mark = skip_darkspace (scan);  scan = skip_whitespace (mark);
 			}

@@ -100,7 +100,7 @@ static dspop* limits_parse (char* name, int argc, char** argv, int isErase)
 		if (isErase && is_opt3 (arg, "zero", "Z")) { op->zeroVal = string_to_valtype (argVal);  continue; }
 		chastise ("[%s] Can't understand \"%s\"\n", name, arg);
 		}
-	if (!op->haveMinVal && !op->haveMaxVal) chastise ("[%s] neither min nor max was provided\n", name);
+	if (!op->haveMinVal && !op->haveMaxVal) chastise ("[%s] neither minimum nor maximum limit was provided\n", name);
 	return (dspop*) op;
 	}
 
@@ -190,7 +190,7 @@ dspop* op_add_constant_parse (char* name, int argc, char** argv)
 		op->val = string_to_valtype (arg);
 		haveVal = true;
 		}
-	if (!haveVal) chastise ("[%s] no value was provided\n", name);
+	if (!haveVal) chastise ("[%s] no constant value was provided\n", name);
 	return (dspop*) op;
 	}
 

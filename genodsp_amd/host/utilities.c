@@ -49,11 +49,17 @@ int strncmp_suffix (const char* str, const char* suffix, size_t n)   /* utilitie
 	return strcmp (str + len - m, suffix);
 	}
 
-int string_to_int (const char* s)
+static const char* first_dark (const char* s)        /* the conversions skip leading blanks, tabs and newlines (utilities.c:143-146) */
+	{ while ((*s == ' ') || (*s == '\t') || (*s == '\n')) s++;  return s; }
+
+int string_to_int (const char* s)                    /* utilities.c:136-178: value, or the reference's three complaints */
 	{
 	int  v;
 	char extra;
-	if (sscanf (s, "%d%c", &v, &extra) != 1) die ("is not an integer", s);
+	const char* ss = first_dark (s);
+	if (*ss == 0) { fprintf (stderr, "an empty string is not an integer\n");  exit (EXIT_FAILURE); }
+	if (sscanf (ss, "%d%c", &v, &extra) != 1) die ("is not an integer", s);
+	if (((v < 0) && (*ss != '-')) || ((v > 0) && (*ss == '-'))) die ("is outside the range of a signed integer", s);
 	return v;
 	}
 
@@ -69,28 +75,29 @@ static int plain_digits (const char* s, u32* v)
 	return true;
 	}
 
-int try_string_to_u32 (const char* s, u32* out)
+int try_string_to_u32 (const char* s, u32* out)      /* string_to_u32 (utilities.c:181-213) without the exit */
 	{
 	u32  v;
 	char extra;
 	if (plain_digits (s, &v)) { *out = v;  return true; }
-	if ((s[0] == '-') || (sscanf (s, "%u%c", &v, &extra) != 1)) return false;
+	const char* ss = first_dark (s);
+	if ((*ss == 0) || (*ss == '-') || (sscanf (ss, "%u%c", &v, &extra) != 1)) return false;
 	*out = v;
 	return true;
 	}
 
 int string_to_u32 (const char* s)
 	{
-	u32  v;
-	char extra;
-	if (plain_digits (s, &v)) return (int) v;
-	if ((s[0] == '-') || (sscanf (s, "%u%c", &v, &extra) != 1)) die ("is not an unsigned integer", s);
-	return (int) v;
+	u32 v;
+	if (try_string_to_u32 (s, &v)) return (int) v;
+	if (*first_dark (s) == 0) { fprintf (stderr, "an empty string is not an unsigned integer\n");  exit (EXIT_FAILURE); }
+	die ("is not an unsigned integer", s);
+	return 0;
 	}
 
 int string_to_unitized_int (const char* s, int byThousands)
 	{
-	char   body[24];
+	char   body[20];                                   /* (the reference's buffer: longer strings are parsed as they are) */
 	size_t len = strlen (s);
 	long   mult = 1;
 	int    v;

@@ -291,9 +291,10 @@ cli_case("cli_anticlump_show", APPENDIX_C_CH, ["--novalue", "--uncovered:show", 
 import hashlib  # noqa: E402
 
 
-def random_cli_case(k, scale=1):
-    """scale > 1 (tools/cli_campaign.py): chromosomes and interval counts that many times larger, so that the kernels'
-    tiles, the ingest batches and the report's chunks all meet their seams; the committed cases are scale 1"""
+def random_cli_case(k, scale=1, into=None, keep_stdout=False):
+    """scale > 1: chromosomes and interval counts that many times larger, so that the kernels' tiles, the ingest
+    batches and the report's chunks all meet their seams (golden_seams.json.gz holds 40 such cases, golden.json the
+    scale-1 ones); keep_stdout: the whole text the reference printed is kept beside the digest"""
     r = np.random.default_rng(SEED + 7000 + k)
     lens = [int(r.integers(6000 * scale, 9000 * scale)), int(r.integers(4000 * scale, 6000 * scale))]
     chroms_text = "".join("chr%s %d\n" % ("RQ"[i], n) for i, n in enumerate(lens))
@@ -352,10 +353,13 @@ def random_cli_case(k, scale=1):
     real = [a.replace("@keep@", "/tmp/golden_%s_keep" % name) for a in args]
     rc, out, err = ref.run_cli(["--chromosomes=" + chrom_path] + real, stdin)
     body = out.splitlines()
-    cases.append({"name": name, "kind": "cli_digest", "chroms_text": chroms_text, "args": args, "files": files,
-                  "stdin": stdin, "returncode": rc, "sha256": hashlib.sha256(out.encode()).hexdigest(),
-                  "lines": len(body), "head": body[:5], "tail": body[-3:],
-                  "stderr_percentile": [l for l in err.splitlines() if l.startswith("percentile ")]})
+    case = {"name": name, "kind": "cli_digest", "chroms_text": chroms_text, "args": args, "files": files,
+            "stdin": stdin, "returncode": rc, "sha256": hashlib.sha256(out.encode()).hexdigest(),
+            "lines": len(body), "head": body[:5], "tail": body[-3:],
+            "stderr_percentile": [l for l in err.splitlines() if l.startswith("percentile ")]}
+    if keep_stdout:
+        case["stdout"] = out
+    (cases if into is None else into).append(case)
 
 
 for k in range(48):
@@ -457,6 +461,27 @@ for tag, what in (("0", ["0"]), ("100", ["100"]), ("0_to_100by10", ["0..100by10"
 cli_case("cli_debug_pipe_globals_input", APPENDIX_C_CH,
          ["--novalue", "--debug=pipe", "--debug=globals", "--precision=2", "--debug=input", "--window=5", "=", "addconst", "1",
           "=", "slidingsum", "=", "mask", "@m@", "=", "variables"], APPENDIX_C_IV, {"m": "chr1 12 40\n# kept\n"})
+
+# ---- seam-crossing command lines and the running-sum cases, in a file of their own (golden_seams.json.gz):
+#      40 of the random pipelines above at thirty times the size (chromosomes of 120-270 kbp, 1800-5400 intervals), as
+#      digests; and six scale-1 pipelines in which a running sum (slidingsum / cumulativesum) follows `smooth` on real
+#      values -- the one place where a parallel evaluation cannot reproduce the reference's single accumulator to the
+#      last bit -- with the reference's whole output, so that the test can hold every base to a stated bound.
+import gzip  # noqa: E402
+
+seams = []
+k = 5000
+while len(seams) < 40:                                    # (a pipeline the reference itself stops at is no fixture)
+    random_cli_case(k, 30, into=seams)
+    if seams[-1]["returncode"] != 0:
+        seams.pop()
+    k += 1
+RUNNING_SUM_SEEDS = (1044, 1125, 1380, 1411, 1455, 1522)
+for k in RUNNING_SUM_SEEDS:
+    random_cli_case(k, 1, into=seams, keep_stdout=True)
+    seams[-1]["kind"] = "cli_running_sum"
+with gzip.GzipFile(os.path.join(HERE, "golden_seams.json.gz"), "wb", mtime=0) as f:
+    f.write(json.dumps({"seed": SEED, "cases": seams}).encode())
 
 np.savez_compressed(os.path.join(HERE, "golden.npz"), **arrays)
 with open(os.path.join(HERE, "golden.json"), "w") as f:
