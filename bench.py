@@ -401,10 +401,12 @@ def other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_base
     kernels = WORKLOAD_KERNELS[args.workload]["nofuse" if args.nofuse else "fused"]
     if args.workload == "peaks":
         kernels = [k.replace("FMA", "false" if args.mode == "exact" else "true") for k in kernels]
-        if args.mode == "exact" and not args.nofuse and os.environ.get("GDSP_PEAKS_FILTER") == "1":
-            kernels = ["hann_extrema_kernel<101, false, true, 5>"]     # opt-in: block sums as a filter, tap-by-tap only where needed
+        if not args.nofuse and os.environ.get("GDSP_PEAKS_FILTER") != "0":
+            # the filtered route (gdsp_peaks.hip): block sums + interval test, then exact taps for what stays undecided
+            kernels = ["peaks_filter_kernel<101, true, 5>", "peaks_exact_kernel<101, %s, true>" % ("false" if args.mode == "exact" else "true"),
+                       "peaks_probe_kernel<101, true, 5>", "fir_fixed_extrema_gated_kernel (leaves at once)"]
     if batch:
-        kernels = [k if k.startswith(("pc_", "hann_extrema")) else batch_name(k) for k in kernels]
+        kernels = [k if k.startswith(("pc_", "peaks_", "fir_fixed_extrema_gated")) else batch_name(k) for k in kernels]
     result = {"metric": "Gbases/sec on %s over 3.1 Gbp" % name, "value": round(total_bases / (wall_ms * 1e-3) / 1e9, 2),
               "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
               "ms_per_step": round(wall_ms, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,

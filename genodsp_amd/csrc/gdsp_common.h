@@ -36,10 +36,6 @@ int  gdsp_hann_blocks_apply (const double* d_in, double* d_out, uint32_t n, uint
 bool gdsp_hann_blocks_batch_available (uint32_t W);                   // (the W=101 kernel has a one-launch-per-device form)
 int  gdsp_hann_blocks_apply_batch (const gdsp_batch_item* items, int nitems, uint32_t W, void* stream);
 int  gdsp_batch_check (const gdsp_batch_item* items, int nitems, bool inPlace);   // gdsp_fir.hip: argument checks shared by the *_batch calls
-// ... and `smooth W=101 = localmax|localmin N` with the block sums as a filter in front of the exact evaluation (bit-identical to
-// it; opt-in, see gdsp_smooth_local_extrema)
-int  gdsp_hann_extrema_apply (const double* d_in, double* d_out, uint32_t n, uint32_t W, const double* h_taps, int fma,
-                              uint32_t N, int wantMax, double fill, void* stream);
 
 // gdsp_hann_far.hip: the same for windows longer than one LDS tile can hold (3201 .. 50001 taps), block totals in HBM
 bool gdsp_hann_far_available (uint32_t W);
@@ -121,7 +117,7 @@ struct GdspBatch
 // half of the table the answer lies in (31 s_cselect in all; unused entries hold the grid size, which no tile id
 // reaches) -- two scalar-load latencies per block instead of the seven of a search that loads as it goes, which cost the
 // hann kernel 6 % of its time.
-__device__ __forceinline__ uint32_t gdsp_batch_tile (const GdspBatch& B, const double*& in, double*& out, uint32_t& n)
+__device__ __forceinline__ uint32_t gdsp_batch_tile (const GdspBatch& B, const double*& in, double*& out, uint32_t& n, uint32_t* vector = NULL)
 	{
 	static_assert (GDSP_BATCH_MAX == 32, "the search below is five levels deep");
 	const uint32_t g = gdsp_xcd_tile (blockIdx.x, B.tile0[GDSP_BATCH_MAX]);
@@ -147,8 +143,40 @@ __device__ __forceinline__ uint32_t gdsp_batch_tile (const GdspBatch& B, const d
 	const uint32_t first = c1? t2[1] : t2[0];                  // = tile0[v]
 	const uint32_t v = (c16? 16u : 0u) + (c8? 8u : 0u) + (c4? 4u : 0u) + (c2? 2u : 0u) + (c1? 1u : 0u);
 	in = B.in[v];  out = B.out[v];  n = B.n[v];
+	if (vector != NULL) *vector = v;
 	return g - first;
 	}
+
+// host: the table for `count` (<= GDSP_BATCH_MAX) non-empty vectors
+template <typename TilesOf>
+static inline void gdsp_batch_make (GdspBatch& B, const gdsp_batch_item* items, int count, TilesOf tilesOf)
+	{
+	B.tile0[0] = 0;
+	for (int k=0 ; k<GDSP_BATCH_MAX ; k++)
+		{
+		if (k < count) { B.in[k] = items[k].d_in;  B.out[k] = items[k].d_out;  B.n[k] = items[k].n;  B.tile0[k+1] = B.tile0[k] + (uint32_t) tilesOf (items[k].n); }
+		else           { B.in[k] = NULL;  B.out[k] = NULL;  B.n[k] = 0;  B.tile0[k+1] = B.tile0[k]; }
+		}
+	B.nvec = (uint32_t) count;
+	}
+
+// ---- `smooth = localmax|localmin` in the reference's arithmetic, filtered (gdsp_peaks.hip): what its launches share.
+// Per vector: how many bases the filter queued for exact evaluation, whether the queue overflowed, what a probe of a few
+// tiles counted, and how many bases the probe looked at.  A vector whose probe found more than PK_DIRECT_NUM/256 of its
+// bases undecided (piecewise-constant depth: every base of a flat run ties) is evaluated base by base by the direct
+// kernel instead -- decided on the device, the same way by every block of every launch.
+struct GdspPeaksCtl { uint32_t count, overflow, probe, sampled; };
+#define GDSP_PEAKS_DIRECT_NUM 3u
+__device__ __forceinline__ bool gdsp_peaks_takes_direct (const GdspPeaksCtl& c) { return (uint64_t) c.probe * 256u > (uint64_t) c.sampled * GDSP_PEAKS_DIRECT_NUM; }
+
+// gdsp_fir.hip: the direct fused kernel over a table of vectors, gated: a block works only when its vector takes the direct
+// route (probe) or its queue overflowed
+int gdsp_fir_extrema_gated_launch (const gdsp_batch_item* items, int count, const GdspPeaksCtl* d_ctl, const double* h_taps,
+                                   int fma, int h, int wantMax, double fill, void* stream);
+// gdsp_peaks.hip: the filtered route for every vector of a table (W = 101, neighbourhoods of 3..15 bases)
+bool gdsp_peaks_filter_available (uint32_t W, uint32_t N);
+int  gdsp_peaks_filter_batch (const gdsp_batch_item* items, int nitems, const double* h_taps, int fma, uint32_t N, int wantMax,
+                              double fill, void* stream);
 
 // host: launch(B, tiles) over tables of up to GDSP_BATCH_MAX vectors each until every item has been covered (empty
 // vectors are skipped).  tilesOf(n) = tiles the kernel needs for a vector of n elements.

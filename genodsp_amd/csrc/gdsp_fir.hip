@@ -246,6 +246,19 @@ void fir_fixed_extrema_batch_kernel (GdspBatch B, FirTaps<W> taps, int h, double
 	fir_fixed_extrema_tile<W, R, FMA, MAX> (in, out, n, tile, taps, h, fill);
 	}
 
+// the same over a table of vectors, gated (gdsp_peaks.hip): a block works only when its vector takes the direct route --
+// the probe of the filtered route chose it, or the filter's queue overflowed; otherwise it leaves at once
+template <int W, int R, bool FMA, bool MAX>
+__global__ __launch_bounds__(FIR_THREADS)
+void fir_fixed_extrema_gated_kernel (GdspBatch B, const GdspPeaksCtl* __restrict__ ctl, FirTaps<W> taps, int h, double fill)
+	{
+	const double* in;  double* out;  uint32_t n, v;
+	const uint32_t tile = gdsp_batch_tile (B, in, out, n, &v);
+	const GdspPeaksCtl c = ctl[v];
+	if (!gdsp_peaks_takes_direct (c) && (c.overflow == 0)) return;
+	fir_fixed_extrema_tile<W, R, FMA, MAX> (in, out, n, tile, taps, h, fill);
+	}
+
 // --------------------------------------------------------- run-time W kernel ----
 // Any odd W (up to the reference's 50001, sum.c:478).  Taps are walked in stages
 // of at most KC so the LDS image stays small; the accumulators live in registers
@@ -481,11 +494,11 @@ int gdsp_smooth_local_extrema (const double* d_in, double* d_out, uint32_t n, ui
 	if (rc != GDSP_OK) return rc;
 	const int   h = (int) ((N - 1) / 2);
 	hipStream_t s = gdsp_stream (stream);
-	// GDSP_PEAKS_FILTER=1 (EXACT only): the block sums of gdsp_hann.hip as an interval filter in front of the tap-by-tap
-	// evaluation, which then runs only for the bases that can survive and what ties with them -- bit-identical, tested,
-	// and not the default: once the clocks have settled it is no faster than evaluating every base
-	if ((mode == GDSP_FIR_EXACT) && (getenv ("GDSP_PEAKS_FILTER") != NULL) && (strcmp (getenv ("GDSP_PEAKS_FILTER"), "1") == 0))
-		return gdsp_hann_extrema_apply (d_in, d_out, n, W, plan->h_taps, 0, N, wantMax, fill, stream);
+	if (gdsp_peaks_filter_available (W, N))                       // the filtered route, see gdsp_smooth_local_extrema_batch
+		{
+		const gdsp_batch_item one = { d_in, d_out, n };
+		return gdsp_peaks_filter_batch (&one, 1, plan->h_taps, mode == GDSP_FIR_FMA, N, wantMax, fill, stream);
+		}
 	if (mode == GDSP_FIR_FMA)
 		{ if (wantMax) fir_extrema_launch<true, true>  (d_in, d_out, n, plan->h_taps, h, fill, s);
 		  else         fir_extrema_launch<true, false> (d_in, d_out, n, plan->h_taps, h, fill, s); }
@@ -593,6 +606,24 @@ static void fir_extrema_batch_launch (const gdsp_batch_item* items, int nitems, 
 			{ hipLaunchKernelGGL ((fir_fixed_extrema_batch_kernel<101, FIR_R, FMA, MAX>), dim3(tiles), dim3(FIR_THREADS), 0, s, B, taps, h, fill); });
 	}
 
+int gdsp_fir_extrema_gated_launch (const gdsp_batch_item* items, int count, const GdspPeaksCtl* d_ctl, const double* h_taps,
+                                   int fma, int h, int wantMax, double fill, void* stream)
+	{
+	FirTaps<101> taps;
+	memcpy (taps.w, h_taps, sizeof(taps.w));
+	const int stride = FIR_THREADS*FIR_R - 2*h;
+	GdspBatch B;
+	gdsp_batch_make (B, items, count, [=] (uint32_t n) { return ((uint64_t) n + stride - 1) / stride; });
+	hipStream_t s = gdsp_stream (stream);
+	const dim3 grid (B.tile0[GDSP_BATCH_MAX]), block (FIR_THREADS);
+	if (fma) { if (wantMax) hipLaunchKernelGGL ((fir_fixed_extrema_gated_kernel<101, FIR_R, true,  true>),  grid, block, 0, s, B, d_ctl, taps, h, fill);
+	           else         hipLaunchKernelGGL ((fir_fixed_extrema_gated_kernel<101, FIR_R, true,  false>), grid, block, 0, s, B, d_ctl, taps, h, fill); }
+	else     { if (wantMax) hipLaunchKernelGGL ((fir_fixed_extrema_gated_kernel<101, FIR_R, false, true>),  grid, block, 0, s, B, d_ctl, taps, h, fill);
+	           else         hipLaunchKernelGGL ((fir_fixed_extrema_gated_kernel<101, FIR_R, false, false>), grid, block, 0, s, B, d_ctl, taps, h, fill); }
+	GDSP_LAUNCH_CHECK ();
+	return GDSP_OK;
+	}
+
 extern "C" int gdsp_smooth_local_extrema_batch (const gdsp_batch_item* items, int nitems, uint32_t W, int mode,
                                                 uint32_t N, int wantMax, double fill, void* stream)
 	{
@@ -606,15 +637,10 @@ extern "C" int gdsp_smooth_local_extrema_batch (const gdsp_batch_item* items, in
 	if (rc != GDSP_OK) return rc;
 	const int   h = (int) ((N - 1) / 2);
 	hipStream_t s = gdsp_stream (stream);
-	if ((mode == GDSP_FIR_EXACT) && (getenv ("GDSP_PEAKS_FILTER") != NULL) && (strcmp (getenv ("GDSP_PEAKS_FILTER"), "1") == 0))
-		{
-		for (int i=0 ; i<nitems ; i++)
-			{
-			rc = gdsp_smooth_local_extrema (items[i].d_in, items[i].d_out, items[i].n, W, mode, N, wantMax, fill, stream);
-			if (rc != GDSP_OK) return rc;
-			}
-		return GDSP_OK;
-		}
+	// the filtered route (gdsp_peaks.hip): block sums rule out ~99.5 % of the bases, the rest are evaluated tap by tap in
+	// this mode's arithmetic -- the same bits, off the FP64 pipe; tie-heavy vectors fall to the direct kernel on the device
+	if (gdsp_peaks_filter_available (W, N))
+		return gdsp_peaks_filter_batch (items, nitems, plan->h_taps, mode == GDSP_FIR_FMA, N, wantMax, fill, stream);
 	if (mode == GDSP_FIR_FMA)
 		{ if (wantMax) fir_extrema_batch_launch<true, true>  (items, nitems, plan->h_taps, h, fill, s);
 		  else         fir_extrema_batch_launch<true, false> (items, nitems, plan->h_taps, h, fill, s); }

@@ -135,319 +135,6 @@ static void hann_launch (const double* d_in, double* d_out, uint32_t n, const do
 	hipLaunchKernelGGL ((hann_blocks_kernel<W>), dim3(ntiles), dim3(HN_THREADS), 0, s, d_in, d_out, n, ntiles, K, d_taps);
 	}
 
-// ------------------------------------------- smooth fused with localmax / localmin, filtered ----
-// `= smooth W=101 = localmax N` (BASELINE configs[2]) has to give the reference's bits: the survivors carry their
-// smoothed value and the neighbourhood test is a strict comparison of smoothed values, so every value that reaches the
-// output or decides a comparison must be the reference's own -- 101 multiplies and 100 adds, each rounded, in order.
-// Evaluating every base that way keeps the FP64 pipe busy 94 % of the time at 0.28 of the HBM rate
-// (fir_fixed_extrema_kernel).  But few bases need it.  The block sums above give every smoothed value to within
-// eps = KAPPA * sum|w_k x_k| of the reference's (KAPPA = 16 W 2^-52: sixteen times the bound the tolerance tests hold
-// the block sums to, forty times the worst ratio ever measured, profiles/r02_hann_adversarial.txt), and with an
-// interval [s - eps, s + eps] around each:
-//   - a base whose interval lies wholly below a neighbour's is beaten whatever the exact values are: fill, nothing more;
-//   - any other base is a candidate: its exact value is needed (it may be output), and so are the exact values of the
-//     neighbours whose intervals overlap its own; neighbours wholly below cannot beat it;
-//   - the candidates and those neighbours -- the local extrema of a smoothed signal and what ties with them, a few
-//     per cent of the bases -- are evaluated tap by tap in the reference's order, and the test is repeated on exact values.
-// The outcome is the reference's bit for bit; only the work is filtered.  sum|w_k x_k| is the smoothed value itself
-// where the tile holds no negative input (read depth: eps relative, and an all-zero window is exactly zero, so zero
-// stretches cost nothing); otherwise the largest magnitude of the tile bounds it (the taps add up to 1).  A tile holding
-// NaN, an infinity, a magnitude of 2^1017 or more (as above) or a nonzero magnitude below 2^-500 (products that
-// underflow) evaluates every base exactly.
-template <int W> struct HannTaps { double w[W]; };
-#define HX_LIST 1024                                    // doubles of the buffer that holds the block totals, then the list: 4096 entries of 2 bytes
-#define HX_HMAX 8                                       // neighbourhoods up to 17 bases take the unrolled interval test
-
-// HH = the neighbourhood's half width when it is at most HX_HMAX (the interval test then runs unrolled, one block of 16
-// bases per thread), 0 for any other (a loop).
-template <int W, bool FMA, bool MAX, int HH>
-__global__ __launch_bounds__(HN_THREADS)
-void hann_extrema_kernel (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t ntiles,
-                          HannConsts<W> K, HannTaps<W> taps, int h, double fill)
-	{
-	typedef HannGeom<W> G;
-	constexpr int    NWORD = (G::OUT + 31) / 32;
-	constexpr double KAPPA = 16.0 * W * 2.220446049250313e-16;
-	// the staged inputs stay (the exact evaluation reads them: from global memory, L2 hits as they are, it took 2.5 us
-	// per tile); the smoothed values -- approximate, then (where needed) exact -- get an image of their own.  78 KiB:
-	// two workgroups per CU, which is what the registers allow anyway.
-	__shared__ __attribute__((aligned(16))) double lds[HN_THREADS * HN_PITCH];
-	__shared__ __attribute__((aligned(16))) double totbuf[HX_LIST];    // block totals, later the list
-	__shared__ __attribute__((aligned(16))) double sm[(G::OUT / HN_G) * HN_PITCH];
-	__shared__ uint32_t candBits[NWORD], needBits[NWORD], markBits[NWORD];
-	__shared__ __attribute__((aligned(16))) uint32_t huge[HN_THREADS/64];
-	__shared__ uint32_t stats[HN_THREADS/64][2];
-	double (*tot)[HN_THREADS] = reinterpret_cast<double (*)[HN_THREADS]> (totbuf);
-	static_assert (sizeof(double) * 3 * HN_THREADS <= sizeof(double) * HX_LIST, "block totals need 6 KiB");
-	static_assert (G::OUT <= 4 * HX_LIST, "the list holds 2-byte entries");
-	static_assert (NWORD <= 4 * 32, "a wave scans 32 words of flags");
-	static_assert (G::OUT % HN_G == 0, "whole blocks");
-
-	const int      p         = threadIdx.x, lane = p & 63, wave = p >> 6;
-	const int      sh        = h & 1;                              // keeps the first staged index even
-	const int      stride    = G::OUT - 2*h - 2*sh;                // outputs kept per tile (even)
-	const uint32_t tile      = gdsp_xcd_tile (blockIdx.x, ntiles);
-	const int64_t  keepStart = (int64_t) tile * stride;            // first output this tile stores
-	const int64_t  compStart = keepStart - h - sh;                 // first smoothed value it computes (even)
-	const int64_t  e0        = compStart - G::LEAD;
-	const bool     live      = (p >= G::HALO_L) && (p < HN_THREADS - G::HALO_R);
-	const int      blk       = p - G::HALO_L;                      // the block of smoothed values a live thread holds
-	const double   never     = MAX? -DBL_MAX : DBL_MAX;            // what a position outside the vector holds: it beats nothing
-	// smoothed values [validLo, validHi) of the tile lie inside the vector (compStart < 0 only in the first tile)
-	const int      validLo   = (compStart < 0)? (int) -compStart : 0;
-	const int      validHi   = (compStart + G::OUT <= (int64_t) n)? G::OUT : (int) ((int64_t) n - compStart);
-
-	if (p < NWORD) { candBits[p] = 0;  needBits[p] = 0;  markBits[p] = 0; }       // (the barriers of the block sums come before their first use)
-	double acc[HN_G];
-	bool direct = hann_tile_sums<W, true> (lds, tot, huge, in, n, e0, K, acc, stats);
-
-	// what kind of tile: any sign bit set, any nonzero magnitude below 2^-500, the largest magnitude
-	uint32_t bigAll = 0, flagsAll = 0;
-#pragma unroll
-	for (int w=0 ; w<HN_THREADS/64 ; w++) { bigAll = max (bigAll, stats[w][0]);  flagsAll |= stats[w][1]; }
-	if (flagsAll & 2u) direct = true;
-	const bool   nonneg = ((flagsAll & 1u) == 0);
-	const double amax   = __longlong_as_double (((long long) (bigAll | 0x000FFFFFu) << 32) | 0xFFFFFFFFll);   // >= every |x| of the tile
-	const double epsAbs = KAPPA * amax;
-	auto eps = [&] (double v) { return nonneg? KAPPA * fabs (v) : epsAbs; };
-	// `a certainly beats b`: a's interval wholly beyond b's.  Without negative inputs every smoothed value is >= 0 (the
-	// stand-in for "outside the vector" aside, which these forms also treat as beating nothing) and the intervals are relative
-	const double shrink = 1.0 - KAPPA, grow = 1.0 + KAPPA, eps2 = 2.0 * epsAbs * grow;
-	auto beats = [&] (double a, double b)
-		{
-		if (MAX) return nonneg? (a * shrink > b * grow) : (a - eps2 > b);
-		else     return nonneg? (a * grow < b * shrink) : (a + eps2 < b);
-		};
-
-	// ---- approximate smoothed values (or, in a tile evaluated exactly, every base a candidate)
-	if (live)
-		{
-		double*  mine = sm + blk * HN_PITCH;
-		uint32_t bits = 0;
-#pragma unroll
-		for (int u=0 ; u<HN_G ; u++)
-			{
-			const int  c      = blk * HN_G + u;
-			const bool inside = (c >= validLo) && (c < validHi);
-			mine[u] = !inside? never : (acc[u] == 0.0)? 0.0 : acc[u];
-			if (inside) bits |= 1u << u;
-			}
-		if (direct)
-			{
-			atomicOr (&candBits[blk >> 1], bits << ((blk & 1) * 16));
-			atomicOr (&needBits[blk >> 1], bits << ((blk & 1) * 16));
-			}
-		}
-	__syncthreads ();
-
-	// The set bits of a bitmap of the tile, queued by one wave (two words per lane, the list in LDS); returns how many.
-	uint16_t* list = reinterpret_cast<uint16_t*> (totbuf);
-	auto queue = [&] (const uint32_t* bitsA, const uint32_t* bitsB)
-		{
-		int total = 0;
-#pragma unroll
-		for (int half=0 ; half<2 ; half++)
-			{
-			const int idx  = half * 64 + lane;
-			uint32_t  word = (idx < NWORD)? (bitsA[idx] | ((bitsB != NULL)? bitsB[idx] : 0u)) : 0u;
-			const int cnt  = __popc (word);
-			int       incl = cnt;
-			for (int d=1 ; d<64 ; d*=2) { const int up = __shfl_up (incl, d, 64);  if (lane >= d) incl += up; }
-			int off = total + incl - cnt;
-			total  += __shfl (incl, 63, 64);
-			while (word != 0) { const int b = __ffs ((int) word) - 1;  list[off++] = (uint16_t) (idx * 32 + b);  word &= word - 1; }
-			}
-		__builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier ();
-		return total;
-		};
-	auto wave_sync = [] () { __builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");  __builtin_amdgcn_wave_barrier (); };
-	auto at = [&] (int j) { return sm[j + (j >> 4)]; };
-	const int keepLo = h + sh;                                     // smoothed values [keepLo, keepHi) are this tile's outputs
-	const int keepHi = (h + sh + stride < validHi)? h + sh + stride : validHi;
-
-	// ---- who is certainly beaten (every base: the extreme of its neighbourhood, one interval test)
-	if (!direct && (HH > 0))
-		{
-		if (live)
-			{
-			// the block and HH values either side of it, in registers; (a block is 17 doubles on in the image)
-			double v[HN_G + 2*HX_HMAX];
-			const double* mine = sm + blk * HN_PITCH;
-#pragma unroll
-			for (int t=-HH ; t<HN_G+HH ; t++)
-				{
-				const int rel = t + ((t >= HN_G)? 1 : 0) - ((t < 0)? 1 : 0);
-				v[t + HH] = ((t < 0) && (blk == 0))? never : mine[rel];     // (what lies before the first block is no output's neighbour)
-				}
-			uint32_t isCand = 0, isNeed = 0;
-#pragma unroll
-			for (int u=0 ; u<HN_G ; u+=2)
-				{
-				double mid = v[u + 1];
-#pragma unroll
-				for (int k=2 ; k<=2*HH ; k++) mid = MAX? fmax (mid, v[u + k]) : fmin (mid, v[u + k]);
-				const double ext0 = MAX? fmax (v[u], mid) : fmin (v[u], mid);
-				const double ext1 = MAX? fmax (mid, v[u + 2*HH + 1]) : fmin (mid, v[u + 2*HH + 1]);
-#pragma unroll
-				for (int q=0 ; q<2 ; q++)
-					{
-					const int    c = blk * HN_G + u + q;
-					const double x = v[u + q + HH], ext = q? ext1 : ext0;
-					// (the extreme of the window includes the base itself, which never beats itself under these tests)
-					const bool beaten = beats (ext, x);
-					const bool kept   = (c >= keepLo) && (c < keepHi);
-					if (kept && !beaten)
-						{
-						isCand |= 1u << (u + q);
-						if (!(nonneg && (x == 0.0))) isNeed |= 1u << (u + q);   // (an all-zero window is exactly zero, and only a tie can meet it)
-						}
-					}
-				}
-			if (isCand) atomicOr (&candBits[blk >> 1], isCand << ((blk & 1) * 16));
-			if (isNeed) atomicOr (&needBits[blk >> 1], isNeed << ((blk & 1) * 16));
-			}
-		}
-	else if (!direct)
-		{
-		for (int o = 2*p ; o < stride ; o += 2*HN_THREADS)
-			{
-			const int c = o + h + sh;                                  // smoothed value of output o (even)
-			double e0v = at (c - h), e1v = at (c + h + 1), mid = at (c - h + 1);
-			for (int k=2 ; k<=2*h ; k++) mid = MAX? fmax (mid, at (c - h + k)) : fmin (mid, at (c - h + k));
-			if (h > 0) { e0v = MAX? fmax (e0v, mid) : fmin (e0v, mid);  e1v = MAX? fmax (mid, e1v) : fmin (mid, e1v); }
-			else       { e0v = at (c);  e1v = at (c + 1); }
-			uint32_t isCand = 0, isNeed = 0;
-#pragma unroll
-			for (int q=0 ; q<2 ; q++)
-				{
-				if (c + q >= keepHi) continue;
-				const double x = at (c + q), ext = q? e1v : e0v;
-				if (beats (ext, x)) continue;
-				isCand |= 1u << q;
-				if (!(nonneg && (x == 0.0))) isNeed |= 1u << q;
-				}
-			if (isCand) atomicOr (&candBits[c >> 5], isCand << (c & 31));     // (c is even: c + 1 sits in the same word)
-			if (isNeed) atomicOr (&needBits[c >> 5], isNeed << (c & 31));
-			}
-		}
-	__syncthreads ();
-
-	// From here on the work is a few dozen bases per tile, so one wave does it, with no barrier of the workgroup in its
-	// way, while the other three write the tile's bulk -- fill where a base is beaten, the (exact) zero of a candidate
-	// in a zero stretch -- and leave: every pair of outputs that holds no candidate awaiting an exact value.
-	double* dst = out + keepStart;
-	auto store_pair = [&] (int c)                                  // (c even: the pair shares a word of flags and a block of values)
-		{
-		const uint32_t two = candBits[c >> 5] >> (c & 31);
-		const double*  val = sm + c + (c >> 4);
-		const double   r0  = (two & 1u)? val[0] : fill;
-		const double   r1  = (two & 2u)? val[1] : fill;
-		if (c + 1 < keepHi) gdsp_st2 (reinterpret_cast<double2*> (dst + (c - keepLo)), make_double2 (r0, r1));
-		else                dst[c - keepLo] = r0;
-		};
-	if (wave != 0)
-		{
-		for (int c = keepLo + 2*(p - 64) ; c < keepHi ; c += 2*(HN_THREADS - 64))
-			{
-			const uint32_t pending = needBits[c >> 5] >> (c & 31);      // (flags of the interval test: nobody changes them any more)
-			if ((pending & 3u) == 0) store_pair (c);
-			}
-		return;
-		}
-
-	// ---- the neighbours whose intervals overlap a candidate's: their exact values are needed too
-	if (!direct)
-		{
-		const int total = queue (needBits, NULL);
-		for (int t=lane ; t<total ; t+=64)
-			{
-			const int    ci = list[t];
-			const double x  = at (ci), mineLo = x - eps (x), mineHi = x + eps (x);
-			for (int j=ci-h ; j<=ci+h ; j++)
-				{
-				const double vj = at (j);
-				const bool overlaps = MAX? (vj + eps (vj) > mineLo) : (vj - eps (vj) < mineHi);
-				if (overlaps && (j != ci) && !(nonneg && (vj == 0.0))) atomicOr (&markBits[j >> 5], 1u << (j & 31));
-				}
-			}
-		wave_sync ();
-		}
-
-	// ---- exact values where they are needed: tap by tap in the reference's order (sum.c:655-663)
-	const int nexact = queue (needBits, markBits);
-	for (int t=lane ; t<nexact ; t+=64)
-		{
-		const int c = list[t];
-		const int e = G::LO + c;                                   // the window's first staged element
-		// element e+k sits at e+k + ((e+k) >> 4) in the image: with e = 16 q + r that is 17 q + r + k + ((r + k) >> 4), and
-		// (r + k) >> 4 = (k >> 4) + ((k & 15) >= 16 - r).  Sixteen addresses per lane, one for each k & 15, leave every
-		// tap's read with a compile-time offset: one instruction instead of four.
-		const double* at16[16];
-#pragma unroll
-		for (int j=0 ; j<16 ; j++) at16[j] = lds + (e + (e >> 4)) + ((j >= 16 - (e & 15))? 1 : 0);
-		double a = 0.0;
-#pragma unroll
-		for (int k=0 ; k<W ; k++)
-			{
-			const double x = at16[k & 15][k + (k >> 4)];
-			a = FMA? __builtin_fma (taps.w[k], x, a) : a + taps.w[k] * x;
-			}
-		sm[c + (c >> 4)] = a;
-		}
-	wave_sync ();
-
-	// ---- the test again, on exact values: every base evaluated exactly strikes the candidates it beats
-	for (int t=lane ; t<nexact ; t+=64)
-		{
-		const int    cj = list[t];
-		const double vj = at (cj);
-		for (int i=cj-h ; i<=cj+h ; i++)
-			{
-			if ((i < 0) || (i >= G::OUT) || (i == cj)) continue;
-			if (((candBits[i >> 5] >> (i & 31)) & 1) == 0) continue;
-			const double vi = at (i);                                  // a candidate's value is exact: evaluated, or an exact zero
-			if (MAX? (vj > vi) : (vj < vi)) atomicAnd (&candBits[i >> 5], ~(1u << (i & 31)));
-			}
-		}
-	wave_sync ();
-
-	// ---- and the pairs of outputs that were waiting: once each, by the candidate that is first in its pair
-	for (int t=lane ; t<nexact ; t+=64)
-		{
-		const int c = list[t], c2 = c & ~1;
-		if ((c < keepLo) || (c >= keepHi)) continue;
-		const uint32_t pending = (needBits[c2 >> 5] >> (c2 & 31)) & 3u;   // (every base flagged by the interval test was a candidate then)
-		if (((needBits[c >> 5] >> (c & 31)) & 1u) == 0) continue;           // a neighbour evaluated for a comparison only
-		if ((c & 1) && (pending & 1u)) continue;                             // the pair is its first candidate's
-		store_pair (c2);
-		}
-	}
-
-// Opt-in (GDSP_PEAKS_FILTER=1, see gdsp_smooth_local_extrema).
-int gdsp_hann_extrema_apply (const double* d_in, double* d_out, uint32_t n, uint32_t W, const double* h_taps, int fma,
-                             uint32_t N, int wantMax, double fill, void* stream)
-	{
-	GDSP_REQUIRE (W == 101, "filtered smooth+extrema is built for W = 101");
-	GDSP_REQUIRE (!fma, "the filtered kernel is built for the reference's arithmetic");
-	typedef HannGeom<101> G;
-	const int h = (int) ((N - 1) / 2);
-	GDSP_REQUIRE ((h >= 0) && (h <= 64), "neighbourhood too wide for the fused kernel");
-	HannConsts<101> K;
-	hann_consts<101> (K);
-	HannTaps<101> taps;
-	memcpy (taps.w, h_taps, sizeof(taps.w));
-	const int      stride = G::OUT - 2*h - 2*(h & 1);
-	const uint32_t ntiles = (uint32_t) (((uint64_t) n + stride - 1) / stride);
-	hipStream_t    s      = gdsp_stream (stream);
-#define HX_LAUNCH_H(MM, HHH) hipLaunchKernelGGL ((hann_extrema_kernel<101, false, MM, HHH>), dim3(ntiles), dim3(HN_THREADS), 0, s, d_in, d_out, n, ntiles, K, taps, h, fill)
-	if (wantMax) { if (h == 5) HX_LAUNCH_H (true, 5);   else HX_LAUNCH_H (true, 0); }
-	else         { if (h == 5) HX_LAUNCH_H (false, 5);  else HX_LAUNCH_H (false, 0); }
-#undef HX_LAUNCH_H
-	GDSP_LAUNCH_CHECK ();
-	return GDSP_OK;
-	}
-
 // ------------------------------------------------------ any window, 81 .. 2001 ----
 // The same evaluation with the geometry as run-time numbers: dq, dr, the number of whole blocks
 // between (their rotations come from a small table in HBM, read as scalars), the halo.  Only the

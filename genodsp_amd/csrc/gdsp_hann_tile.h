@@ -22,7 +22,7 @@ __device__ __forceinline__ uint32_t hann_magnitude_hi (double x)
 // A tile the block sums must not touch: out[o] = sum_k taps[k] * x[first + o + k], ascending k, one fused
 // multiply-add per tap (what fir_*_kernel<.., FMA> does).  Output o = p + 256*i; results go back into the
 // LDS image like the block-sum results.  Rare (a tile holding inf / NaN / |x| >= 2^1017), so not tuned.
-static __device__ __noinline__ void hann_direct_tile (double* lds, const double* __restrict__ taps, int W, int first, int nout,
+__attribute__((unused)) static __device__ __noinline__ void hann_direct_tile (double* lds, const double* __restrict__ taps, int W, int first, int nout,
                                                int nthreads = HN_THREADS)
 	{
 	const int p = threadIdx.x;

@@ -1,0 +1,527 @@
+// gdsp_peaks.hip -- `= smooth W=101 = localmax|localmin N` (BASELINE configs[2]) in the reference's arithmetic, off the
+// FP64 pipe: a filter at the speed of the block sums, then exact taps for the few bases the filter cannot decide.
+//
+// What has to come out is the reference's, bit for bit (sum.c:651-663 feeding minmax.c:1183-1227 / :981-1022): a
+// surviving base carries its smoothed value -- 101 multiplies and 100 adds, each rounded, in order -- and the test is a
+// strict comparison of such values.  Evaluating every base that way keeps the FP64 pipe busy at 0.28 of the HBM rate
+// (fir_fixed_extrema_kernel, gdsp_fir.hip).  But the block sums of gdsp_hann_tile.h give every smoothed value to within
+// eps = KAPPA * sum|w_k x_k| (KAPPA = 16 W 2^-52: sixteen times the bound the tolerance tests hold the block sums to),
+// and an interval [s - eps, s + eps] around each settles almost everything:
+//   * a base whose interval lies wholly beyond a neighbour's is beaten whatever the exact values are -> `fill`;
+//   * a base of an all-zero window is exactly zero, and so are neighbours that do not beat it -> 0, no arithmetic;
+//   * the rest -- the local extrema of a smoothed signal and what ties with them, ~0.5 % of the bases of real-valued
+//     coverage -- are QUEUED (their positions, in HBM).
+// Four launches per table of vectors, no host round trip:
+//   P  probe: the filter on 64 tiles spread over each vector, counting only.  A vector on which more than 3/256 of the
+//      bases stay undecided (piecewise-constant read depth smooths into runs of exactly equal values: every base a
+//      tie) takes the direct kernel instead; every block of the later launches reads the same counters and decides alike.
+//   A  filter: block sums -> interval test -> `fill` / 0 written with 16-byte stores, undecided bases queued in the tile's
+//      own strip in HBM (16-bit tile-local indices; an LDS atomic per wave).  LDS and registers of hann_blocks_kernel:
+//      3 workgroups per CU.
+//   B  exact: one workgroup per tile, 16 lanes per queued base: its 2h+1 neighbours' windows staged in LDS, one lane per
+//      neighbour evaluates tap by tap in the reference's order, the test is repeated on exact values, the base is rewritten.
+//   C  the direct fused kernel, gated: its blocks leave at once unless the vector's probe chose it or its queue overflowed.
+// Bit-identical to the direct kernel on every input (tests: ties, mirror images, zero stretches, mixed signs, NaN / inf,
+// tile seams, whole chromosomes).  A tile holding NaN, an infinity, a magnitude >= 2^1017 or a nonzero magnitude below
+// 2^-500 (products that underflow) queues every base.
+
+#include <string.h>
+#include <stdlib.h>
+#include <mutex>
+#include <vector>
+#include "gdsp_hann_tile.h"
+
+#define PK_HMAX        7                                  // neighbourhoods up to 15 bases: one lane of a 16-lane group per neighbour
+#define PK_PROBE_TILES 64
+#define PK_TILE_CAP    192                                // undecided bases a tile can queue (4.8 % of its 3974: nine times the average on real-valued coverage)
+#define PK_WHOLE_TILE  0xFFFFFFFFu                        // a tile's count when every one of its bases is to be evaluated
+#define PK_GROUP       16                                 // lanes per queued base in the exact kernel
+#define PK_XS          144                                // doubles per group strip: 2h+1 + 100 <= 117 staged inputs; 144 puts the four groups of a wave 32 banks apart
+
+template <int W> struct PeaksTaps { double w[W]; };
+// Queues: one strip of PK_TILE_CAP 16-bit tile-local indices per tile of the grid, and the tile's count beside it -- a
+// workgroup owns its strip, so queueing costs an LDS atomic per wave and no global one (a per-vector queue with one global
+// atomic per wave held the filter at half its speed: 3 M atomics on 24 addresses, from all eight XCDs).
+
+// route: 0 = the probe decides; 1 = the filter whatever the probe counts, 2 = the direct kernel (GDSP_PEAKS_ROUTE: tests)
+__global__ void peaks_init_kernel (GdspPeaksCtl* ctl, GdspBatch B, uint32_t stride, int route)
+	{
+	const uint32_t v = threadIdx.x;
+	if (v >= GDSP_BATCH_MAX) return;
+	const uint32_t tiles = B.tile0[v+1] - B.tile0[v];
+	GdspPeaksCtl c;
+	c.count = 0;  c.overflow = 0;  c.probe = 0;
+	c.sampled = 4 * ((tiles < PK_PROBE_TILES)? tiles : PK_PROBE_TILES) * stride;     // quarter bases, like the probe's count
+	if (route == 1) c.sampled = 0x40000000u;                       // (a probe counts at most 4 x 64 x 3984 quarter bases: gdsp_peaks_takes_direct never says yes)
+	if (route == 2) { c.sampled = 0;  c.probe = 0x00800000u; }
+	ctl[v] = c;
+	}
+
+// One tile of the filter.  PROBE: count the bases that need exact taps into ctl->probe and write nothing.
+//
+// The smoothed values never leave the registers: a thread holds the 16 of its block, gets the HH either side from its
+// neighbours by wave shifts (the two lanes at a wave's ends through a few words of LDS), and the staged INPUTS stay in
+// the LDS image -- so a base that is certainly a peak (its interval wholly beyond every neighbour's: the usual case on
+// real-valued coverage) gets its exact value right here, one lane per base, tap by tap from that image, in the
+// reference's order.  Only bases that tie or nearly tie with a neighbour -- the comparison itself needs exact values --
+// go to the tile's strip in HBM for the exact kernel.
+#define PK_SURE_CAP 256                                       // certain peaks a tile evaluates in place (one lane each); more go to the strip
+template <int W, bool FMA, bool MAX, int HH, bool PROBE>
+__device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t tile,
+                                                   const HannConsts<W>& K, const double* __restrict__ d_taps, double fill, GdspPeaksCtl* ctl,
+                                                   uint16_t* __restrict__ strip, uint32_t* __restrict__ tileCount, uint32_t cap,
+                                                   uint32_t* __restrict__ tileList, uint32_t gt, int dbg = 0)
+	{
+	typedef HannGeom<W> G;
+	constexpr double KAPPA = 16.0 * W * 2.220446049250313e-16;
+	constexpr int    h = HH, sh = HH & 1;                          // sh keeps the first staged index even
+	constexpr int    stride = G::OUT - 2*h - 2*sh;                 // outputs kept per tile (even)
+	constexpr int    NW = HN_THREADS / 64;
+	__shared__ __attribute__((aligned(16))) double lds[HN_THREADS * HN_PITCH];
+	__shared__ double tot[3][HN_THREADS];
+	__shared__ __attribute__((aligned(16))) uint32_t huge[NW];
+	__shared__ uint32_t stats[NW][2];
+	__shared__ double   edgeLo[NW][HH], edgeHi[NW][HH];            // a wave's first block's first HH values, its last block's last HH
+	__shared__ uint32_t zeroBits[HN_THREADS/2], sureBits[HN_THREADS/2];   // per block of 16 outputs (16 bits each): exact zeros; peaks evaluated in place
+	__shared__ uint16_t sureList[PK_SURE_CAP];
+	__shared__ double   tapsLds[W];                                // the window, for the exact values (as scalar operands its 202 words crowd out the block sums' constants)
+	__shared__ uint32_t nsure, queued;
+
+	const int      p         = threadIdx.x, lane = p & 63, wave = p >> 6;
+	const int64_t  keepStart = (int64_t) tile * stride;            // first output this tile stores
+	const int64_t  compStart = keepStart - h - sh;                 // first smoothed value it computes (even)
+	const int64_t  e0        = compStart - G::LEAD;
+	const bool     live      = (p >= G::HALO_L) && (p < HN_THREADS - G::HALO_R);
+	const int      blk       = p - G::HALO_L;                      // the block of smoothed values a live thread holds
+	const double   never     = MAX? -DBL_MAX : DBL_MAX;            // what a position outside the vector holds: it beats nothing
+	const int      validLo   = (compStart < 0)? (int) -compStart : 0;
+	const int      validHi   = (compStart + G::OUT <= (int64_t) n)? G::OUT : (int) ((int64_t) n - compStart);
+	const int      keepLo    = h + sh;                             // smoothed values [keepLo, keepHi) are this tile's outputs
+	const int      keepHi    = (keepLo + stride < validHi)? keepLo + stride : validHi;
+
+	if (p == 0) { nsure = 0;  queued = 0; }                        // (the barriers of the block sums come before their first use)
+	if (!PROBE && (p < W)) tapsLds[p] = d_taps[p];
+	double acc[HN_G];
+	bool direct = hann_tile_sums<W, true> (lds, tot, huge, in, n, e0, K, acc, stats);
+
+	uint32_t bigAll = 0, flagsAll = 0;
+#pragma unroll
+	for (int w=0 ; w<NW ; w++) { bigAll = max (bigAll, stats[w][0]);  flagsAll |= stats[w][1]; }
+	if (flagsAll & 2u) direct = true;
+	const bool   nonneg = ((flagsAll & 1u) == 0);
+	const double amax   = __longlong_as_double (((long long) (bigAll | 0x000FFFFFu) << 32) | 0xFFFFFFFFll);   // >= every |x| of the tile
+	const double epsAbs = KAPPA * amax;
+	// `a certainly beats b`: a's interval wholly beyond b's.  Without negative inputs every smoothed value is >= 0 and the
+	// intervals are relative (sum|w x| is the value itself); otherwise the largest magnitude of the tile bounds sum|w x|
+	const double shrink = 1.0 - KAPPA, grow = 1.0 + KAPPA, eps2 = 2.0 * epsAbs * grow;
+	auto beats = [&] (double a, double b)
+		{
+		if (MAX) return nonneg? (a * shrink > b * grow) : (a - eps2 > b);
+		else     return nonneg? (a * grow < b * shrink) : (a + eps2 < b);
+		};
+
+	// ---- the block and HH values either side of it, in registers
+	double v[HN_G + 2*HH];
+#pragma unroll
+	for (int u=0 ; u<HN_G ; u++)
+		{
+		const int  c      = blk * HN_G + u;
+		const bool inside = live && (c >= validLo) && (c < validHi);
+		v[HH + u] = !inside? never : (acc[u] == 0.0)? 0.0 : acc[u];
+		}
+	if (lane == 0)  { for (int t=0 ; t<HH ; t++) edgeLo[wave][t] = v[HH + t]; }
+	if (lane == 63) { for (int t=0 ; t<HH ; t++) edgeHi[wave][t] = v[HN_G + t]; }
+#pragma unroll
+	for (int t=0 ; t<HH ; t++)
+		{
+		v[t]             = __shfl_up   (v[HN_G + t], 1, 64);       // the previous block's last HH values
+		v[HN_G + HH + t] = __shfl_down (v[HH + t],   1, 64);       // the next block's first HH
+		}
+	__syncthreads ();
+#pragma unroll
+	for (int t=0 ; t<HH ; t++)
+		{
+		if (lane == 0)  v[t]             = (wave == 0)?    never : edgeHi[wave-1][t];
+		if (lane == 63) v[HN_G + HH + t] = (wave == NW-1)? never : edgeLo[wave+1][t];
+		}
+
+	// ---- the interval test
+	uint32_t isNeed = 0, isZero = 0, isSure = 0;
+	if (live && !(dbg & 2))
+		{
+		if (direct)
+			{
+#pragma unroll
+			for (int u=0 ; u<HN_G ; u++) { const int c = blk * HN_G + u;  if ((c >= keepLo) && (c < keepHi)) isNeed |= 1u << u; }
+			}
+		else
+			{
+			// the extreme of the HH values before a base and of the HH after it (the base itself left out), for all 16 bases
+			// at once: extremes of runs of 2, 4, ... values by doubling, a run of HH put together from those
+			double run[HN_G + HH + 1];                             // run[i] = extreme of v[i .. i+HH-1]
+				{
+				constexpr int NV = HN_G + 2*HH;
+				double m2[NV], m4[NV];
+#pragma unroll
+				for (int i=0 ; i+1<NV ; i++) m2[i] = MAX? fmax (v[i], v[i+1]) : fmin (v[i], v[i+1]);
+#pragma unroll
+				for (int i=0 ; i+3<NV ; i++) m4[i] = MAX? fmax (m2[i], m2[i+2]) : fmin (m2[i], m2[i+2]);
+#pragma unroll
+				for (int i=0 ; i<HN_G+HH+1 ; i++)
+					{
+					double r;
+					if      (HH == 1) r = v[i];
+					else if (HH == 2) r = m2[i];
+					else if (HH == 3) r = MAX? fmax (m2[i], v[i+2])    : fmin (m2[i], v[i+2]);
+					else if (HH == 4) r = m4[i];
+					else if (HH == 5) r = MAX? fmax (m4[i], v[i+4])    : fmin (m4[i], v[i+4]);
+					else if (HH == 6) r = MAX? fmax (m4[i], m2[i+4])   : fmin (m4[i], m2[i+4]);
+					else              r = MAX? fmax (m4[i], m4[i+3])   : fmin (m4[i], m4[i+3]);      // HH == 7: two runs of 4 overlapping by one
+					run[i] = r;
+					}
+				}
+#pragma unroll
+			for (int u=0 ; u<HN_G ; u++)
+				{
+				const int    c   = blk * HN_G + u;
+				const double ext = MAX? fmax (run[u], run[u + HH + 1]) : fmin (run[u], run[u + HH + 1]);
+				const double x   = v[u + HH];
+				if ((c < keepLo) || (c >= keepHi) || beats (ext, x)) continue;      // not this tile's, or certainly beaten: `fill`
+				if (nonneg && (x == 0.0)) isZero |= 1u << u;           // an all-zero window is exactly zero, and only a tie can meet it
+				else if (beats (x, ext))  isSure |= 1u << u;           // certainly the extreme of its neighbourhood: only its exact value is missing
+				else                      isNeed |= 1u << u;           // ties, near-ties: the comparison needs exact values
+				}
+			}
+		}
+
+	if (PROBE)
+		{
+		int cnt = 4 * __popc (isNeed) + __popc (isSure);           // in quarter bases: a certain peak costs a lane, an undecided base sixteen
+		for (int off=32 ; off>0 ; off>>=1) cnt += __shfl_xor (cnt, off, 64);
+		if ((lane == 0) && (cnt != 0)) atomicAdd (&ctl->probe, (uint32_t) cnt);   // (ctl->sampled is in quarter bases too)
+		return;
+		}
+
+	// ---- certain peaks: a list in LDS (what does not fit joins the undecided)
+	if (!direct)
+		{
+		const int cnt = __popc (isSure);
+		int incl = cnt;
+		for (int d=1 ; d<64 ; d*=2) { const int up = __shfl_up (incl, d, 64);  if (lane >= d) incl += up; }
+		const int waveTotal = __shfl (incl, 63, 64);
+		if (waveTotal != 0)                                        // (uniform over the wave)
+			{
+			uint32_t base = 0;
+			if (lane == 0) base = atomicAdd (&nsure, (uint32_t) waveTotal);
+			base = (uint32_t) __shfl ((int) base, 0, 64);
+			uint32_t at = base + (uint32_t) (incl - cnt);
+			uint32_t word = isSure;
+			while (word != 0)
+				{
+				const int u = __ffs ((int) word) - 1;
+				word &= word - 1;
+				if (at < PK_SURE_CAP) sureList[at] = (uint16_t) (blk * HN_G + u);
+				else                  { isSure &= ~(1u << u);  isNeed |= 1u << u; }
+				at++;
+				}
+			}
+		}
+	// ---- undecided bases: tile-local indices into the tile's strip (a tile that must be evaluated whole queues nothing)
+	if (!direct)
+		{
+		const int cnt = __popc (isNeed);
+		int incl = cnt;
+		for (int d=1 ; d<64 ; d*=2) { const int up = __shfl_up (incl, d, 64);  if (lane >= d) incl += up; }
+		const int waveTotal = __shfl (incl, 63, 64);
+		if (waveTotal != 0)
+			{
+			uint32_t base = 0;
+			if (lane == 0) base = atomicAdd (&queued, (uint32_t) waveTotal);
+			base = (uint32_t) __shfl ((int) base, 0, 64);
+			uint32_t at = base + (uint32_t) (incl - cnt);
+			uint32_t word = isNeed;
+			while (word != 0)
+				{
+				const int u = __ffs ((int) word) - 1;
+				word &= word - 1;
+				if (at < cap) strip[at] = (uint16_t) (blk * HN_G + u);
+				at++;
+				}
+			}
+		}
+	if (live)                                                      // every block of 16 has its own half word: plain stores
+		{
+		reinterpret_cast<uint16_t*> (zeroBits)[blk] = (uint16_t) isZero;
+		reinterpret_cast<uint16_t*> (sureBits)[blk] = (uint16_t) (direct? 0u : isSure);
+		}
+	__syncthreads ();
+	if (p == 0)
+		{
+		const uint32_t q = direct? PK_WHOLE_TILE : queued;
+		*tileCount = q;
+		if (q != 0) tileList[atomicAdd (&ctl->count, 1u)] = gt;    // (few tiles have anything for the exact kernel)
+		if (!direct && (queued > cap)) ctl->overflow = 1;          // more undecided bases than a strip holds: the vector goes through the direct kernel
+		}
+
+	// ---- exact values of the certain peaks, one lane each, from the staged inputs: tap by tap in the reference's order
+	//      (sum.c:655-663); the base is written by the lane that evaluated it
+	const int sure = (int) ((nsure < PK_SURE_CAP)? nsure : PK_SURE_CAP);
+	if ((p < sure) && !(dbg & 1))
+		{
+		const int c = sureList[p];
+		const int e = G::LO + c;                                   // the window's first staged element
+		// element e+k sits at e+k + ((e+k) >> 4) in the image: with e = 16 q + r that is 17 q + r + k + ((r + k) >> 4), and
+		// (r + k) >> 4 = (k >> 4) + ((k & 15) >= 16 - r).  Sixteen addresses per lane, one for each k & 15, leave every
+		// tap's read with a compile-time offset.
+		const double* at16[16];
+#pragma unroll
+		for (int j=0 ; j<16 ; j++) at16[j] = lds + (e + (e >> 4)) + ((j >= 16 - (e & 15))? 1 : 0);
+		double a = 0.0;
+#pragma unroll
+		for (int k=0 ; k<W ; k++)
+			{
+			const double x = at16[k & 15][k + (k >> 4)];
+			a = FMA? __builtin_fma (tapsLds[k], x, a) : a + tapsLds[k] * x;
+			}
+		out[compStart + c] = a;
+		}
+
+	// ---- the tile's other outputs: zero where an exact zero stands, `fill` elsewhere (a queued base is rewritten by the
+	//      exact kernel); pairs, 16 bytes per lane; a pair that holds a certain peak leaves that element to its lane
+	double* dst = out + keepStart;
+	for (int c = keepLo + 2*p ; c < keepHi ; c += 2*HN_THREADS)    // (keepLo is even)
+		{
+		const uint32_t two  = zeroBits[c >> 5] >> (c & 31);
+		const uint32_t skip = (sureBits[c >> 5] >> (c & 31)) & 3u;
+		const double r0 = (two & 1u)? 0.0 : fill, r1 = (two & 2u)? 0.0 : fill;
+		if ((skip == 0) && (c + 1 < keepHi)) gdsp_st2 (reinterpret_cast<double2*> (dst + (c - keepLo)), make_double2 (r0, r1));
+		else
+			{
+			if ((skip & 1u) == 0)                        dst[c - keepLo]     = r0;
+			if (((skip & 2u) == 0) && (c + 1 < keepHi)) dst[c - keepLo + 1] = r1;
+			}
+		}
+	}
+
+template <int W, bool MAX, int HH>
+__global__ __launch_bounds__(HN_THREADS)
+void peaks_probe_kernel (GdspBatch B, HannConsts<W> K, GdspPeaksCtl* ctl)
+	{
+	const uint32_t v = blockIdx.x / PK_PROBE_TILES, j = blockIdx.x % PK_PROBE_TILES;
+	const uint32_t tiles = B.tile0[v+1] - B.tile0[v];
+	const uint32_t take  = (tiles < PK_PROBE_TILES)? tiles : PK_PROBE_TILES;
+	if (j >= take) return;
+	const uint32_t tile = (uint32_t) (((uint64_t) j * tiles) / take);
+	peaks_filter_tile<W, false, MAX, HH, true> (B.in[v], NULL, B.n[v], tile, K, NULL, 0.0, &ctl[v], NULL, NULL, 0, NULL, 0);
+	}
+
+template <int W, bool FMA, bool MAX, int HH>
+__global__ __launch_bounds__(HN_THREADS) __attribute__((amdgpu_waves_per_eu(3)))     // three workgroups per CU, like hann_blocks_kernel
+void peaks_filter_kernel (GdspBatch B, HannConsts<W> K, const double* __restrict__ d_taps, double fill, GdspPeaksCtl* ctl, uint16_t* strips,
+                          uint32_t* counts, uint32_t cap, uint32_t* tileList, int dbg)
+	{
+	const double* in;  double* out;  uint32_t n, v;
+	const uint32_t tile = gdsp_batch_tile (B, in, out, n, &v);
+	if (gdsp_peaks_takes_direct (ctl[v])) return;                  // (the probe is complete: an earlier launch on the same stream)
+	const uint32_t gt = B.tile0[v] + tile;                         // the tile's number in the grid: its strip and its count
+	peaks_filter_tile<W, FMA, MAX, HH, false> (in, out, n, tile, K, d_taps, fill, &ctl[v], strips + (size_t) gt * cap, counts + gt, cap,
+	                                           tileList + B.tile0[v], gt, dbg);
+	}
+
+// The exact kernel, for the bases whose comparison needs exact values (ties and near-ties): a workgroup takes a tile from
+// its vector's list of tiles that queued something, 16 lanes per queued base i.  Inputs x[i-h-H .. i+h+H] (zero outside
+// the vector) are staged in the group's LDS strip; lane L < 2h+1 evaluates the smoothed value of base i-h+L tap by tap,
+// ascending, multiply then add (FMA: fused, for --smooth=fma) -- the reference's operations in the reference's order,
+// sum.c:655-663; the test of minmax.c:1195-1216 follows on those values.
+template <int W, bool FMA, bool MAX>
+__global__ __launch_bounds__(HN_THREADS)
+void peaks_exact_kernel (GdspBatch B, PeaksTaps<W> taps, int h, double fill, const GdspPeaksCtl* __restrict__ ctl,
+                         const uint16_t* __restrict__ strips, const uint32_t* __restrict__ counts, uint32_t cap,
+                         const uint32_t* __restrict__ tileList)
+	{
+	typedef HannGeom<W> G;
+	constexpr int H = (W - 1) / 2;
+	constexpr int GROUPS = HN_THREADS / PK_GROUP;
+	__shared__ double xs[GROUPS][PK_XS];
+	const int    sh = h & 1, stride = G::OUT - 2*h - 2*sh, keepLo = h + sh;
+	const int    grp = threadIdx.x / PK_GROUP, L = threadIdx.x % PK_GROUP;
+	const double never = MAX? -INFINITY : INFINITY;
+	const int    need = 2*h + 1 + 2*H;                             // staged inputs per base
+
+	for (uint32_t v=0 ; v<B.nvec ; v++)
+		{
+		const GdspPeaksCtl c = ctl[v];
+		if (gdsp_peaks_takes_direct (c) || (c.overflow != 0)) continue;      // the direct kernel rewrites the whole vector
+		const double*  in  = B.in[v];
+		double*        out = B.out[v];
+		const int64_t  n   = (int64_t) B.n[v];
+		for (uint32_t k=blockIdx.x ; k<c.count ; k+=gridDim.x)
+			{
+			const uint32_t gt   = tileList[B.tile0[v] + k];
+			const uint32_t tile = gt - B.tile0[v];
+			uint32_t count = counts[gt];
+			const int64_t keepStart = (int64_t) tile * stride, compStart = keepStart - keepLo;
+			const bool    whole = (count == PK_WHOLE_TILE);
+			if (whole) count = (uint32_t) ((keepStart + stride <= n)? stride : (n - keepStart));
+			const uint16_t* strip = strips + (size_t) gt * cap;
+			// every group of a wave makes the same number of trips (the last ones idle), so the wave-level barriers below meet
+			const uint32_t trips = (count + GROUPS - 1) / GROUPS;
+			for (uint32_t t=0 ; t<trips ; t++)
+				{
+				const uint32_t idx  = t * GROUPS + grp;
+				const bool     busy = (idx < count);
+				const int64_t  i    = !busy? 0 : whole? keepStart + idx : compStart + strip[idx];
+				const int64_t  g0   = i - h - H;
+				if (busy)
+					{
+					for (int e=L ; e<need ; e+=PK_GROUP)
+						{
+						const int64_t g = g0 + e;
+						xs[grp][e] = ((g >= 0) && (g < n))? in[g] : 0.0;
+						}
+					}
+				__builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier ();
+				double a = 0.0;
+				if (busy && (L <= 2*h))
+					{
+					const double* x = &xs[grp][L];
+#pragma unroll
+					for (int kk=0 ; kk<W ; kk++)
+						a = FMA? __builtin_fma (taps.w[kk], x[kk], a) : a + taps.w[kk] * x[kk];
+					}
+				const int64_t j = i - h + L;
+				const double  s = (busy && (L <= 2*h) && (j >= 0) && (j < n))? a : never;
+				const double  centre = __shfl (s, h, PK_GROUP);
+				double ext = (L == h)? never : s;                      // the extreme of the neighbours
+#pragma unroll
+				for (int m=PK_GROUP/2 ; m>0 ; m>>=1)
+					{
+					const double o = __shfl_xor (ext, m, PK_GROUP);
+					ext = MAX? fmax (ext, o) : fmin (ext, o);
+					}
+				if (busy && (L == h)) out[i] = (MAX? (ext > centre) : (ext < centre))? fill : centre;
+				__builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier ();                          // the strip is free for the next trip
+				}
+			}
+		}
+	}
+
+// ------------------------------------------------------------------- host ----
+struct PeaksWork { int device;  void* stream;  GdspPeaksCtl* ctl;  uint16_t* strips;  uint32_t* counts;  uint32_t* tileList;  size_t tiles; };
+static std::vector<PeaksWork> peaksWork;
+static std::mutex peaksWorkLock;
+
+// the control words, strips and counts of (device, stream): allocated on first use, grown when a table has more tiles
+static int peaks_work (void* stream, size_t tiles, PeaksWork* out)
+	{
+	int device = 0;
+	GDSP_HIP_TRY (hipGetDevice (&device));
+	std::lock_guard<std::mutex> hold (peaksWorkLock);
+	PeaksWork* w = NULL;
+	for (PeaksWork& e : peaksWork) { if ((e.device == device) && (e.stream == stream)) w = &e; }
+	if (w == NULL)
+		{
+		PeaksWork e = { device, stream, NULL, NULL, NULL, NULL, 0 };
+		GDSP_HIP_TRY (hipMalloc ((void**) &e.ctl, GDSP_BATCH_MAX * sizeof(GdspPeaksCtl)));
+		peaksWork.push_back (e);
+		w = &peaksWork.back ();
+		}
+	if (w->tiles < tiles)
+		{
+		if (w->strips != NULL)
+			{
+			GDSP_HIP_TRY (hipStreamSynchronize (gdsp_stream (stream)));        // (a launch in flight may still read them)
+			GDSP_HIP_TRY (hipFree (w->strips));
+			GDSP_HIP_TRY (hipFree (w->counts));
+			GDSP_HIP_TRY (hipFree (w->tileList));
+			w->strips = NULL;  w->counts = NULL;  w->tileList = NULL;  w->tiles = 0;
+			}
+		const size_t want = tiles + tiles / 8 + 64;
+		GDSP_HIP_TRY (hipMalloc ((void**) &w->strips, want * PK_TILE_CAP * sizeof(uint16_t)));
+		GDSP_HIP_TRY (hipMalloc ((void**) &w->counts, want * sizeof(uint32_t)));
+		GDSP_HIP_TRY (hipMalloc ((void**) &w->tileList, want * sizeof(uint32_t)));
+		w->tiles = want;
+		}
+	*out = *w;
+	return GDSP_OK;
+	}
+
+bool gdsp_peaks_filter_available (uint32_t W, uint32_t N)
+	{
+	const char* e = getenv ("GDSP_PEAKS_FILTER");                  // GDSP_PEAKS_FILTER=0: every base through the direct kernel (A/B, tests)
+	if ((e != NULL) && (strcmp (e, "0") == 0)) return false;
+	return (W == 101) && (N >= 3) && ((N - 1) / 2 <= PK_HMAX);
+	}
+
+template <bool MAX, int HH>
+static int peaks_launch (const gdsp_batch_item* items, int count, const HannConsts<101>& K, const PeaksTaps<101>& taps, int fma,
+                         double fill, const double* h_taps, void* stream)
+	{
+	typedef HannGeom<101> G;
+	constexpr int stride = G::OUT - 2*HH - 2*(HH & 1);
+	hipStream_t s = gdsp_stream (stream);
+	GdspBatch B;
+	gdsp_batch_make (B, items, count, [] (uint32_t n) { return ((uint64_t) n + stride - 1) / stride; });
+	// test hooks: GDSP_PEAKS_ROUTE=filter|direct overrides the probe, GDSP_PEAKS_QUEUE_CAP=<positions> shrinks every strip
+	// (a strip that overflows sends its vector through the direct kernel as well)
+	const char* routeEnv = getenv ("GDSP_PEAKS_ROUTE");
+	const int   route    = (routeEnv == NULL)? 0 : (strcmp (routeEnv, "filter") == 0)? 1 : (strcmp (routeEnv, "direct") == 0)? 2 : 0;
+	const char* capEnv   = getenv ("GDSP_PEAKS_QUEUE_CAP");
+	uint32_t    cap      = PK_TILE_CAP;
+	if ((capEnv != NULL) && (atoll (capEnv) >= 0) && (atoll (capEnv) < PK_TILE_CAP)) cap = (uint32_t) atoll (capEnv);
+	const uint32_t tiles = B.tile0[GDSP_BATCH_MAX];
+	PeaksWork w;
+	int rc = peaks_work (stream, tiles, &w);
+	if (rc != GDSP_OK) return rc;
+
+	hipLaunchKernelGGL (peaks_init_kernel, dim3(1), dim3(64), 0, s, w.ctl, B, (uint32_t) stride, route);
+	const double* d_taps = NULL;                                   // the reference's window on the device (gdsp_fir.hip: cached per device)
+	rc = gdsp_smooth_taps_device (101, &d_taps);
+	if (rc != GDSP_OK) return rc;
+	hipLaunchKernelGGL ((peaks_probe_kernel<101, MAX, HH>), dim3(count * PK_PROBE_TILES), dim3(HN_THREADS), 0, s, B, K, w.ctl);
+	const int exactBlocks = 4096;
+	const int dbg = getenv ("GDSP_PEAKS_DBG")? atoi (getenv ("GDSP_PEAKS_DBG")) : 0;
+	if (fma)
+		{
+		hipLaunchKernelGGL ((peaks_filter_kernel<101, true, MAX, HH>), dim3(tiles), dim3(HN_THREADS), 0, s, B, K, d_taps, fill, w.ctl, w.strips, w.counts, cap, w.tileList, dbg);
+		hipLaunchKernelGGL ((peaks_exact_kernel<101, true, MAX>), dim3(exactBlocks), dim3(HN_THREADS), 0, s, B, taps, HH, fill, w.ctl, w.strips, w.counts, cap, w.tileList);
+		}
+	else
+		{
+		hipLaunchKernelGGL ((peaks_filter_kernel<101, false, MAX, HH>), dim3(tiles), dim3(HN_THREADS), 0, s, B, K, d_taps, fill, w.ctl, w.strips, w.counts, cap, w.tileList, dbg);
+		hipLaunchKernelGGL ((peaks_exact_kernel<101, false, MAX>), dim3(exactBlocks), dim3(HN_THREADS), 0, s, B, taps, HH, fill, w.ctl, w.strips, w.counts, cap, w.tileList);
+		}
+	GDSP_LAUNCH_CHECK ();
+	return gdsp_fir_extrema_gated_launch (items, count, w.ctl, h_taps, fma, HH, MAX, fill, stream);
+	}
+
+int gdsp_peaks_filter_batch (const gdsp_batch_item* items, int nitems, const double* h_taps, int fma, uint32_t N, int wantMax,
+                             double fill, void* stream)
+	{
+	const int h = (int) ((N - 1) / 2);
+	GDSP_REQUIRE ((h >= 1) && (h <= PK_HMAX), "neighbourhood outside the filter's range");
+	HannConsts<101> K;
+	hann_consts<101> (K);
+	PeaksTaps<101> taps;
+	memcpy (taps.w, h_taps, sizeof(taps.w));
+	std::vector<gdsp_batch_item> live;
+	for (int i=0 ; i<nitems ; i++) { if (items[i].n != 0) live.push_back (items[i]); }
+	for (size_t at=0 ; at<live.size () ; at+=GDSP_BATCH_MAX)
+		{
+		const int count = (int) std::min<size_t> (GDSP_BATCH_MAX, live.size () - at);
+		int rc;
+#define PK_CASE(HHH) case HHH: rc = wantMax? peaks_launch<true, HHH>  (&live[at], count, K, taps, fma, fill, h_taps, stream) \
+                                           : peaks_launch<false, HHH> (&live[at], count, K, taps, fma, fill, h_taps, stream);  break;
+		switch (h)
+			{
+			PK_CASE (1) PK_CASE (2) PK_CASE (3) PK_CASE (4) PK_CASE (5) PK_CASE (6)
+			default: rc = wantMax? peaks_launch<true, 7>  (&live[at], count, K, taps, fma, fill, h_taps, stream)
+			                     : peaks_launch<false, 7> (&live[at], count, K, taps, fma, fill, h_taps, stream);  break;
+			}
+#undef PK_CASE
+		if (rc != GDSP_OK) return rc;
+		}
+	return GDSP_OK;
+	}

@@ -99,10 +99,10 @@ def test_smooth_w101_full_chromosome(gd, real):
     # the index output of config 3: peaks of the smoothed track
     peaks = gd.localmax(out, 11)
     stencil_check(peaks, lambda x: cpu.local_extrema(cpu.smooth(x, 101), 11, 1, 0.0), 1, 55, rng)
-    # ... and the fused kernels -- the one that evaluates every base, and the one (opt-in) that evaluates tap by tap only
-    # what its interval filter cannot rule out (hann_extrema_kernel): every one of the 249 M bases carries the bits of
-    # the two kernels run one after the other
-    for env in ({}, {"GDSP_PEAKS_FILTER": "1"}):
+    # ... and the fused forms -- the filtered route (gdsp_peaks.hip: tap by tap only what its interval filter cannot rule
+    # out; the default), and the kernel that evaluates every base: every one of the 249 M bases carries the bits of the
+    # two kernels run one after the other
+    for env in ({}, {"GDSP_PEAKS_ROUTE": "filter"}, {"GDSP_PEAKS_FILTER": "0"}):
         os.environ.update(env)
         try:
             fused = gd.smooth_local_extrema(real, 101, 11, True, 0.0)
@@ -126,7 +126,7 @@ def test_fused_peaks_on_read_depth_full_chromosome(gd, depth):
     out = gd.smooth(depth, 101, mode=gd.FIR_EXACT)
     for want_max, fill in ((True, 0.0), (False, cpu.DBL_MAX)):
         two = gd.local_extrema(out, 11, want_max, fill)
-        for env in ({"GDSP_PEAKS_FILTER": "1"}, {}):              # the filtered kernel (opt-in) on this signal full of ties; the default
+        for env in ({}, {"GDSP_PEAKS_ROUTE": "filter"}, {"GDSP_PEAKS_FILTER": "0"}):   # the probe's choice (the direct kernel on this signal full of ties), the filter forced (its queues overflow), the direct kernel
             os.environ.update(env)
             try:
                 fused = gd.smooth_local_extrema(depth, 101, 11, want_max, fill)

@@ -622,8 +622,8 @@ def test_fused_smooth_localmax_is_the_two_operators(n, N, gd):
 
 
 def _filter_cases(n, rng):
-    """Signals for the filtered fused kernel (hann_extrema_kernel): ties, near-ties, zero stretches, mixed signs, and the
-    values that send a tile to the tap-by-tap evaluation."""
+    """Signals for the filtered route of the fused kernel (gdsp_peaks.hip): ties, near-ties, zero stretches, mixed signs,
+    and the values that make a tile queue every base."""
     t = np.arange(n)
     cases = {}
     x = np.full(n, 30.0); x[n // 3: n // 2] = 31.0; x[n // 2: n // 2 + 7] = 0.0
@@ -650,13 +650,18 @@ def _filter_cases(n, rng):
     return cases
 
 
-@pytest.mark.parametrize("n", [2291, 2292, 2293, 2294, 3971, 3972, 3973, 3974, 4584, 7944, 7945, 20011])
-@pytest.mark.parametrize("N", [2, 3, 11, 12, 41])
+PEAKS_ROUTES = ({}, {"GDSP_PEAKS_ROUTE": "filter"}, {"GDSP_PEAKS_ROUTE": "direct"}, {"GDSP_PEAKS_ROUTE": "filter", "GDSP_PEAKS_QUEUE_CAP": "7"},
+                {"GDSP_PEAKS_FILTER": "0"})
+
+
+@pytest.mark.parametrize("n", [2291, 2292, 2293, 2294, 3961, 3962, 3963, 3971, 3972, 3973, 3974, 4584, 7944, 7945, 20011])
+@pytest.mark.parametrize("N", [2, 3, 5, 11, 12, 15, 17, 41])
 def test_filtered_smooth_extrema_is_bit_identical(n, N, gd):
-    """`smooth W=101 = localmax|localmin N` with GDSP_PEAKS_FILTER=1 evaluates tap by tap only the bases the block sums
-    cannot rule out (gdsp_hann.hip: hann_extrema_kernel, tiles of 3984 - 2h - 2(h&1) outputs): the output is still that
-    of the two reference loops run one after the other, on every kind of signal, and that of the kernel that evaluates
-    every base (tiles of 2304 - 2h)."""
+    """`smooth W=101 = localmax|localmin N` evaluates tap by tap only the bases the block sums cannot rule out
+    (gdsp_peaks.hip: filter tiles of 3984 - 2h - 2(h&1) outputs, undecided positions queued in HBM, 16 lanes per queued
+    base in the exact kernel; neighbourhoods of 3..15 bases): the output is still that of the two reference loops run
+    one after the other, on every kind of signal -- whichever route the probe picks, with the filter forced, with the
+    direct kernel forced, with a queue of seven positions that overflows at once, and with the filter switched off."""
     rng = np.random.default_rng(n * 131 + N)
     for name, x in _filter_cases(n, rng).items():
         d = gd.DeviceVector.from_numpy(x)
@@ -664,8 +669,7 @@ def test_filtered_smooth_extrema_is_bit_identical(n, N, gd):
             sm = cpu.smooth(x, 101)
         for want_max, fill in ((True, 0.0), (False, cpu.DBL_MAX)):
             want = cpu.local_extrema(sm, N, 1 if want_max else 0, fill)
-            # the kernel that evaluates every base (the default), and the filtered one (opt-in)
-            for env in ({}, {"GDSP_PEAKS_FILTER": "1"}):
+            for env in PEAKS_ROUTES:
                 os.environ.update(env)
                 try:
                     got = gd.smooth_local_extrema(d, 101, N, want_max, fill).numpy()
@@ -673,6 +677,26 @@ def test_filtered_smooth_extrema_is_bit_identical(n, N, gd):
                     for key in env:
                         del os.environ[key]
                 assert bits_equal(got, want), (name, want_max, env, first_diff(got, want))
+
+
+def test_filtered_smooth_extrema_in_fma_arithmetic(gd):
+    """--smooth=fma through the same filter: the exact kernel then fuses each tap, and the output is that of the fma FIR
+    followed by the neighbourhood test (the block sums are as close to fma's values as to the reference's)."""
+    rng = np.random.default_rng(77)
+    for n in (3973, 20011):
+        for name, x in _filter_cases(n, rng).items():
+            d = gd.DeviceVector.from_numpy(x)
+            sm = gd.smooth(d, 101, mode=gd.FIR_FMA)
+            for want_max, fill in ((True, 0.0), (False, cpu.DBL_MAX)):
+                want = gd.local_extrema(sm, 11, want_max, fill).numpy()
+                for env in ({"GDSP_PEAKS_ROUTE": "filter"}, {"GDSP_PEAKS_FILTER": "0"}):
+                    os.environ.update(env)
+                    try:
+                        got = gd.smooth_local_extrema(d, 101, 11, want_max, fill, mode=gd.FIR_FMA).numpy()
+                    finally:
+                        for key in env:
+                            del os.environ[key]
+                    assert bits_equal(got, want), (name, want_max, env, first_diff(got, want))
 
 
 @pytest.mark.parametrize("n", [1, 2, 127, 129, 16384, 16385, 100000, 300007])
