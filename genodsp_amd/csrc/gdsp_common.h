@@ -175,6 +175,7 @@ int gdsp_fir_extrema_gated_launch (const gdsp_batch_item* items, int count, cons
                                    int fma, int h, int wantMax, double fill, void* stream);
 // gdsp_peaks.hip: the filtered route for every vector of a table (W = 101, neighbourhoods of 3..15 bases)
 bool gdsp_peaks_filter_available (uint32_t W, uint32_t N);
+bool gdsp_peaks_filter_wanted_for_fma (void);                      // GDSP_PEAKS_FILTER=fma
 int  gdsp_peaks_filter_batch (const gdsp_batch_item* items, int nitems, const double* h_taps, int fma, uint32_t N, int wantMax,
                               double fill, void* stream);
 

@@ -494,7 +494,7 @@ int gdsp_smooth_local_extrema (const double* d_in, double* d_out, uint32_t n, ui
 	if (rc != GDSP_OK) return rc;
 	const int   h = (int) ((N - 1) / 2);
 	hipStream_t s = gdsp_stream (stream);
-	if (gdsp_peaks_filter_available (W, N))                       // the filtered route, see gdsp_smooth_local_extrema_batch
+	if (gdsp_peaks_filter_available (W, N) && ((mode == GDSP_FIR_EXACT) || gdsp_peaks_filter_wanted_for_fma ()))   // the filtered route, see gdsp_smooth_local_extrema_batch
 		{
 		const gdsp_batch_item one = { d_in, d_out, n };
 		return gdsp_peaks_filter_batch (&one, 1, plan->h_taps, mode == GDSP_FIR_FMA, N, wantMax, fill, stream);
@@ -638,8 +638,10 @@ extern "C" int gdsp_smooth_local_extrema_batch (const gdsp_batch_item* items, in
 	const int   h = (int) ((N - 1) / 2);
 	hipStream_t s = gdsp_stream (stream);
 	// the filtered route (gdsp_peaks.hip): block sums rule out ~99.5 % of the bases, the rest are evaluated tap by tap in
-	// this mode's arithmetic -- the same bits, off the FP64 pipe; tie-heavy vectors fall to the direct kernel on the device
-	if (gdsp_peaks_filter_available (W, N))
+	// the reference's arithmetic -- the same bits, off the FP64 pipe; tie-heavy vectors fall to the direct kernel on the
+	// device.  For EXACT (185 against 140 Gbases/s over the genome); one fused multiply-add per tap is fast enough for
+	// the direct kernel to win (215), so FMA takes the filter only when asked to (GDSP_PEAKS_FILTER=fma: tests)
+	if (gdsp_peaks_filter_available (W, N) && ((mode == GDSP_FIR_EXACT) || gdsp_peaks_filter_wanted_for_fma ()))
 		return gdsp_peaks_filter_batch (items, nitems, plan->h_taps, mode == GDSP_FIR_FMA, N, wantMax, fill, stream);
 	if (mode == GDSP_FIR_FMA)
 		{ if (wantMax) fir_extrema_batch_launch<true, true>  (items, nitems, plan->h_taps, h, fill, s);

@@ -100,7 +100,7 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 	const int      keepHi    = (keepLo + stride < validHi)? keepLo + stride : validHi;
 
 	if (p == 0) { nsure = 0;  queued = 0; }                        // (the barriers of the block sums come before their first use)
-	if (!PROBE && (p < W)) tapsLds[p] = d_taps[p];
+	if (!PROBE && (p < W) && !(dbg & 32)) tapsLds[p] = d_taps[p];
 	double acc[HN_G];
 	bool direct = hann_tile_sums<W, true> (lds, tot, huge, in, n, e0, K, acc, stats);
 
@@ -129,6 +129,7 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 		const bool inside = live && (c >= validLo) && (c < validHi);
 		v[HH + u] = !inside? never : (acc[u] == 0.0)? 0.0 : acc[u];
 		}
+	if (!(dbg & 4)) {
 	if (lane == 0)  { for (int t=0 ; t<HH ; t++) edgeLo[wave][t] = v[HH + t]; }
 	if (lane == 63) { for (int t=0 ; t<HH ; t++) edgeHi[wave][t] = v[HN_G + t]; }
 #pragma unroll
@@ -144,6 +145,7 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 		if (lane == 0)  v[t]             = (wave == 0)?    never : edgeHi[wave-1][t];
 		if (lane == 63) v[HN_G + HH + t] = (wave == NW-1)? never : edgeLo[wave+1][t];
 		}
+	}
 
 	// ---- the interval test
 	uint32_t isNeed = 0, isZero = 0, isSure = 0;
@@ -203,7 +205,7 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 		}
 
 	// ---- certain peaks: a list in LDS (what does not fit joins the undecided)
-	if (!direct)
+	if (!direct && !(dbg & 8))
 		{
 		const int cnt = __popc (isSure);
 		int incl = cnt;
@@ -227,7 +229,7 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 			}
 		}
 	// ---- undecided bases: tile-local indices into the tile's strip (a tile that must be evaluated whole queues nothing)
-	if (!direct)
+	if (!direct && !(dbg & 8))
 		{
 		const int cnt = __popc (isNeed);
 		int incl = cnt;
@@ -447,6 +449,9 @@ static int peaks_work (void* stream, size_t tiles, PeaksWork* out)
 	*out = *w;
 	return GDSP_OK;
 	}
+
+bool gdsp_peaks_filter_wanted_for_fma (void)
+	{ const char* e = getenv ("GDSP_PEAKS_FILTER");  return (e != NULL) && (strcmp (e, "fma") == 0); }
 
 bool gdsp_peaks_filter_available (uint32_t W, uint32_t N)
 	{
