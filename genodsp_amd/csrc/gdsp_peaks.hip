@@ -70,7 +70,7 @@ template <int W, bool FMA, bool MAX, int HH, bool PROBE>
 __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t tile,
                                                    const HannConsts<W>& K, const double* __restrict__ d_taps, double fill, GdspPeaksCtl* ctl,
                                                    uint16_t* __restrict__ strip, uint32_t* __restrict__ tileCount, uint32_t cap,
-                                                   uint32_t* __restrict__ tileList, uint32_t gt, int dbg = 0)
+                                                   uint32_t* __restrict__ tileList, uint32_t gt)
 	{
 	typedef HannGeom<W> G;
 	constexpr double KAPPA = 16.0 * W * 2.220446049250313e-16;
@@ -100,26 +100,141 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 	const int      keepHi    = (keepLo + stride < validHi)? keepLo + stride : validHi;
 
 	if (p == 0) { nsure = 0;  queued = 0; }                        // (the barriers of the block sums come before their first use)
-	if (!PROBE && (p < W) && !(dbg & 32)) tapsLds[p] = d_taps[p];
+	if (!PROBE && (p < W)) tapsLds[p] = d_taps[p];
 	double acc[HN_G];
-	bool direct = hann_tile_sums<W, true> (lds, tot, huge, in, n, e0, K, acc, stats);
+	bool direct = hann_tile_sums<W, false> (lds, tot, huge, in, n, e0, K, acc);
 
-	uint32_t bigAll = 0, flagsAll = 0;
-#pragma unroll
-	for (int w=0 ; w<NW ; w++) { bigAll = max (bigAll, stats[w][0]);  flagsAll |= stats[w][1]; }
-	if (flagsAll & 2u) direct = true;
-	const bool   nonneg = ((flagsAll & 1u) == 0);
-	const double amax   = __longlong_as_double (((long long) (bigAll | 0x000FFFFFu) << 32) | 0xFFFFFFFFll);   // >= every |x| of the tile
-	const double epsAbs = KAPPA * amax;
-	// `a certainly beats b`: a's interval wholly beyond b's.  Without negative inputs every smoothed value is >= 0 and the
-	// intervals are relative (sum|w x| is the value itself); otherwise the largest magnitude of the tile bounds sum|w x|
-	const double shrink = 1.0 - KAPPA, grow = 1.0 + KAPPA, eps2 = 2.0 * epsAbs * grow;
-	auto beats = [&] (double a, double b)
+	// ---- what the tile's inputs are like, from the own block in the LDS image (after the block sums: inside them, where
+	// the registers are fullest, the same few integer operations per element cost a fifth of the kernel): is a sign bit
+	// set, is there a nonzero magnitude below 2^-500.  stats[wave][1] = { bit 0, bit 1 }; read after the next barrier.
 		{
-		if (MAX) return nonneg? (a * shrink > b * grow) : (a - eps2 > b);
-		else     return nonneg? (a * grow < b * shrink) : (a + eps2 < b);
-		};
+		const double* xb = lds + p * HN_PITCH;
+		uint32_t signs = 0, smallest = 0xFFFFFFFFu;
+#pragma unroll
+		for (int u=0 ; u<HN_G ; u++)
+			{
+			const uint32_t hi = (uint32_t) (__double_as_longlong (xb[u]) >> 32), lo = (uint32_t) __double_as_longlong (xb[u]);
+			signs |= hi;
+			const uint32_t key = (hi & 0x7FFFFFFFu) | min (lo, 1u);    // 0 only for a zero; a denormal's is 1
+			smallest = min (smallest, key - 1u);                      // (a zero wraps to the top: ignored)
+			}
+		const uint32_t flags = ((__builtin_amdgcn_ballot_w64 ((signs >> 31) != 0) != 0)? 1u : 0u)
+		                     | ((__builtin_amdgcn_ballot_w64 (smallest < 0x20B00000u - 1u) != 0)? 2u : 0u);
+		if (lane == 0) stats[wave][1] = flags;
+		}
 
+	// the high words of the own block's smoothed values, as 32-bit integers (see the test below), and the words the
+	// neighbouring threads need: exchanged now, so that one barrier serves the statistics and the edges
+	const uint32_t away = MAX? 0u : 0x7FEFFFFFu;                   // outside the vector: beats nothing
+	uint32_t k[HN_G + 2*HH];
+#pragma unroll
+	for (int u=0 ; u<HN_G ; u++)
+		{
+		const int  c      = blk * HN_G + u;
+		const bool inside = live && (c >= validLo) && (c < validHi);
+		k[HH + u] = inside? (uint32_t) (__double_as_longlong (acc[u]) >> 32) & 0x7FFFFFFFu : away;          // (-0.0 is a zero)
+		}
+	uint32_t* edgeLoK = reinterpret_cast<uint32_t*> (&edgeLo[0][0]);
+	uint32_t* edgeHiK = reinterpret_cast<uint32_t*> (&edgeHi[0][0]);
+	if (lane == 0)  { for (int t=0 ; t<HH ; t++) edgeLoK[wave*HH + t] = k[HH + t]; }
+	if (lane == 63) { for (int t=0 ; t<HH ; t++) edgeHiK[wave*HH + t] = k[HN_G + t]; }
+#pragma unroll
+	for (int t=0 ; t<HH ; t++)
+		{
+		k[t]             = (uint32_t) __shfl_up   ((int) k[HN_G + t], 1, 64);          // the previous block's last HH words
+		k[HN_G + HH + t] = (uint32_t) __shfl_down ((int) k[HH + t],   1, 64);          // the next block's first HH
+		}
+	__syncthreads ();
+#pragma unroll
+	for (int t=0 ; t<HH ; t++)
+		{
+		if (lane == 0)  k[t]             = (wave == 0)?    away : edgeHiK[(wave-1)*HH + t];
+		if (lane == 63) k[HN_G + HH + t] = (wave == NW-1)? away : edgeLoK[(wave+1)*HH + t];
+		}
+	uint32_t flagsAll = 0;
+#pragma unroll
+	for (int w=0 ; w<NW ; w++) flagsAll |= stats[w][1];
+	if (flagsAll & 2u) direct = true;
+	const bool nonneg = ((flagsAll & 1u) == 0);
+
+	uint32_t isNeed = 0, isZero = 0, isSure = 0;
+	if (nonneg && !direct)
+		{
+		// ---- no negative input: every smoothed value is >= 0, and doubles >= 0 order like their bit patterns.  The test
+		// runs on the HIGH WORDS alone, as 32-bit integers (full-rate instructions; v_max_f64 / v_cmp_f64 are not): a value
+		// whose high word is at least 2 above another's exceeds it by more than one part in 2^21, far beyond the two
+		// intervals' reach (KAPPA ~ 4e-13), so "certainly beaten" and "certainly the extreme" are decided exactly as by
+		// the intervals, only more cautiously -- what falls within two units of the neighbours' extreme (flat tops, ties)
+		// is left to the exact kernel.  A high word of 0 is an exact zero (no magnitude below 2^-500 in such a tile).
+		// A thread holds the 16 words of its block and has got HH either side from its neighbours by wave shifts (the two
+		// lanes at a wave's ends through a few words of LDS).  Outside the vector: 0 (MAX) / DBL_MAX's (MIN): beats nothing.
+		if (live)
+			{
+			// the extreme of the HH words before a base and of the HH after it, for all 16 bases at once: runs of 2 and 4 by doubling
+			constexpr int NV = HN_G + 2*HH;
+			uint32_t m2[NV], m4[NV], run[HN_G + HH + 1];
+#pragma unroll
+			for (int i=0 ; i+1<NV ; i++) m2[i] = MAX? max (k[i], k[i+1]) : min (k[i], k[i+1]);
+#pragma unroll
+			for (int i=0 ; i+3<NV ; i++) m4[i] = MAX? max (m2[i], m2[i+2]) : min (m2[i], m2[i+2]);
+#pragma unroll
+			for (int i=0 ; i<HN_G+HH+1 ; i++)
+				{
+				uint32_t r;
+				if      (HH == 1) r = k[i];
+				else if (HH == 2) r = m2[i];
+				else if (HH == 3) r = MAX? max (m2[i], k[i+2])  : min (m2[i], k[i+2]);
+				else if (HH == 4) r = m4[i];
+				else if (HH == 5) r = MAX? max (m4[i], k[i+4])  : min (m4[i], k[i+4]);
+				else if (HH == 6) r = MAX? max (m4[i], m2[i+4]) : min (m4[i], m2[i+4]);
+				else              r = MAX? max (m4[i], m4[i+3]) : min (m4[i], m4[i+3]);
+				run[i] = r;
+				}
+#pragma unroll
+			for (int u=0 ; u<HN_G ; u++)
+				{
+				const int      c   = blk * HN_G + u;
+				const uint32_t ext = MAX? max (run[u], run[u + HH + 1]) : min (run[u], run[u + HH + 1]);
+				const uint32_t x   = k[u + HH];
+				if ((c < keepLo) || (c >= keepHi)) continue;
+				if (MAX)
+					{
+					if (ext > x + 1) continue;                     // certainly beaten: `fill`
+					if (x == 0)          isZero |= 1u << u;        // (then ext <= 1: among zeros a tie; a neighbour of word 1 is < 2^-1000: none here)
+					else if (x > ext + 1) isSure |= 1u << u;
+					else                  isNeed |= 1u << u;
+					}
+				else
+					{
+					if (x == 0) { isZero |= 1u << u;  continue; }  // nothing is below zero here: kept
+					if (ext + 1 < x) continue;                     // certainly beaten
+					if (x + 1 < ext) isSure |= 1u << u;
+					else             isNeed |= 1u << u;
+					}
+				}
+			}
+		}
+	else
+	{
+	// ---- negative inputs in the tile (or a tile to be evaluated whole): the intervals themselves, in double precision.
+	// sum|w x| is bounded by the tile's largest magnitude (the taps add up to 1): found now, from the staged inputs
+	double amax = 0.0;
+		{
+		const double* xb = lds + p * HN_PITCH;
+#pragma unroll
+		for (int u=0 ; u<HN_G ; u++) amax = fmax (amax, fabs (xb[u]));
+		for (int off=32 ; off>0 ; off>>=1) amax = fmax (amax, __shfl_xor (amax, off, 64));
+		__syncthreads ();                                          // (the edge words have been read)
+		if (lane == 0) edgeLo[wave][0] = amax;
+		__syncthreads ();
+		amax = 0.0;
+		for (int w=0 ; w<NW ; w++) amax = fmax (amax, edgeLo[w][0]);
+		__syncthreads ();
+		}
+	const double epsAbs = KAPPA * amax;
+	// `a certainly beats b`: a's interval wholly beyond b's
+	const double eps2 = 2.0 * epsAbs * (1.0 + KAPPA);
+	auto beats = [&] (double a, double b) { return MAX? (a - eps2 > b) : (a + eps2 < b); };
 	// ---- the block and HH values either side of it, in registers
 	double v[HN_G + 2*HH];
 #pragma unroll
@@ -129,7 +244,6 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 		const bool inside = live && (c >= validLo) && (c < validHi);
 		v[HH + u] = !inside? never : (acc[u] == 0.0)? 0.0 : acc[u];
 		}
-	if (!(dbg & 4)) {
 	if (lane == 0)  { for (int t=0 ; t<HH ; t++) edgeLo[wave][t] = v[HH + t]; }
 	if (lane == 63) { for (int t=0 ; t<HH ; t++) edgeHi[wave][t] = v[HN_G + t]; }
 #pragma unroll
@@ -145,11 +259,9 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 		if (lane == 0)  v[t]             = (wave == 0)?    never : edgeHi[wave-1][t];
 		if (lane == 63) v[HN_G + HH + t] = (wave == NW-1)? never : edgeLo[wave+1][t];
 		}
-	}
 
 	// ---- the interval test
-	uint32_t isNeed = 0, isZero = 0, isSure = 0;
-	if (live && !(dbg & 2))
+	if (live)
 		{
 		if (direct)
 			{
@@ -189,12 +301,13 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 				const double ext = MAX? fmax (run[u], run[u + HH + 1]) : fmin (run[u], run[u + HH + 1]);
 				const double x   = v[u + HH];
 				if ((c < keepLo) || (c >= keepHi) || beats (ext, x)) continue;      // not this tile's, or certainly beaten: `fill`
-				if (nonneg && (x == 0.0)) isZero |= 1u << u;           // an all-zero window is exactly zero, and only a tie can meet it
-				else if (beats (x, ext))  isSure |= 1u << u;           // certainly the extreme of its neighbourhood: only its exact value is missing
-				else                      isNeed |= 1u << u;           // ties, near-ties: the comparison needs exact values
+				if (beats (x, ext)) isSure |= 1u << u;                 // certainly the extreme of its neighbourhood: only its exact value is missing
+				else                isNeed |= 1u << u;                 // ties, near-ties: the comparison needs exact values
 				}
 			}
 		}
+
+	}
 
 	if (PROBE)
 		{
@@ -205,7 +318,7 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 		}
 
 	// ---- certain peaks: a list in LDS (what does not fit joins the undecided)
-	if (!direct && !(dbg & 8))
+	if (!direct)
 		{
 		const int cnt = __popc (isSure);
 		int incl = cnt;
@@ -229,7 +342,7 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 			}
 		}
 	// ---- undecided bases: tile-local indices into the tile's strip (a tile that must be evaluated whole queues nothing)
-	if (!direct && !(dbg & 8))
+	if (!direct)
 		{
 		const int cnt = __popc (isNeed);
 		int incl = cnt;
@@ -268,7 +381,7 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 	// ---- exact values of the certain peaks, one lane each, from the staged inputs: tap by tap in the reference's order
 	//      (sum.c:655-663); the base is written by the lane that evaluated it
 	const int sure = (int) ((nsure < PK_SURE_CAP)? nsure : PK_SURE_CAP);
-	if ((p < sure) && !(dbg & 1))
+	if (p < sure)
 		{
 		const int c = sureList[p];
 		const int e = G::LO + c;                                   // the window's first staged element
@@ -320,14 +433,14 @@ void peaks_probe_kernel (GdspBatch B, HannConsts<W> K, GdspPeaksCtl* ctl)
 template <int W, bool FMA, bool MAX, int HH>
 __global__ __launch_bounds__(HN_THREADS) __attribute__((amdgpu_waves_per_eu(3)))     // three workgroups per CU, like hann_blocks_kernel
 void peaks_filter_kernel (GdspBatch B, HannConsts<W> K, const double* __restrict__ d_taps, double fill, GdspPeaksCtl* ctl, uint16_t* strips,
-                          uint32_t* counts, uint32_t cap, uint32_t* tileList, int dbg)
+                          uint32_t* counts, uint32_t cap, uint32_t* tileList)
 	{
 	const double* in;  double* out;  uint32_t n, v;
 	const uint32_t tile = gdsp_batch_tile (B, in, out, n, &v);
 	if (gdsp_peaks_takes_direct (ctl[v])) return;                  // (the probe is complete: an earlier launch on the same stream)
 	const uint32_t gt = B.tile0[v] + tile;                         // the tile's number in the grid: its strip and its count
 	peaks_filter_tile<W, FMA, MAX, HH, false> (in, out, n, tile, K, d_taps, fill, &ctl[v], strips + (size_t) gt * cap, counts + gt, cap,
-	                                           tileList + B.tile0[v], gt, dbg);
+	                                           tileList + B.tile0[v], gt);
 	}
 
 // The exact kernel, for the bases whose comparison needs exact values (ties and near-ties): a workgroup takes a tile from
@@ -487,15 +600,14 @@ static int peaks_launch (const gdsp_batch_item* items, int count, const HannCons
 	if (rc != GDSP_OK) return rc;
 	hipLaunchKernelGGL ((peaks_probe_kernel<101, MAX, HH>), dim3(count * PK_PROBE_TILES), dim3(HN_THREADS), 0, s, B, K, w.ctl);
 	const int exactBlocks = 4096;
-	const int dbg = getenv ("GDSP_PEAKS_DBG")? atoi (getenv ("GDSP_PEAKS_DBG")) : 0;
 	if (fma)
 		{
-		hipLaunchKernelGGL ((peaks_filter_kernel<101, true, MAX, HH>), dim3(tiles), dim3(HN_THREADS), 0, s, B, K, d_taps, fill, w.ctl, w.strips, w.counts, cap, w.tileList, dbg);
+		hipLaunchKernelGGL ((peaks_filter_kernel<101, true, MAX, HH>), dim3(tiles), dim3(HN_THREADS), 0, s, B, K, d_taps, fill, w.ctl, w.strips, w.counts, cap, w.tileList);
 		hipLaunchKernelGGL ((peaks_exact_kernel<101, true, MAX>), dim3(exactBlocks), dim3(HN_THREADS), 0, s, B, taps, HH, fill, w.ctl, w.strips, w.counts, cap, w.tileList);
 		}
 	else
 		{
-		hipLaunchKernelGGL ((peaks_filter_kernel<101, false, MAX, HH>), dim3(tiles), dim3(HN_THREADS), 0, s, B, K, d_taps, fill, w.ctl, w.strips, w.counts, cap, w.tileList, dbg);
+		hipLaunchKernelGGL ((peaks_filter_kernel<101, false, MAX, HH>), dim3(tiles), dim3(HN_THREADS), 0, s, B, K, d_taps, fill, w.ctl, w.strips, w.counts, cap, w.tileList);
 		hipLaunchKernelGGL ((peaks_exact_kernel<101, false, MAX>), dim3(exactBlocks), dim3(HN_THREADS), 0, s, B, taps, HH, fill, w.ctl, w.strips, w.counts, cap, w.tileList);
 		}
 	GDSP_LAUNCH_CHECK ();
