@@ -158,6 +158,8 @@ def main():
         for i in mine:
             gd.smooth(vin[i], WINDOW, out=vout[i], mode=mode, stream=lane_of[i].handle)
 
+    per_rank_ms = []                                  # filled by timed(): HIP-event ms per step of every rank, rank order
+
     def timed(mode, steps, warmup, step=step):
         for _ in range(warmup):
             step(mode)
@@ -181,7 +183,13 @@ def main():
         t1 = time.perf_counter()
         wall_ms = (t1 - t0) * 1e3 / steps
         dev_ms = e0.elapsed_ms(e1) / steps          # HIP events on the launch stream
+        per_rank_ms.clear()
+        per_rank_ms.append(round(dev_ms, 4))
         if dist is not None:
+            mine_ms = torch.tensor([dev_ms], dtype=torch.float64, device=reduce_device)
+            every = [torch.zeros_like(mine_ms) for _ in range(world)]
+            dist.all_gather(every, mine_ms)                                  # each rank's own device time for the step
+            per_rank_ms[:] = [round(float(x[0]), 4) for x in every]
             t = torch.tensor([wall_ms, dev_ms], dtype=torch.float64, device=reduce_device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wall_ms, dev_ms = float(t[0]), float(t[1])
@@ -197,7 +205,37 @@ def main():
 
     modes = {"hann": gd.FIR_HANN, "fma": gd.FIR_FMA, "exact": gd.FIR_EXACT}
     wall_ms, dev_ms = timed(modes[args.mode], args.steps, args.warmup)
+    ranks_ms = list(per_rank_ms)
     others = {m: timed(modes[m], max(1, args.steps // 2), 1) for m in modes if m != args.mode}
+
+    # ---- with more than one rank, the other split of the genome too, in the same run: equal stretches of the
+    #      concatenated genome (makespan efficiency 1.000 by construction; whole chromosomes dealt longest-first reach
+    #      0.965 at 8) -- one timed pass, the same arithmetic, so that one run of the driver records both
+    other_split = None
+    if world > 1:
+        alt = "bases" if args.sharding == "chromosomes" else "chromosomes"
+        alt_shards = shard_pieces(lengths, world, alt, lpt_shards)
+        alt_pieces = list(alt_shards[rank])
+        alt_held = [piece_extent(q, lengths) if alt == "bases" else (0, lengths[q[0]]) for q in alt_pieces]
+        alt_in = [gd.DeviceVector(hi - lo) for lo, hi in alt_held]
+        alt_out = [gd.DeviceVector(hi - lo) for lo, hi in alt_held]
+        for q, (lo, hi), v in zip(alt_pieces, alt_held, alt_in):
+            gd.synth_coverage(SEED, q[0], lo, hi - lo, mode=1, out=v, stream=stream.handle)
+        stream.sync()
+        alt_items = gd.batch_items(alt_in, alt_out)
+
+        def alt_step(mode):
+            if batch:
+                gd.call("gdsp_smooth_batch", alt_items, len(alt_in), WINDOW, mode, stream.handle)
+                return
+            for a, b in zip(alt_in, alt_out):
+                gd.smooth(a, WINDOW, out=b, mode=mode, stream=stream.handle)
+
+        alt_wall, alt_dev = timed(modes[args.mode], max(1, args.steps // 2), 1, step=alt_step)
+        other_split = {"sharding": alt, "value": round(total_bases / (alt_wall * 1e-3) / 1e9, 2), "unit": "Gbases/s",
+                       "ms_per_step": round(alt_wall, 4), "per_rank_ms": list(per_rank_ms),
+                       "bases_per_rank": [sum(b - a for _, _, a, b in sh) for sh in alt_shards]}
+        del alt_in, alt_out
 
     # ---- parity spot check against the CPU oracle (checker only): sampled windows of the
     #      longest local chromosome, exact mode must be bit-identical, fma within tolerance
@@ -250,7 +288,11 @@ def main():
         "other_modes": [{"fir_mode": m, "value": round(total_bases / (w * 1e-3) / 1e9, 2),
                          "ms_per_step": round(w, 4), "roofline": roofline(m, d)} for m, (w, d) in others.items()],
         "parity": parity,
+        "per_rank_ms": ranks_ms,
+        "bases_per_rank": [sum(b - a for _, _, a, b in sh) for sh in shards],
     }
+    if other_split is not None:
+        result["other_sharding"] = other_split
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(gd, lengths, names, stream)
         result["cpu_baseline_all_cores"] = cpu_baseline_all_cores(gd, lengths, names, stream)
@@ -548,36 +590,33 @@ def cpu_baseline(gd, lengths, names, stream):
 
 
 def cpu_baseline_all_cores(gd, lengths, names, stream):
-    """the CPU restatement (oracle port; ctypes releases the GIL) over every host core this process
-    may use, chromosomes cut into one stretch per core with the half window of neighbours each needs.  Reported
-    beside the single-threaded reference, never instead of it."""
-    from concurrent.futures import ThreadPoolExecutor
+    """the CPU restatement (oracle port) over every host core this process may use: pthreads inside
+    liboracle.so, thread t of T taking the t-th stretch of every chromosome of the sample (neighbours read in place),
+    outputs allocated and touched before the clock starts (page faults of 6.8 GB of fresh output are not smoothing).
+    Reported beside the single-threaded reference, never instead of it."""
     from oracle import cpu
     nproc = os.cpu_count() or 1
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else nproc     # what `nproc` prints
     if os.environ.get("GDSP_HOST_CORES"):
         cores = min(cores, int(os.environ["GDSP_HOST_CORES"]))
     sample = [names.index(c) for c in ("chr13", "chr14", "chr15", "chr16", "chr17", "chr18", "chr19", "chr20", "chr21", "chr22", "chrY")]
-    half = (WINDOW - 1) // 2
-    jobs = []
+    vecs = []
     for i in sample:
         d = gd.synth_coverage(SEED, i, 0, lengths[i], mode=1, stream=stream.handle)
         stream.sync()
-        v = d.numpy()
-        per = max(1, (lengths[i] + cores - 1) // cores)
-        for a in range(0, lengths[i], per):
-            b = min(lengths[i], a + per)
-            jobs.append(v[max(0, a - half):min(lengths[i], b + half)])
+        vecs.append(d.numpy())
+    outs = [np.zeros_like(v) for v in vecs]                                # allocated and touched
     bases = sum(lengths[i] for i in sample)
     t0 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=cores) as pool:
-        list(pool.map(lambda x: cpu.smooth(x, WINDOW).size, jobs))          # (results are dropped as they come)
+    outs, started = cpu.smooth_threads(vecs, WINDOW, cores, outs)
     dt = time.perf_counter() - t0
-    return {"value": round(bases / dt / 1e9, 5), "unit": "Gbases/s", "cores": cores, "kind": "port",
-            "host_logical_cpus": nproc, "usable_by_this_process": cores,
-            "sample": "smooth W=101 on chr13..chr22+chrY (%d bases) cut into %d stretches over %d threads (every core this "
-                      "process may use; kind \"port\" = the CPU restatement, the reference itself is single-threaded), %.1f s"
-                      % (bases, len(jobs), cores, dt)}
+    # ... and they are the single-threaded loop's bits (a stretch of the last chromosome)
+    same = outs[-1][:200000].tobytes() == cpu.smooth(vecs[-1][:200050], WINDOW)[:200000].tobytes()
+    return {"value": round(bases / dt / 1e9, 5), "unit": "Gbases/s", "cores": started, "kind": "port",
+            "host_logical_cpus": nproc, "usable_by_this_process": cores, "same_bits_as_one_thread": bool(same),
+            "sample": "smooth W=101 on chr13..chr22+chrY (%d bases), %d pthreads each taking one stretch of every chromosome (every "
+                      "core this process may use; kind \"port\" = the CPU restatement, the reference itself is single-threaded), "
+                      "outputs preallocated, %.2f s" % (bases, started, dt)}
 
 
 if __name__ == "__main__":

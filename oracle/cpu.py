@@ -112,6 +112,21 @@ def smooth(v, W):
     return out
 
 
+def smooth_threads(vecs, W, threads, outs=None):
+    """orc_smooth of every vector over `threads` pthreads inside the library; outs: preallocated (and touched) arrays"""
+    vecs = [np.ascontiguousarray(v, np.float64) for v in vecs]
+    outs = outs if outs is not None else [np.zeros_like(v) for v in vecs]
+    n = len(vecs)
+    pv = (C.c_void_p * n)(*[v.ctypes.data for v in vecs])
+    po = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+    lens = (C.c_uint32 * n)(*[v.size for v in vecs])
+    L = lib()
+    L.orc_smooth_threads.restype = C.c_int
+    L.orc_smooth_threads.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int]
+    started = L.orc_smooth_threads(pv, lens, po, n, W, threads)
+    return outs, started
+
+
 def sliding_sum(v, W, denom=1.0):
     v, pv = _in(v)
     out = np.empty_like(v)

@@ -70,6 +70,57 @@ void orc_smooth (const double* v, uint32_t n, uint32_t W, double* out)
 	free (w);
 	}
 
+/* The same loop over every host core (bench.py's cpu_baseline_all_cores: the reference itself is single-threaded,
+ * chromosomes and stretches of them are independent for this operator, genodsp.c:909-921): thread t of T evaluates
+ * outputs [n t/T, n (t+1)/T) of every vector, reading its neighbours' inputs in place, writing into out[] that the
+ * caller has allocated AND touched (first-touch page faults are not smoothing).  Same arithmetic, same bits. */
+#include <pthread.h>
+typedef struct { const double* const* vecs;  const uint32_t* lens;  double* const* outs;  int nvec;  const double* w;
+                 uint32_t W;  int t, T; } smooth_job;
+
+static void* smooth_worker (void* arg)
+	{
+	const smooth_job* j = (const smooth_job*) arg;
+	int64_t hOff = (j->W - 1) / 2, ix, k, kLo, kHi;
+	int     c;
+	for (c=0 ; c<j->nvec ; c++)
+		{
+		const double* v = j->vecs[c];
+		const int64_t n = j->lens[c], a = n * j->t / j->T, b = n * (j->t + 1) / j->T;
+		for (ix=a ; ix<b ; ix++)
+			{
+			double acc = 0.0;
+			kLo = (ix < hOff)? hOff-ix : 0;
+			kHi = (int64_t) j->W - 1;
+			if (ix - hOff + kHi > n - 1) kHi = n - 1 + hOff - ix;
+			for (k=kLo ; k<=kHi ; k++)
+				acc += j->w[k] * v[ix-hOff+k];
+			j->outs[c][ix] = acc;
+			}
+		}
+	return NULL;
+	}
+
+int orc_smooth_threads (const double* const* vecs, const uint32_t* lens, double* const* outs, int nvec, uint32_t W, int threads)
+	{
+	double*     w    = (double*) malloc ((size_t) W * sizeof(double));
+	pthread_t*  tid  = (pthread_t*) malloc ((size_t) threads * sizeof(pthread_t));
+	smooth_job* jobs = (smooth_job*) malloc ((size_t) threads * sizeof(smooth_job));
+	int t, started = 0;
+	orc_hann_window (W, w);
+	for (t=0 ; t<threads ; t++)
+		{
+		smooth_job j = { vecs, lens, outs, nvec, w, W, t, threads };
+		jobs[t] = j;
+		if (pthread_create (&tid[t], NULL, smooth_worker, &jobs[t]) != 0) break;
+		started++;
+		}
+	for (t=started ; t<threads ; t++) smooth_worker (&jobs[t]);        /* (threads that could not be started: done here) */
+	for (t=0 ; t<started ; t++) pthread_join (tid[t], NULL);
+	free (w);  free (tid);  free (jobs);
+	return started;
+	}
+
 /* Running window sum, sum.c:436-460: one accumulator walks the vector, adding
  * the entering value and subtracting the leaving one; the sum after step ix is
  * the output for centre ix-hOff; a final pass divides by the denominator. */

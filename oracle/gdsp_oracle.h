@@ -29,6 +29,8 @@ extern "C" {
 void orc_hann_window    (uint32_t W, double* w);
 void orc_fir            (const double* v, uint32_t n, const double* w, uint32_t W, double* out);
 void orc_smooth         (const double* v, uint32_t n, uint32_t W, double* out);
+int  orc_smooth_threads (const double* const* vecs, const uint32_t* lens, double* const* outs, int nvec, uint32_t W,
+                         int threads);   /* orc_smooth of several vectors over `threads` pthreads; -> threads started */
 void orc_sliding_sum    (const double* v, uint32_t n, uint32_t W, double denom, double* out);
 void orc_window_sum     (double* v, uint32_t n, uint32_t W, double denom, int useActual, double zeroVal);
 void orc_cumulative_sum (double* v, uint32_t n);

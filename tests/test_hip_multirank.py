@@ -94,3 +94,17 @@ def test_smooth_over_equal_stretches_of_the_genome():
         assert r["parity"]["ok"] and r["parity"]["exact_bit_identical"]
         assert "equal stretches" in r["config"]["sharding"]
     assert two["roofline"]["algorithmic_bytes_per_launch"] * two["roofline"]["launches_per_step"] <= 16 * (two["config"]["bases"] // 2 + 1)
+
+
+def test_smooth_over_two_ranks_reports_both_splits_and_every_ranks_time():
+    """At N > 1 one run records both ways of splitting the genome -- whole chromosomes dealt longest-first (the metric)
+    and equal stretches of bases -- with each rank's own HIP-event milliseconds, so that a single run of the scaling
+    bench shows the load balance of either."""
+    two = _bench(2, "smooth", 0.02)
+    assert two["n_gpus"] == 2 and len(two["per_rank_ms"]) == 2 and all(t > 0 for t in two["per_rank_ms"])
+    assert sum(two["bases_per_rank"]) == two["config"]["bases"]
+    alt = two["other_sharding"]
+    assert alt["sharding"] == "bases" and len(alt["per_rank_ms"]) == 2 and alt["value"] > 0
+    assert sum(alt["bases_per_rank"]) == two["config"]["bases"]
+    assert max(alt["bases_per_rank"]) - min(alt["bases_per_rank"]) <= 1            # equal shares
+    assert two["parity"]["ok"]
