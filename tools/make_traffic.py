@@ -3,7 +3,7 @@
 HBM bytes of one launch (FETCH_SIZE, WRITE_SIZE, corrected as the summaries say) over its algorithmic bytes (B/base of
 the operator x bases of the launch).  bench.py multiplies a live launch's algorithmic bytes by that ratio for
 roofline.traffic and prints where the ratio came from.
-usage: python3 tools/make_traffic.py <library build id> [profiles dir]"""
+usage: python3 tools/make_traffic.py <library build id> [profiles dir] [round tag, default r03]"""
 import glob
 import json
 import os
@@ -12,7 +12,8 @@ import sys
 
 SKIP = ("synth_coverage_kernel", "__amd_rocclr", "fill", "copyBuffer")
 # bytes the operator has to move per base: in + out, or in only for the passes that only read
-ALGORITHMIC = {"pc_sample_kernel": 8, "pc_partition_kernel": 8, "cumsum_totals_kernel": 8, "report_count_kernel": 8,
+ALGORITHMIC = {"peaks_probe_kernel": None, "peaks_exact_kernel": None, "peaks_init_kernel": None, "fir_fixed_extrema_gated_kernel": None,
+               "pc_sample_kernel": 8, "pc_partition_kernel": 8, "cumsum_totals_kernel": 8, "report_count_kernel": 8,
                "report_write_kernel": 8, "clump_chunk_stats_kernel": 8, "clump_write_kernel": 8,
                # launches over a few words per chunk, or whose traffic is not a per-base figure: bytes only
                "clump_chunk_scan_kernel": None, "clump_bits_": None, "report_scan_kernel": None, "pc_hist_keys_kernel": None,
@@ -21,7 +22,8 @@ ALGORITHMIC = {"pc_sample_kernel": 8, "pc_partition_kernel": 8, "cumsum_totals_k
 lib = sys.argv[1]
 root = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 kernels = {}
-for path in sorted(glob.glob(os.path.join(root, "r02_prof_*.txt"))):
+tag = sys.argv[3] if len(sys.argv) > 3 else "r03"
+for path in sorted(glob.glob(os.path.join(root, tag + "_prof_*.txt"))):
     lines = open(path).read().splitlines()
     m = re.match(r"# (\S+) on (\d+) bases", lines[0])
     if not m:

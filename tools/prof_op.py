@@ -2,7 +2,9 @@
 """Small driver for rocprofv3: a few launches of one operator on one chromosome-sized vector.
 usage: python3 tools/prof_op.py <op> [launches] [n]
 ops: clump cumsum sum1000 sum100 slidingsum close open dilate erode localmax bestmax binarize smooth_exact smooth_fma
-     smooth_hann smooth_hann1001 smooth_hann2001 peaks_exact peaks_fma morph_fused percentile report select"""
+     smooth_hann smooth_hann1001 smooth_hann2001 peaks_exact peaks_fma morph_fused percentile report select
+     smooth_hann_batch smooth_exact_batch morph_fused_batch binarize_batch peaks_exact_batch   (three vectors of n/2, n/3, n/6
+     bases in one launch: the gdsp_*_batch forms, what genodsp_hip and bench.py launch by default)"""
 import ctypes as C
 import os
 import sys
@@ -25,6 +27,10 @@ def copy(dst, src):
     gd.call("gdsp_memcpy_d2d", dst.ptr, src.ptr, n * 8, None)
 
 
+# three vectors that share the two big buffers: the one-launch-per-device forms
+cuts = [0, (n // 2) & ~1, (n // 2 + n // 3) & ~1, n]
+parts_in = lambda src: [gd.DeviceVector(cuts[i+1] - cuts[i], src.buf, 8 * cuts[i]) for i in range(3)]
+parts_b = parts_in(b)
 work = None
 if op == "clump":
     work = gd.DeviceBuffer(gd.lib().gdsp_clump_work(n))
@@ -54,6 +60,11 @@ RUN = {
     "peaks_exact": lambda: gd.smooth_local_extrema(real, 101, 11, True, 0.0, out=b, mode=gd.FIR_EXACT),
     "peaks_fma": lambda: gd.smooth_local_extrema(real, 101, 11, True, 0.0, out=b, mode=gd.FIR_FMA),
     "morph_fused": lambda: gd.dilate_erode(depth, l, r, l, r, binarize=(0.0, False, 1.0, 0.0), out=b),
+    "smooth_hann_batch": lambda: gd.smooth_batch(parts_in(real), 101, outs=parts_b, mode=gd.FIR_HANN),
+    "smooth_exact_batch": lambda: gd.smooth_batch(parts_in(real), 101, outs=parts_b, mode=gd.FIR_EXACT),
+    "peaks_exact_batch": lambda: gd.smooth_local_extrema_batch(parts_in(real), 101, 11, True, 0.0, outs=parts_b, mode=gd.FIR_EXACT),
+    "morph_fused_batch": lambda: gd.dilate_erode_batch(parts_in(depth), l, r, l, r, binarize=(0.0, False, 1.0, 0.0), outs=parts_b),
+    "binarize_batch": lambda: (copy(a, depth), gd.binarize_batch(parts_in(a), 10.0)),
     "percentile": lambda: gd.percentile([real], [99000]),
     "report": lambda: gd.report_runs(depth),
 }
