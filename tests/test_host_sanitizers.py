@@ -228,3 +228,23 @@ def test_seam_crossing_command_lines_under_the_sanitizers(tmp_path):
         rc, out, err = run(BIN, case["args"], case["stdin"], tmp_path, chroms=case["chroms_text"], files=case.get("files"))
         assert rc == 0 and "Sanitizer" not in err and "runtime error" not in err, (case["name"], err[-2000:])
         assert hashlib.sha256(out).hexdigest() == case["sha256"], (case["name"], case["args"])
+
+
+def test_threaded_output_formatting_under_the_sanitizers(tmp_path):
+    """more than 65 536 output lines: the report is formatted by a team of threads (format_runs, genodsp_hip.c), every
+    stretch into its own buffer -- the same bytes as the reference prints, NA lines and a value that needs printf's
+    slow path included, whatever the team's size"""
+    chroms = "chrT 150000\nchrU 300\n"
+    text = "chrT 100 70000 3\nchrT 70000 70001 1e300\nchrT 70500 149000 2.5\nchrU 10 20 1\n"
+    for flags in (["--nocollapse", "--precision=2"], ["--nocollapse", "--uncovered:NA", "--precision=0"],
+                  ["--nocollapse", "--precision=12", "--origin=one"]):
+        outs = []
+        for threads in ("1", "4", "7"):
+            ENV["GDSP_OUTPUT_THREADS"] = threads
+            try:
+                rc, out, err = same_as_reference(flags, text, tmp_path, chroms=chroms)
+            finally:
+                del ENV["GDSP_OUTPUT_THREADS"]
+            assert rc == 0 and out.count(b"\n") > 140000
+            outs.append(out)
+        assert outs[0] == outs[1] == outs[2]
