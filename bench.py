@@ -589,6 +589,22 @@ def cpu_baseline(gd, lengths, names, stream):
             "hip_exact_bit_identical_on_sample": bool(same)}
 
 
+def cpu_quota_cores():
+    """the CPU share of this container in cores (cgroup v2 cpu.max or v1 cfs quota), None when unlimited / unknown"""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+            return None if q == "max" else max(1, int(int(q) / int(per)))
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+            q, per = int(f.read()), int(g.read())
+            return None if q <= 0 else max(1, q // per)
+    except Exception:
+        return None
+
+
 def cpu_baseline_all_cores(gd, lengths, names, stream):
     """the CPU restatement (oracle port) over every host core this process may use: pthreads inside
     liboracle.so, thread t of T taking the t-th stretch of every chromosome of the sample (neighbours read in place),
@@ -597,6 +613,9 @@ def cpu_baseline_all_cores(gd, lengths, names, stream):
     from oracle import cpu
     nproc = os.cpu_count() or 1
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else nproc     # what `nproc` prints
+    quota = cpu_quota_cores()
+    if quota is not None:
+        cores = max(1, min(cores, quota))          # a container's CPU share: more threads than that only take turns
     if os.environ.get("GDSP_HOST_CORES"):
         cores = min(cores, int(os.environ["GDSP_HOST_CORES"]))
     sample = [names.index(c) for c in ("chr13", "chr14", "chr15", "chr16", "chr17", "chr18", "chr19", "chr20", "chr21", "chr22", "chrY")]
@@ -613,10 +632,12 @@ def cpu_baseline_all_cores(gd, lengths, names, stream):
     # ... and they are the single-threaded loop's bits (a stretch of the last chromosome)
     same = outs[-1][:200000].tobytes() == cpu.smooth(vecs[-1][:200050], WINDOW)[:200000].tobytes()
     return {"value": round(bases / dt / 1e9, 5), "unit": "Gbases/s", "cores": started, "kind": "port",
-            "host_logical_cpus": nproc, "usable_by_this_process": cores, "same_bits_as_one_thread": bool(same),
+            "host_logical_cpus": nproc, "usable_by_this_process": cores, "cgroup_cpu_quota_cores": quota,
+            "same_bits_as_one_thread": bool(same),
             "sample": "smooth W=101 on chr13..chr22+chrY (%d bases), %d pthreads each taking one stretch of every chromosome (every "
                       "core this process may use; kind \"port\" = the CPU restatement, the reference itself is single-threaded), "
                       "outputs preallocated, %.2f s" % (bases, started, dt)}
+
 
 
 if __name__ == "__main__":

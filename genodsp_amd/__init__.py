@@ -550,10 +550,56 @@ def rccl_version():
 def percentile_stats():
     """What the last percentile() did: route (SELECT_RADIX / SELECT_BRACKET), population, subsample size,
     candidates kept on this rank, percentiles that fell back, histogram passes over the population."""
-    out = (C.c_uint64 * 6)()
+    out = (C.c_uint64 * 8)()
     lib().gdsp_percentiles_stats(out)
-    keys = ("route", "population", "sample", "candidates", "fallbacks", "population_passes")
+    keys = ("route", "population", "sample", "candidates", "fallbacks", "population_passes", "binarize_in_one_pass")
     return dict(zip(keys, [int(x) for x in out]))
+
+
+class PercentileBinarize(C.Structure):
+    _fields_ = [("which", C.c_int), ("tiesAbove", C.c_int), ("one", C.c_double), ("zero", C.c_double), ("d_out", C.c_void_p)]
+
+
+def percentile_binarize(vecs, p_thousandths, which=0, outs=None, ties_above=False, one=1.0, zero=0.0, window=1, lo=-DBL_MAX,
+                        hi=DBL_MAX, stream=None, strategy=SELECT_AUTO, sample_target=0, device_allreduce=None):
+    """`= percentile P = binarize --threshold=percentileP` in one read of the signal (gdsp_percentiles_binarize):
+    -> (count, [values], outs, one_pass); outs[i] = binarize(vecs[i], values[which]), the vectors are left intact."""
+    device = current_device()
+    outs = outs if outs is not None else [v.like() for v in vecs]
+    src = (SelectSource * max(1, len(vecs)))()
+    for i, v in enumerate(vecs):
+        src[i].d_v, src[i].n, src[i].device, src[i].stream = v.ptr, v.n, device, stream
+    optrs = (C.c_void_p * max(1, len(vecs)))(*[o.ptr.value for o in outs])
+    fuse = PercentileBinarize(int(which), int(ties_above), float(one), float(zero), C.cast(optrs, C.c_void_p))
+    pts = (C.c_uint32 * len(p_thousandths))(*[int(p) for p in p_thousandths])
+    vals = (C.c_double * len(p_thousandths))()
+    count, one_pass = C.c_uint64(0), C.c_int(0)
+    failure = []
+
+    def device_reduce(_ctx, d_words, n, op, s):
+        try:
+            device_allreduce(d_words, n, ("sum", "min", "max")[op], s)
+            return 0
+        except Exception as e:
+            failure.append(e)
+            return 1
+
+    dcb = DEVICE_REDUCE_FN(device_reduce) if device_allreduce is not None else None
+    try:
+        if dcb is not None:
+            call("gdsp_percentiles_use_device_reduce", dcb, None)
+        call("gdsp_percentiles_binarize", src, len(vecs), int(window), float(lo), float(hi), pts, len(p_thousandths),
+             int(strategy), int(sample_target), C.cast(None, REDUCE_FN), None, vals, C.byref(count), C.byref(fuse), C.byref(one_pass))
+    except GdspError:
+        if failure:
+            raise failure[0]
+        raise
+    finally:
+        if dcb is not None:
+            call("gdsp_percentiles_use_device_reduce", None, None)
+    if count.value == 0:
+        return 0, [], outs, False
+    return int(count.value), [float(x) for x in vals], outs, bool(one_pass.value)
 
 
 def percentile_by_passes(vecs, p_thousandths, window=1, lo=-DBL_MAX, hi=DBL_MAX, allreduce=None, stream=None):

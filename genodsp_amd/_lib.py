@@ -100,6 +100,7 @@ SIGNATURES = {
     "gdsp_double_to_key": (_u64, [_f64]),
     "gdsp_percentile_rank": (_u32, [_u32, _u32]),
     "gdsp_percentiles": (_int, [_vp, _int, _u32, _f64, _f64, _vp, _int, _int, _u32, _vp, _vp, _vp, _vp]),
+    "gdsp_percentiles_binarize": (_int, [_vp, _int, _u32, _f64, _f64, _vp, _int, _int, _u32, _vp, _vp, _vp, _vp, _vp, C.POINTER(_int)]),
     "gdsp_percentiles_stats": (None, [_vp]),
     "gdsp_comm_create": (_int, [C.POINTER(_vp), C.POINTER(_int), _int]),
     "gdsp_comm_destroy": (_int, [_vp]),

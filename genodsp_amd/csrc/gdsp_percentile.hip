@@ -103,15 +103,25 @@ void pc_sample_kernel (const double* __restrict__ v, uint32_t n, uint32_t window
 #define PC_REPL         64
 #define PC_CTR_ALL      (PC_REPL * PC_CTR_WORDS + 1)      // replicas, then the candidate count
 
-template <int M, bool BOUNDED, bool DENSE>
+// FUSE: `= percentile P = binarize --threshold=percentileP` in the same read (logical.c:216-268 behind percentile.c:392-751).
+// The threshold T -- the percentile -- is not known yet, but its bracket [vLo, vHi] is: a value above vHi is above T, a
+// value below vLo (or a NaN) is not, and both are written as `one` / `zero` right here (16-byte stores, out of place).
+// What lies inside the bracket, pivot ties included (0.1 % of real-valued coverage, a few per cent of read depth), is
+// left for pc_fixup_kernel: its position goes to a list (wave-aggregated like the candidates), `zero` is written
+// meanwhile.  8 B read + 8 B written per base for the pair of operators instead of 24.
+struct PcFuse { double vLo, vHi, one, zero;  double* out;  uint32_t* pos;  unsigned long long* posCount;  uint32_t posCap; };
+
+template <int M, bool BOUNDED, bool DENSE, bool FUSE>
 __global__ __launch_bounds__(PC_THREADS)
 void pc_partition_kernel (const double* __restrict__ v, uint32_t n, uint32_t window, double lo, double hi, PcPivots P,
                           unsigned long long* __restrict__ ctr, uint64_t* __restrict__ cand, unsigned long long cap,
-                          uint32_t ntiles)
+                          uint32_t ntiles, PcFuse F)
 	{
 	constexpr int NC = 2*M + 5;                                // counters of this instantiation
 	__shared__ uint64_t wbuf[PC_THREADS/64][PC_WAVE_BUF];
 	__shared__ uint32_t wcount[PC_THREADS/64][NC];
+	__shared__ uint32_t ubuf[FUSE? PC_THREADS/64 : 1][FUSE? PC_WAVE_BUF : 1];
+	uint32_t uheld = 0;                                        // undecided positions waiting in this wave's buffer (wave uniform)
 
 	const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const size_t   npop = DENSE? (size_t) n : ((size_t) n + window - 1) / window;
@@ -204,14 +214,53 @@ void pc_partition_kernel (const double* __restrict__ v, uint32_t n, uint32_t win
 			}
 		};
 
+	auto uflush = [&] ()
+		{
+		unsigned long long base = 0;
+		if (lane == 0) base = atomicAdd (F.posCount, (unsigned long long) uheld);
+		base = __shfl (base, 0, 64);
+		for (uint32_t i=lane ; i<uheld ; i+=64) { if (base + i < F.posCap) F.pos[base + i] = ubuf[wave][i]; }
+		uheld = 0;
+		};
+	// the binarized value of x where the bracket decides it, `zero` and a queued position where it does not
+	auto settle = [&] (double x, size_t e, bool exists)
+		{
+		const bool isOne = (x > F.vHi);
+		const bool open  = exists && !isOne && !(x < F.vLo) && (x == x);
+		const uint64_t und = __ballot (open);
+		if (und != 0)
+			{
+			if (open) ubuf[wave][uheld + __popcll (und & ((1ULL << lane) - 1))] = (uint32_t) e;
+			uheld += (uint32_t) __popcll (und);
+			__builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier ();
+			if (uheld > PC_WAVE_BUF - 64) uflush ();
+			}
+		return isOne? F.one : F.zero;
+		};
+
 	for (uint32_t tile=blockIdx.x ; tile<ntiles ; tile+=step)
 		{
 		double2 cur[8];
 		load (tile, cur);
 #pragma unroll
 		for (int u=0 ; u<8 ; u++) { count (cur[u].x);  count (cur[u].y); }
+		if (FUSE)                                                  // (DENSE: element e of the vector is population element e)
+			{
+			const size_t base = (size_t) tile * PC_TILE;
+			const bool   full = (base + PC_TILE <= npop);
+#pragma unroll
+			for (int u=0 ; u<8 ; u++)
+				{
+				const size_t e = base + 2 * ((size_t) u*PC_THREADS + threadIdx.x);
+				const double r0 = settle (cur[u].x, e, e < npop), r1 = settle (cur[u].y, e + 1, e + 1 < npop);
+				if (full) gdsp_st2 (reinterpret_cast<double2*> (F.out + e), make_double2 (r0, r1));
+				else { if (e < npop) F.out[e] = r0;  if (e + 1 < npop) F.out[e + 1] = r1; }
+				}
+			}
 		}
 	if (held) flush ();
+	if (FUSE && uheld) uflush ();
 
 	auto wave_sum = [&] (uint32_t c)
 		{
@@ -276,6 +325,34 @@ void pc_hist_keys_kernel (const uint64_t* __restrict__ keys, unsigned long long 
 		}
 	}
 
+// the bases the bracket left open, now that the threshold is known (logical.c:247-257)
+__global__ __launch_bounds__(PC_THREADS)
+void pc_fixup_kernel (const double* __restrict__ v, double* __restrict__ out, const uint32_t* __restrict__ pos,
+                      const unsigned long long* __restrict__ posCount, uint32_t cap, double T, int tiesAbove, double one, double zero)
+	{
+	const unsigned long long count = (*posCount < cap)? *posCount : cap;
+	const size_t stride = (size_t) gridDim.x * PC_THREADS;
+	for (size_t i = (size_t) blockIdx.x * PC_THREADS + threadIdx.x ; i < count ; i += stride)
+		{
+		const uint32_t e = pos[i];
+		const double   x = v[e];
+		out[e] = (tiesAbove? (x >= T) : (x > T))? one : zero;
+		}
+	}
+
+// ... and the whole vector when the one-pass route could not be taken for it (a list that overflowed, an unaligned or
+// strided source, a percentile that fell outside its bracket): binarize, out of place
+__global__ __launch_bounds__(PC_THREADS)
+void pc_binarize_kernel (const double* __restrict__ v, double* __restrict__ out, uint32_t n, double T, int tiesAbove, double one, double zero)
+	{
+	const size_t stride = (size_t) gridDim.x * PC_THREADS;
+	for (size_t i = (size_t) blockIdx.x * PC_THREADS + threadIdx.x ; i < n ; i += stride)
+		{
+		const double x = v[i];
+		out[i] = (tiesAbove? (x >= T) : (x > T))? one : zero;
+		}
+	}
+
 // ------------------------------------------------------------- host side ----
 static const int pcShift[] = { 52, 39, 26, 13, 0 };
 static const int pcBits[]  = { 12, 13, 13, 13, 13 };
@@ -290,9 +367,12 @@ struct PcDevice                                               // scratch of one 
 	uint64_t* tmp;        // PC_TMP_WORDS: host scalars on their way through a device-side reduction
 	uint64_t* sample;  size_t sampleCap;
 	uint64_t* cand;    size_t candCap;
+	uint32_t* pos;     size_t posCap;     // fused binarize: positions the bracket left open, every source's strip one after the other
+	unsigned long long* posCount;         // one counter per source (PC_MAX_FUSED_SOURCES)
 	};
+#define PC_MAX_FUSED_SOURCES 256
 #define PC_TMP_WORDS 64
-static uint64_t   pcStats[6];
+static uint64_t   pcStats[8];
 static gdsp_comm*            pcComm    = NULL;                // see gdsp_percentiles_use_comm
 static gdsp_device_reduce_fn pcDReduce = NULL;                // see gdsp_percentiles_use_device_reduce
 static void*                 pcDReduceCtx = NULL;
@@ -313,6 +393,7 @@ static int pc_device (int device, size_t sampleCap, size_t candCap, PcDevice** o
 		GDSP_HIP_TRY (hipMalloc ((void**) &d->hist, PC_HIST_WORDS * sizeof(uint64_t)));
 		GDSP_HIP_TRY (hipMalloc ((void**) &d->ctr,  PC_CTR_ALL * sizeof(uint64_t)));
 		GDSP_HIP_TRY (hipMalloc ((void**) &d->tmp,  PC_TMP_WORDS * sizeof(uint64_t)));
+		GDSP_HIP_TRY (hipMalloc ((void**) &d->posCount, PC_MAX_FUSED_SOURCES * sizeof(unsigned long long)));
 		}
 	if (d->sampleCap < sampleCap)
 		{
@@ -343,6 +424,12 @@ struct PcJob                                                  // one call of gds
 	std::vector<PcDevice*> scratch;                           // same order
 	std::vector<void*>     stream;                            // a stream of that device (its first source's)
 	std::vector<uint64_t>  sampleCount, candCount;            // per device
+	// `percentile = binarize` in one read (gdsp_percentiles_binarize): what is asked, and what the counting pass did about it
+	const gdsp_percentile_binarize* fuse;
+	std::vector<int>       fusedSource;                       // per source: its slot in the device's position strips, -1 = not fused
+	std::vector<size_t>    posOffset, posCap;                 // per source
+	double                 vLo, vHi;                          // the bracket the fused stores relied on
+	bool                   fusedAny;
 	};
 
 #define PC_TRY(call) do { int rc_ = (call);  if (rc_ != GDSP_OK) return rc_; } while (0)
@@ -501,11 +588,9 @@ static int pc_radix (PcJob& J, const uint32_t* pts, const std::vector<int>& whic
 	return GDSP_OK;
 	}
 
-extern "C" {
-
-int gdsp_percentiles (const gdsp_select_source* sources, int nsources, uint32_t window, double lo, double hi,
-                      const uint32_t* pThousandths, int npercentiles, int strategy, uint32_t sampleTarget,
-                      gdsp_reduce_fn reduce, void* reduceCtx, double* values, uint64_t* count)
+static int pc_run (const gdsp_select_source* sources, int nsources, uint32_t window, double lo, double hi,
+                   const uint32_t* pThousandths, int npercentiles, int strategy, uint32_t sampleTarget,
+                   gdsp_reduce_fn reduce, void* reduceCtx, double* values, uint64_t* count, PcJob& J)
 	{
 	GDSP_REQUIRE ((values != NULL) && (count != NULL) && (pThousandths != NULL), "NULL pointer");
 	GDSP_REQUIRE ((nsources >= 0) && (npercentiles >= 1), "nothing to do");
@@ -517,13 +602,10 @@ int gdsp_percentiles (const gdsp_select_source* sources, int nsources, uint32_t 
 	if (defaultTarget) sampleTarget = PC_SAMPLE_TARGET;
 	if (!(lo <= hi)) strategy = GDSP_SELECT_RADIX;                // only NaNs can pass such a filter: no brackets
 
-	std::lock_guard<std::mutex> hold (pcLock);
 	memset (pcStats, 0, sizeof(pcStats));
 	int homeDevice = 0;
 	GDSP_HIP_TRY (hipGetDevice (&homeDevice));
-	struct Home { int device;  ~Home () { (void) hipSetDevice (device); } } home = { homeDevice };   // whatever path returns
 
-	PcJob J;
 	J.src = sources;  J.nsrc = nsources;  J.window = window;  J.lo = lo;  J.hi = hi;  J.reduce = reduce;  J.ctx = reduceCtx;
 	J.comm = pcComm;  J.dreduce = pcDReduce;  J.dctx = pcDReduceCtx;
 	GDSP_REQUIRE (!((J.comm != NULL) && (J.dreduce != NULL)), "a communicator and a device reduction hook are both set");
@@ -591,6 +673,33 @@ int gdsp_percentiles (const gdsp_select_source* sources, int nsources, uint32_t 
 		PcDevice* sc = NULL;
 		PC_TRY (pc_device (J.devices[d], bracket? slots + 64 : 0, cands, &sc));
 		J.scratch.push_back (sc);
+		}
+	// fused binarize: a strip of positions per dense source (a sixteenth of its bases; more undecided than that and the
+	// source is binarized by a pass of its own)
+	J.fusedSource.assign (nsources, -1);  J.posOffset.assign (nsources, 0);  J.posCap.assign (nsources, 0);  J.fusedAny = false;
+	if ((J.fuse != NULL) && bracket && (window == 1))
+		{
+		for (size_t d=0 ; d<J.devices.size () ; d++)
+			{
+			size_t words = 0;
+			int    slot  = 0;
+			for (int i=0 ; i<nsources ; i++)
+				{
+				if ((sources[i].device != J.devices[d]) || (sources[i].n == 0) || !gdsp_aligned16 (sources[i].d_v)
+				 || !gdsp_aligned16 (J.fuse->d_out[i]) || (slot == PC_MAX_FUSED_SOURCES)) continue;
+				J.fusedSource[i] = slot++;  J.posOffset[i] = words;  J.posCap[i] = (size_t) sources[i].n / 16 + 4096;
+				words += J.posCap[i];
+				}
+			PcDevice* sc = J.scratch[d];
+			if (sc->posCap < words)
+				{
+				GDSP_HIP_TRY (hipSetDevice (J.devices[d]));
+				if (sc->pos != NULL) GDSP_HIP_TRY (hipFree (sc->pos));
+				sc->pos = NULL;  sc->posCap = 0;
+				GDSP_HIP_TRY (hipMalloc ((void**) &sc->pos, (words + words / 8) * sizeof(uint32_t)));
+				sc->posCap = words + words / 8;
+				}
+			}
 		}
 	J.sampleCount.assign (J.devices.size (), 0);
 	J.candCount.assign (J.devices.size (), 0);
@@ -678,11 +787,21 @@ int gdsp_percentiles (const gdsp_select_source* sources, int nsources, uint32_t 
 
 	// ---- 3. the counting pass (bounds as far out as the defaults only keep the infinities away)
 	const bool bounded = !((lo <= -DBL_MAX) && (hi >= DBL_MAX));
+	// a fused binarize rests on the bracket of ITS percentile: a NaN end cannot be compared, an open end decides nothing
+	bool fuseUsable = false;
+	if (J.fuse != NULL)
+		{
+		const int w = J.fuse->which;
+		J.vLo = openLo[w]? -INFINITY : gdsp_value_of (bLo[w]);
+		J.vHi = openHi[w]?  INFINITY : gdsp_value_of (bHi[w]);
+		fuseUsable = (J.vLo == J.vLo) && (J.vHi == J.vHi);
+		}
 	uint64_t   padded  = 0;                                      // elements the kernels count, padding included
 	for (size_t d=0 ; d<J.devices.size () ; d++)
 		{
 		GDSP_HIP_TRY (hipSetDevice (J.devices[d]));
 		GDSP_HIP_TRY (hipMemsetAsync (J.scratch[d]->ctr, 0, PC_CTR_ALL * sizeof(uint64_t), gdsp_stream (J.stream[d])));
+		GDSP_HIP_TRY (hipMemsetAsync (J.scratch[d]->posCount, 0, PC_MAX_FUSED_SOURCES * sizeof(unsigned long long), gdsp_stream (J.stream[d])));
 		unsigned long long* ctr = (unsigned long long*) J.scratch[d]->ctr;
 		for (int i=0 ; i<nsources ; i++)
 			{
@@ -692,13 +811,27 @@ int gdsp_percentiles (const gdsp_select_source* sources, int nsources, uint32_t 
 			const uint32_t perWG  = std::max<uint32_t> (1, std::min<uint32_t> (PC_TILES_PER_WG, ntiles / PC_MIN_WGS));
 			const uint32_t blocks = (ntiles + perWG - 1) / perWG;
 			const bool     dense  = (window == 1) && gdsp_aligned16 (sources[i].d_v);
+			const bool     fused  = (J.fusedSource[i] >= 0) && fuseUsable;
+			PcFuse F;
+			memset (&F, 0, sizeof(F));
+			if (fused)
+				{
+				F.vLo = J.vLo;  F.vHi = J.vHi;  F.one = J.fuse->one;  F.zero = J.fuse->zero;  F.out = J.fuse->d_out[i];
+				F.pos = J.scratch[d]->pos + J.posOffset[i];  F.posCount = J.scratch[d]->posCount + J.fusedSource[i];
+				F.posCap = (uint32_t) J.posCap[i];
+				J.fusedAny = true;
+				}
+			else J.fusedSource[i] = -1;
 #define PC_LAUNCH_B(MM, BB)                                                                                                    \
-			do { if (dense) hipLaunchKernelGGL ((pc_partition_kernel<MM, BB, true>),  dim3(blocks), dim3(PC_THREADS), 0,          \
+			do { if (fused) hipLaunchKernelGGL ((pc_partition_kernel<MM, BB, true, true>),  dim3(blocks), dim3(PC_THREADS), 0,    \
 			                                     gdsp_stream (J.stream[d]), sources[i].d_v, sources[i].n, window, lo, hi, P, ctr, \
-			                                     J.scratch[d]->cand, (unsigned long long) J.scratch[d]->candCap, ntiles);  \
-			     else       hipLaunchKernelGGL ((pc_partition_kernel<MM, BB, false>), dim3(blocks), dim3(PC_THREADS), 0,          \
+			                                     J.scratch[d]->cand, (unsigned long long) J.scratch[d]->candCap, ntiles, F);  \
+			     else if (dense) hipLaunchKernelGGL ((pc_partition_kernel<MM, BB, true, false>),  dim3(blocks), dim3(PC_THREADS), 0, \
 			                                     gdsp_stream (J.stream[d]), sources[i].d_v, sources[i].n, window, lo, hi, P, ctr, \
-			                                     J.scratch[d]->cand, (unsigned long long) J.scratch[d]->candCap, ntiles); } while (0)
+			                                     J.scratch[d]->cand, (unsigned long long) J.scratch[d]->candCap, ntiles, F);  \
+			     else       hipLaunchKernelGGL ((pc_partition_kernel<MM, BB, false, false>), dim3(blocks), dim3(PC_THREADS), 0,   \
+			                                     gdsp_stream (J.stream[d]), sources[i].d_v, sources[i].n, window, lo, hi, P, ctr, \
+			                                     J.scratch[d]->cand, (unsigned long long) J.scratch[d]->candCap, ntiles, F); } while (0)
 #define PC_LAUNCH(MM) do { if (bounded) PC_LAUNCH_B (MM, true);  else PC_LAUNCH_B (MM, false); } while (0)
 			padded += (uint64_t) ntiles * PC_TILE;
 			if      (P.m <= 2)  PC_LAUNCH (2);
@@ -820,6 +953,106 @@ int gdsp_percentiles (const gdsp_select_source* sources, int nsources, uint32_t 
 	return finish (rc);
 	}
 
+// binarize every source into its output now that the threshold is known: the bases the bracket left open where the
+// counting pass wrote the rest, the whole vector elsewhere
+static int pc_finish_binarize (PcJob& J, double T, bool* onePass)
+	{
+	const gdsp_percentile_binarize* f = J.fuse;
+	const bool bracketHolds = J.fusedAny && (T >= J.vLo) && (T <= J.vHi);
+	// positions queued per fused source: one copy per device
+	std::vector<std::vector<unsigned long long> > queued (J.devices.size ());
+	if (bracketHolds)
+		{
+		for (size_t d=0 ; d<J.devices.size () ; d++)
+			{
+			queued[d].assign (PC_MAX_FUSED_SOURCES, 0);
+			GDSP_HIP_TRY (hipSetDevice (J.devices[d]));
+			GDSP_HIP_TRY (hipMemcpyAsync (queued[d].data (), J.scratch[d]->posCount, PC_MAX_FUSED_SOURCES * sizeof(unsigned long long),
+			                              hipMemcpyDeviceToHost, gdsp_stream (J.stream[d])));
+			}
+		for (size_t d=0 ; d<J.devices.size () ; d++)
+			{ GDSP_HIP_TRY (hipSetDevice (J.devices[d]));  GDSP_HIP_TRY (hipStreamSynchronize (gdsp_stream (J.stream[d]))); }
+		}
+	bool all = bracketHolds;
+	for (int i=0 ; i<J.nsrc ; i++)
+		{
+		if (J.src[i].n == 0) continue;
+		size_t d = 0;
+		while (J.devices[d] != J.src[i].device) d++;
+		GDSP_HIP_TRY (hipSetDevice (J.devices[d]));
+		hipStream_t st = gdsp_stream (J.stream[d]);
+		const int slot = bracketHolds? J.fusedSource[i] : -1;
+		if ((slot >= 0) && (queued[d][slot] <= J.posCap[i]))
+			{
+			const unsigned long long count = queued[d][slot];
+			if (count == 0) continue;
+			const uint32_t blocks = (uint32_t) std::min<unsigned long long> (2048, (count + PC_THREADS - 1) / PC_THREADS);
+			hipLaunchKernelGGL (pc_fixup_kernel, dim3(blocks), dim3(PC_THREADS), 0, st, J.src[i].d_v, f->d_out[i],
+			                    J.scratch[d]->pos + J.posOffset[i], J.scratch[d]->posCount + slot, (uint32_t) J.posCap[i],
+			                    T, f->tiesAbove, f->one, f->zero);
+			}
+		else
+			{
+			all = false;
+			const uint32_t blocks = (uint32_t) std::min<size_t> (4096, ((size_t) J.src[i].n + PC_THREADS - 1) / PC_THREADS);
+			hipLaunchKernelGGL (pc_binarize_kernel, dim3(blocks), dim3(PC_THREADS), 0, st, J.src[i].d_v, f->d_out[i], J.src[i].n,
+			                    T, f->tiesAbove, f->one, f->zero);
+			}
+		GDSP_LAUNCH_CHECK ();
+		}
+	*onePass = all;
+	return GDSP_OK;
+	}
+
+static int pc_entry (const gdsp_select_source* sources, int nsources, uint32_t window, double lo, double hi,
+                     const uint32_t* pThousandths, int npercentiles, int strategy, uint32_t sampleTarget,
+                     gdsp_reduce_fn reduce, void* reduceCtx, double* values, uint64_t* count,
+                     const gdsp_percentile_binarize* fuse, int* onePass)
+	{
+	std::lock_guard<std::mutex> hold (pcLock);
+	int homeDevice = 0;
+	GDSP_HIP_TRY (hipGetDevice (&homeDevice));
+	struct Home { int device;  ~Home () { (void) hipSetDevice (device); } } home = { homeDevice };   // whatever path returns
+	PcJob J;
+	J.fuse = fuse;  J.fusedAny = false;  J.vLo = J.vHi = 0.0;
+	if (onePass != NULL) *onePass = 0;
+	if (fuse != NULL)
+		{
+		GDSP_REQUIRE ((fuse->which >= 0) && (fuse->which < npercentiles), "the fused binarize names no requested percentile");
+		GDSP_REQUIRE (fuse->d_out != NULL, "NULL outputs");
+		for (int i=0 ; i<nsources ; i++)
+			GDSP_REQUIRE ((sources[i].n == 0) || ((fuse->d_out[i] != NULL) && (fuse->d_out[i] != sources[i].d_v)), "outputs must be distinct from the sources and non-NULL");
+		}
+	int rc = pc_run (sources, nsources, window, lo, hi, pThousandths, npercentiles, strategy, sampleTarget, reduce, reduceCtx,
+	                 values, count, J);
+	if ((rc != GDSP_OK) || (fuse == NULL) || (*count == 0)) return rc;
+	bool all = false;
+	rc = pc_finish_binarize (J, values[fuse->which], &all);
+	pcStats[6] = all? 1 : 0;
+	if (onePass != NULL) *onePass = all? 1 : 0;
+	return rc;
+	}
+
+extern "C" {
+
+int gdsp_percentiles (const gdsp_select_source* sources, int nsources, uint32_t window, double lo, double hi,
+                      const uint32_t* pThousandths, int npercentiles, int strategy, uint32_t sampleTarget,
+                      gdsp_reduce_fn reduce, void* reduceCtx, double* values, uint64_t* count)
+	{
+	return pc_entry (sources, nsources, window, lo, hi, pThousandths, npercentiles, strategy, sampleTarget, reduce, reduceCtx,
+	                 values, count, NULL, NULL);
+	}
+
+int gdsp_percentiles_binarize (const gdsp_select_source* sources, int nsources, uint32_t window, double lo, double hi,
+                               const uint32_t* pThousandths, int npercentiles, int strategy, uint32_t sampleTarget,
+                               gdsp_reduce_fn reduce, void* reduceCtx, double* values, uint64_t* count,
+                               const gdsp_percentile_binarize* fuse, int* onePass)
+	{
+	GDSP_REQUIRE (fuse != NULL, "nothing to fuse");
+	return pc_entry (sources, nsources, window, lo, hi, pThousandths, npercentiles, strategy, sampleTarget, reduce, reduceCtx,
+	                 values, count, fuse, onePass);
+	}
+
 // how the devices' counts are combined from now on (see the head of this file); NULL = on the host
 int gdsp_percentiles_use_comm (gdsp_comm* comm)
 	{
@@ -835,7 +1068,7 @@ int gdsp_percentiles_use_device_reduce (gdsp_device_reduce_fn fn, void* ctx)
 	return GDSP_OK;
 	}
 
-void gdsp_percentiles_stats (uint64_t out[6])
+void gdsp_percentiles_stats (uint64_t out[8])
 	{
 	std::lock_guard<std::mutex> hold (pcLock);
 	memcpy (out, pcStats, sizeof(pcStats));

@@ -292,10 +292,25 @@ int gdsp_percentiles_use_comm (gdsp_comm* comm);
 typedef int (*gdsp_device_reduce_fn) (void* ctx, uint64_t* d_words, size_t count, int op, void* stream);
 int gdsp_percentiles_use_device_reduce (gdsp_device_reduce_fn fn, void* ctx);
 
+/* `= percentile P = binarize --threshold=percentileP` (percentile.c:392-751 feeding logical.c:216-268) in ONE read of the
+ * signal: the counting pass knows the bracket the percentile lies in before it knows the percentile, so it writes
+ * one / zero for every base outside that bracket as it counts and queues the positions inside it (0.1 % of real-valued
+ * coverage) for a fix-up once the value is known -- 16 B/base for the pair instead of 24.  d_out[i] receives
+ * binarize(source i) against values[which] (out of place: the sources are left intact); *onePass = 1 when every source
+ * went that way, 0 when some (or all) were binarized by a pass of their own -- strided sampling (window > 1), the radix
+ * route, a percentile that fell outside its bracket, more than n/16 bases inside the bracket.  Same values, same
+ * outputs either way.  *count = 0 (nothing qualifies): no output is written. */
+typedef struct gdsp_percentile_binarize { int which;  int tiesAbove;  double one, zero;  double* const* d_out; } gdsp_percentile_binarize;
+int gdsp_percentiles_binarize (const gdsp_select_source* sources, int nsources, uint32_t window, double lo, double hi,
+                               const uint32_t* pThousandths, int npercentiles, int strategy, uint32_t sampleTarget,
+                               gdsp_reduce_fn reduce, void* reduceCtx, double* values, uint64_t* count,
+                               const gdsp_percentile_binarize* fuse, int* onePass);
+
 /* what the last gdsp_percentiles call of this process did: [0] route taken (GDSP_SELECT_RADIX or
  * _BRACKET), [1] population, [2] subsample size, [3] candidates kept on this rank, [4] percentiles
- * that fell back to the radix route, [5] histogram passes over the population */
-void gdsp_percentiles_stats (uint64_t out[6]);
+ * that fell back to the radix route, [5] histogram passes over the population, [6] 1 when a fused binarize
+ * was settled in the counting pass for every source, [7] unused */
+void gdsp_percentiles_stats (uint64_t out[8]);
 
 /* ---- genodsp.c read_intervals / add.c / multiply.c ------------------------------ */
 

@@ -1,0 +1,59 @@
+"""GPU: `= percentile P = binarize --threshold=percentileP` in one read of the signal (gdsp_percentiles_binarize):
+the percentile values are gdsp_percentiles' and the outputs are gdsp_binarize's against that value, bit for bit --
+whether the counting pass settled every base (one_pass), some sources fell to a pass of their own, or the whole call
+took the radix route.  Reference: percentile.c:392-751 feeding logical.c:216-268."""
+import numpy as np
+import pytest
+
+from conftest import bits_equal
+from oracle import cpu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gd():
+    import genodsp_amd
+    return genodsp_amd
+
+
+def signals(n, seed):
+    rng = np.random.default_rng(seed)
+    out = {"real": cpu.synth_coverage(20240611, 3, 0, n, 1), "depth": cpu.synth_coverage(20240611, 4, 0, n, 0)}
+    x = rng.standard_normal(n) * 5.0
+    x[::97] = np.nan
+    x[5::1013] = np.inf
+    x[7::1019] = -np.inf
+    out["noise with nan and inf"] = x
+    return out
+
+
+@pytest.mark.parametrize("n", [5000, 1 << 20, 3_000_001])
+def test_fused_equals_percentile_then_binarize(n, gd):
+    for name, x in signals(n, n).items():
+        parts = [x[: n // 3], x[n // 3: n // 3 + 16 * ((n // 2) // 16)], x[n // 3 + 16 * ((n // 2) // 16):]]
+        vecs = [gd.DeviceVector.from_numpy(p) for p in parts]
+        for pts, which in (([99000], 0), ([50000, 90000, 99900], 1), ([100], 0)):
+            for kw in ({}, {"ties_above": True, "one": 7.0, "zero": -2.0}, {"lo": 1.0, "hi": 40.0}, {"window": 3}):
+                cnt, vals = gd.percentile(vecs, pts, **{k: v for k, v in kw.items() if k in ("lo", "hi", "window")})
+                c2, v2, outs, one_pass = gd.percentile_binarize(vecs, pts, which=which, **kw)
+                assert (c2, v2) == (cnt, vals), (name, pts, kw)
+                if cnt == 0:
+                    continue
+                T = vals[which]
+                for p, o in zip(parts, outs):
+                    want = cpu.binarize(p, T, kw.get("ties_above", False), kw.get("one", 1.0), kw.get("zero", 0.0))
+                    assert bits_equal(o.numpy(), want), (name, pts, kw, one_pass)
+                if n >= (1 << 21) and name == "real" and "window" not in kw:
+                    assert one_pass, (pts, kw)                     # the counting pass settled it (the route under test)
+                if "window" in kw or n < 10000:
+                    assert not one_pass
+
+
+def test_fused_leaves_sources_intact_and_reports_nothing_when_nothing_qualifies(gd):
+    x = cpu.synth_coverage(20240611, 1, 0, 2_500_000, 1)
+    v = gd.DeviceVector.from_numpy(x)
+    cnt, vals, outs, one_pass = gd.percentile_binarize([v], [99000])
+    assert bits_equal(v.numpy(), x) and one_pass
+    cnt, vals, outs, one_pass = gd.percentile_binarize([v], [99000], lo=1e30, hi=1e31)
+    assert cnt == 0 and vals == [] and not one_pass
