@@ -819,6 +819,8 @@ static void to_pieces (void)
 	signalInPieces = true;  halosFresh = true;
 	}
 
+int signal_in_whole_chromosomes (void) { return !shardBases && !signalInPieces; }
+
 /* stretches -> whole chromosomes: every stretch returns the bases it answers for */
 void to_whole (void)
 	{
@@ -1880,7 +1882,15 @@ int main (int argc, char** argv)
 			double t0 = now_ms ();
 			u64 ivBefore = intervalsRead;
 			if (reportGpu) sync_all_devices ();
-			(*stopOp->funcApply) (stopOp, "*", maxLength, NULL);
+			int ran = 1;
+			if (fuseChains && (stopOp->funcApply == op_percentile_apply))
+				{
+				/* `percentile P = binarize --threshold=percentileP`: the binarize in the percentile's own read of the signal */
+				ran = percentile_with_binarize (stopOp, stopOp->next);
+				if ((ran == 2) && trackOperations)
+					{ for (int i=0 ; chromsSorted[i]!=NULL ; i++) fprintf (stderr, "%s(%s)\n", stopOp->next->name, chromsSorted[i]->chrom); }
+				}
+			else (*stopOp->funcApply) (stopOp, "*", maxLength, NULL);
 			if (reportGpu)
 				{
 				u64 total = 0;
@@ -1893,9 +1903,10 @@ int main (int argc, char** argv)
 					snprintf (label, sizeof(label), "%s (file: parse, stage, apply)", stopOp->name);
 					wall_phase (stopOp, label, now_ms () - t0, intervalsRead - ivBefore, "intervals", 0);
 					}
+				else if (ran == 2) wall_phase (stopOp, "percentile=binarize", now_ms () - t0, total, "bases", 24);
 				else wall_phase (stopOp, stopOp->name, now_ms () - t0, total, "bases", (stopOp->funcApply == op_percentile_apply)? 8 : 16);
 				}
-			firstOp = stopOp->next;
+			firstOp = (ran == 2)? stopOp->next->next : stopOp->next;
 			}
 		}
 

@@ -25,6 +25,7 @@ void sync_all_devices    (void);
  * 16-byte aligned vector v lies in (an elementwise operator may as well run over all of it) */
 typedef struct sigpart { spec* s;  valtype* v;  u32 n;  u32 first;  valtype* base;  u32 baseLen; } sigpart;
 int  signal_parts (sigpart** parts);
+int  signal_in_whole_chromosomes (void);       /* false under --sharding=bases (the signal may live in stretches) */
 void to_whole (void);                          /* make the whole chromosomes current (file-driven operators, report) */
 /* how whole-genome operators (percentile, invert) combine what the devices of this process found: the
  * reduction hook for gdsp_percentiles (NULL: the library adds its devices' counts on the host) */
@@ -65,6 +66,10 @@ int   op_reach            (dspop* op, u32* left, u32* right);
 void  op_local_describe   (dspop* op, u32* neighborhood, int* wantMax, valtype* fill);
 void  op_morph_describe   (dspop* op, u32* left, u32* right, valtype* T, valtype* one, valtype* zero);
 void  op_binarize_describe (dspop* op, valtype* T, int* tiesAbove, valtype* one, valtype* zero);
+const char* op_binarize_pending (dspop* op, int* tiesAbove, valtype* one, valtype* zero);
+/* `= percentile P = binarize --threshold=percentileP` in one read of the signal: runs the percentile operator and, when the
+ * operator after it is that binarize, the binarize with it; returns how many operators ran (1 or 2) */
+int   percentile_with_binarize (dspop* percentile, dspop* next);
 
 /* argument helpers used by every operator's parse function */
 #define OP_SHORT(fn, text)                                                            \

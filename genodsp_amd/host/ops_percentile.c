@@ -158,6 +158,8 @@ void op_percentile_free (dspop* _op)
 	free (op);
 	}
 
+static void percentile_name (char* varName, u32 percentile);
+
 static void percentile_name (char* varName, u32 percentile)     /* percentile.c:756-780 */
 	{
 	if (percentile % percentileStepUnits == 0)
@@ -169,7 +171,47 @@ static void percentile_name (char* varName, u32 percentile)     /* percentile.c:
 	sprintf (varName, "percentile%f", pPct);
 	}
 
+static int percentile_run (dspop* _op, dspop* binarize);
+
 void op_percentile_apply (dspop* _op, arg_dont_complain(char* vName), arg_dont_complain(u32 vLen), arg_dont_complain(valtype* v))
+	{ percentile_run (_op, NULL); }
+
+dspprototypes(op_binarize)
+
+/* The percentile, and -- when `next` is a binarize whose threshold is one of this operator's percentiles, the signal lives
+ * in whole chromosomes and nothing asks for the reference's detour through a file -- that binarize in the same read of
+ * the signal (gdsp_percentiles_binarize: the counting pass writes one / zero wherever its bracket already decides).
+ * The outputs land in the partner vectors, which then become the signal.  Same values, same messages in the same
+ * order, same signal as the two operators one after the other. */
+static int percentile_fusable (dspop* _op, dspop* next)
+	{
+	dspop_percentile* op = (dspop_percentile*) _op;
+	char varName[100];
+	int  ties;  valtype one, zero;
+	if ((next == NULL) || (next->funcApply != op_binarize_apply)) return false;
+	const char* want = op_binarize_pending (next, &ties, &one, &zero);
+	if ((want == NULL) || (op->preserveFilename != NULL) || !signal_in_whole_chromosomes ()) return false;
+	if ((op->mapFilename == NULL) && ((op->percentileLo == 0) || (op->percentileLo == 100*percentileStepUnits))
+	 && ((op->percentileHi == 0) || (op->percentileHi == 100*percentileStepUnits))) return false;        /* answered from the extremes alone */
+	for (u32 pt=op->percentileLo ; pt<=op->percentileHi ; pt+=op->percentileStep)
+		{
+		percentile_name (varName, pt);
+		if (strcmp (varName, want) == 0) return true;
+		if (op->percentileStep == 0) break;
+		}
+	return false;
+	}
+
+int percentile_with_binarize (dspop* _op, dspop* next)
+	{
+	if (percentile_fusable (_op, next)) return percentile_run (_op, next)? 2 : 1;
+	percentile_run (_op, NULL);
+	return 1;
+	}
+
+/* returns true when `binarize` was run with it (false: the percentile alone has run -- or, asked to fuse what cannot be
+ * fused, nothing has) */
+static int percentile_run (dspop* _op, dspop* binarize)
 	{
 	dspop_percentile* op = (dspop_percentile*) _op;
 	char  varName[100];
@@ -225,8 +267,29 @@ void op_percentile_apply (dspop* _op, arg_dont_complain(char* vName), arg_dont_c
 	u64 numValues = 0;
 	void* reduceCtx = NULL;
 	gdsp_reduce_fn reduce = reduce_over_devices (&reduceCtx);
-	check_gdsp (gdsp_percentiles (src, nsrc, op->windowSize, op->minAllowed, op->maxAllowed, pts, npct,
-	                              selectStrategy, 0, reduce, reduceCtx, vals, &numValues), "percentile");
+	int fused = false;
+	if (binarize != NULL)
+		{
+		/* which of this operator's percentiles is the binarize's threshold? */
+		gdsp_percentile_binarize fuse;
+		const char* want = op_binarize_pending (binarize, &fuse.tiesAbove, &fuse.one, &fuse.zero);
+		fuse.which = -1;
+		for (int ip=0 ; (want != NULL) && (ip<npct) ; ip++)
+			{ percentile_name (varName, pts[ip]);  if (strcmp (varName, want) == 0) fuse.which = ip; }
+		if (fuse.which < 0) { fprintf (stderr, "[%s] internal error: nothing to fuse\n", _op->name);  exit (EXIT_FAILURE); }   /* (percentile_fusable said yes) */
+		double** outs = (double**) calloc (nsrc? nsrc : 1, sizeof(double*));
+		if (outs == NULL) { fprintf (stderr, "[%s] out of memory\n", _op->name);  exit (EXIT_FAILURE); }
+		for (int i=0 ; i<nsrc ; i++) outs[i] = partner_of (parts[i].s);
+		fuse.d_out = outs;
+		int onePass = 0;
+		check_gdsp (gdsp_percentiles_binarize (src, nsrc, op->windowSize, op->minAllowed, op->maxAllowed, pts, npct,
+		                                       selectStrategy, 0, reduce, reduceCtx, vals, &numValues, &fuse, &onePass), "percentile");
+		free (outs);
+		fused = (numValues != 0);
+		}
+	else
+		check_gdsp (gdsp_percentiles (src, nsrc, op->windowSize, op->minAllowed, op->maxAllowed, pts, npct,
+		                              selectStrategy, 0, reduce, reduceCtx, vals, &numValues), "percentile");
 	if (nsrc > 0) select_device_of (parts[0].s);
 	free (src);
 	if (numValues == 0)
@@ -234,7 +297,7 @@ void op_percentile_apply (dspop* _op, arg_dont_complain(char* vName), arg_dont_c
 		fprintf (stderr, "[%s] percentile can't be computed;  no input values meet the criteria\n", _op->name);
 		if (mapF != NULL) fclose (mapF);
 		free (pts);  free (vals);
-		return;
+		return false;                                    /* (a binarize that was to run with it runs on its own, and says what the reference says) */
 		}
 
 	for (int ip=0 ; ip<npct ; ip++)
@@ -261,4 +324,12 @@ void op_percentile_apply (dspop* _op, arg_dont_complain(char* vName), arg_dont_c
 		FILE* f = fopen (op->preserveFilename, "wb");
 		if (f != NULL) fclose (f);
 		}
+	if (fused)
+		{
+		/* the binarize's own words when it picks its threshold up (logical.c:234-243), then its output becomes the signal */
+		valtype T, one, zero;  int ties;
+		op_binarize_describe (binarize, &T, &ties, &one, &zero);
+		for (spec** c=chromsSorted ; *c!=NULL ; c++) flip_spec (*c);
+		}
+	return fused;
 	}

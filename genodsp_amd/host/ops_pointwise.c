@@ -61,6 +61,14 @@ void op_binarize_free (dspop* _op)
 	free (op);
 	}
 
+/* what binarize will do once its threshold variable exists (the variable's name: NULL when the threshold is a number) */
+const char* op_binarize_pending (dspop* _op, int* tiesAbove, valtype* one, valtype* zero)
+	{
+	dspop_binarize* op = (dspop_binarize*) _op;
+	*tiesAbove = op->tiesAbove;  *one = op->oneVal;  *zero = op->zeroVal;
+	return op->thresholdVarName;
+	}
+
 void op_binarize_describe (dspop* _op, valtype* T, int* tiesAbove, valtype* one, valtype* zero)
 	{
 	dspop_binarize* op = (dspop_binarize*) _op;

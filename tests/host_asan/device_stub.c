@@ -213,6 +213,22 @@ int gdsp_percentiles (const source* src, int nsrc, uint32_t window, double lo, d
 	free (vecs);  free (lens);
 	return OK;
 	}
+typedef struct fusebin { int which;  int tiesAbove;  double one, zero;  double* const* out; } fusebin;
+int gdsp_percentiles_binarize (const source* src, int nsrc, uint32_t window, double lo, double hi, const uint32_t* pts, int npts,
+                               int strategy, uint32_t sampleTarget, void* reduce, void* ctx, double* values, uint64_t* count,
+                               const fusebin* fuse, int* onePass)
+	{
+	gdsp_percentiles (src, nsrc, window, lo, hi, pts, npts, strategy, sampleTarget, reduce, ctx, values, count);
+	*onePass = 0;
+	if (*count == 0) return OK;
+	for (int i=0 ; i<nsrc ; i++)
+		{
+		if (src[i].n == 0) continue;
+		memcpy (fuse->out[i], src[i].v, (size_t) src[i].n * sizeof(double));
+		orc_binarize (fuse->out[i], src[i].n, values[fuse->which], fuse->tiesAbove, fuse->one, fuse->zero);
+		}
+	return OK;
+	}
 int gdsp_percentiles_use_comm (void* c) { (void) c;  return OK; }
 
 /* the interval-file operators that walk sorted intervals: the CSR lists them tile by tile in file order */

@@ -363,3 +363,34 @@ def test_many_small_interval_batches_give_the_same_output(case, tmp_path, monkey
     rc, out, err = run(case["args"], case["stdin"], case["chroms_text"], tmp_path, case.get("files"))
     assert rc == 0, err
     assert hashlib.sha256(out.encode()).hexdigest() == case["sha256"], case["args"]
+
+
+def test_percentile_feeding_binarize_runs_in_one_read_of_the_signal(tmp_path, monkeypatch):
+    """`= percentile P = binarize --threshold=percentileP` without --preserve: the driver hands both operators to
+    gdsp_percentiles_binarize (the counting pass writes one / zero wherever its bracket decides).  Same stdout, same
+    stderr (the percentile line, then binarize's note about its threshold) as the two operators one after the other
+    (--nofuse), with read depth and with real values, several percentiles, ties above, under --gpus=2 shards too."""
+    import numpy as np
+    monkeypatch.setenv("GDSP_OVERSUBSCRIBE_GPUS", "1")
+    rng = np.random.default_rng(31)
+    n = 2_600_000                                        # above the 2^20 values where the bracketing route starts
+    for valued in (False, True):
+        lines = []
+        for _ in range(60000):
+            a = int(rng.integers(0, n - 400))
+            z = a + int(rng.integers(30, 400))
+            lines.append("chrP\t%d\t%d\t%.3f" % (a, z, rng.random() * 3 + 0.1) if valued else "chrP\t%d\t%d" % (a, z))
+        for i in range(300):
+            lines.append("chrQ\t%d\t%d%s" % (40 * i, 40 * i + 55, "\t2.5" if valued else ""))
+        iv = "\n".join(lines) + "\n"
+        base = ([] if valued else ["--novalue"]) + ["--precision=3"]
+        for ops in (["=", "percentile", "90", "--min=1/inf", "=", "binarize", "--threshold=percentile90"],
+                    ["=", "percentile", "50..99by7", "=", "binarize", "--threshold=percentile92", "--ties:above", "--one=5", "--zero=-1", "=", "addconst", "1"],
+                    ["=", "smooth", "W=11", "=", "percentile", "99.5", "--min=1/inf", "--quiet", "=", "binarize", "T=percentile99.5", "=", "dilate", "30"]):
+            got = {}
+            for extra in ([], ["--nofuse"], ["--gpus=2"]):
+                rc, out, err = run(base + extra + ops, iv, "chrP %d\nchrQ 13000\n" % n, tmp_path)
+                assert rc == 0, err
+                got[tuple(extra)] = (out, err)
+            assert got[()] == got[("--nofuse",)] == got[("--gpus=2",)], ops
+            assert len(got[()][0].splitlines()) > 100 and "[binarize] using percentile" in got[()][1]
