@@ -44,8 +44,10 @@ def test_fused_equals_percentile_then_binarize(n, gd):
                 for p, o in zip(parts, outs):
                     want = cpu.binarize(p, T, kw.get("ties_above", False), kw.get("one", 1.0), kw.get("zero", 0.0))
                     assert bits_equal(o.numpy(), want), (name, pts, kw, one_pass)
-                if n >= (1 << 21) and name == "real" and "window" not in kw:
+                if n >= (1 << 21) and name == "real" and "window" not in kw and pts != [100]:
                     assert one_pass, (pts, kw)                     # the counting pass settled it (the route under test)
+                # (the 0.1th percentile of this signal is the zero a third of its bases hold: more ties inside the bracket
+                #  than a strip takes, so those sources are binarized by a pass of their own -- same output)
                 if "window" in kw or n < 10000:
                     assert not one_pass
 
