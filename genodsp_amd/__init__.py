@@ -465,6 +465,10 @@ DEVICE_REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_
 SELECT_AUTO, SELECT_RADIX, SELECT_BRACKET = 0, 1, 2
 
 
+import threading as _threading
+_PERCENTILE_HOOK = _threading.RLock()
+
+
 def percentile(vecs, p_thousandths, window=1, lo=-DBL_MAX, hi=DBL_MAX, allreduce=None, stream=None,
                strategy=SELECT_AUTO, sample_target=0, device_allreduce=None):
     """Exact percentiles of the sampled genome (percentile.c:392-751), non-destructive: gdsp_percentiles.
@@ -502,18 +506,21 @@ def percentile(vecs, p_thousandths, window=1, lo=-DBL_MAX, hi=DBL_MAX, allreduce
     assert allreduce is None or device_allreduce is None
     cb = REDUCE_FN(reduce) if allreduce is not None else C.cast(None, REDUCE_FN)
     dcb = DEVICE_REDUCE_FN(device_reduce) if device_allreduce is not None else None
-    try:
-        if dcb is not None:
-            call("gdsp_percentiles_use_device_reduce", dcb, None)
-        call("gdsp_percentiles", src, len(vecs), int(window), float(lo), float(hi), pts, len(p_thousandths),
-             int(strategy), int(sample_target), cb, None, vals, C.byref(count))
-    except GdspError:
-        if failure:
-            raise failure[0]
-        raise
-    finally:
-        if dcb is not None:
-            call("gdsp_percentiles_use_device_reduce", None, None)
+    # the device hook is state of the library (one per process): installed, used and cleared under one lock, so that
+    # two threads calling percentile() cannot swap or clear each other's hook in mid-call
+    with _PERCENTILE_HOOK:
+        try:
+            if dcb is not None:
+                call("gdsp_percentiles_use_device_reduce", dcb, None)
+            call("gdsp_percentiles", src, len(vecs), int(window), float(lo), float(hi), pts, len(p_thousandths),
+                 int(strategy), int(sample_target), cb, None, vals, C.byref(count))
+        except GdspError:
+            if failure:
+                raise failure[0]
+            raise
+        finally:
+            if dcb is not None:
+                call("gdsp_percentiles_use_device_reduce", None, None)
     if count.value == 0:
         return 0, []
     return int(count.value), [float(x) for x in vals]
@@ -585,6 +592,7 @@ def percentile_binarize(vecs, p_thousandths, which=0, outs=None, ties_above=Fals
             return 1
 
     dcb = DEVICE_REDUCE_FN(device_reduce) if device_allreduce is not None else None
+    _PERCENTILE_HOOK.acquire()
     try:
         if dcb is not None:
             call("gdsp_percentiles_use_device_reduce", dcb, None)
@@ -597,6 +605,7 @@ def percentile_binarize(vecs, p_thousandths, which=0, outs=None, ties_above=Fals
     finally:
         if dcb is not None:
             call("gdsp_percentiles_use_device_reduce", None, None)
+        _PERCENTILE_HOOK.release()
     if count.value == 0:
         return 0, [], outs, False
     return int(count.value), [float(x) for x in vals], outs, bool(one_pass.value)

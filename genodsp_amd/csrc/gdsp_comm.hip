@@ -118,7 +118,12 @@ int gdsp_comm_create (gdsp_comm** out, const int* devices, int ndevices)
 	GDSP_HIP_TRY (hipGetDevice (&home));
 	gdsp_comm* c = (gdsp_comm*) calloc (1, sizeof(gdsp_comm));
 	if (c != NULL) { c->devices = (int*) calloc (ndevices, sizeof(int));  c->comms = (ncclComm_t*) calloc (ndevices, sizeof(ncclComm_t)); }
-	if ((c == NULL) || (c->devices == NULL) || (c->comms == NULL)) { gdsp_set_error ("out of host memory");  return GDSP_ENOMEM; }
+	if ((c == NULL) || (c->devices == NULL) || (c->comms == NULL))
+		{
+		if (c != NULL) { free (c->devices);  free (c->comms);  free (c); }
+		gdsp_set_error ("out of host memory");
+		return GDSP_ENOMEM;
+		}
 	c->ndev = ndevices;
 	memcpy (c->devices, devices, ndevices * sizeof(int));
 	// With NCCL_DEBUG set (VERSION on this pool's machines) RCCL prints a banner with printf while it

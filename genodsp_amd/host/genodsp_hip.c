@@ -684,17 +684,20 @@ static void allocate_vectors (void)
 
 /* reach of the maximal run [firstOp, stopOp) when every operator in it can work on a stretch: the reaches add up
  * along the chain, plus one base per operator (dilate treats position 0 of its vector specially, morphology.c:925) */
-static int run_reach (dspop* firstOp, dspop* stopOp, u32* left, u32* right)
+static int run_reach (dspop* firstOp, dspop* stopOp, u32* left, u32* right, int* pointwise)
 	{
 	u64 L = 0, R = 0;
+	int flat = true;                                  /* every operator of the run looks at its own base only */
 	for (dspop* op=firstOp ; op!=stopOp ; op=op->next)
 		{
 		u32 l, r;
 		if (!op_reach (op, &l, &r)) return false;
+		if ((l | r) != 0) flat = false;
 		L += (u64) l + 1;  R += (u64) r + 1;
 		}
 	if ((L > HALO_LIMIT) || (R > HALO_LIMIT)) return false;
 	*left = (u32) L;  *right = (u32) R;
+	if (pointwise != NULL) *pointwise = flat;
 	return true;
 	}
 
@@ -709,7 +712,7 @@ static void plan_pieces (void)
 		dspop* stopOp;
 		u32 l, r;
 		for (stopOp=firstOp ; stopOp!=NULL ; stopOp=stopOp->next) { if (stopOp->atRandom) break; }
-		if ((stopOp != firstOp) && run_reach (firstOp, stopOp, &l, &r))
+		if ((stopOp != firstOp) && run_reach (firstOp, stopOp, &l, &r, NULL))
 			{ if (l > haloCap) haloCap = l;  if (r > haloCap) haloCap = r; }
 		firstOp = (stopOp == NULL)? NULL : stopOp->next;
 		}
@@ -1803,9 +1806,10 @@ int main (int argc, char** argv)
 		if (stopOp != firstOp)
 			{
 			u32 reachL = 0, reachR = 0;
-			int sharded = shardBases && run_reach (firstOp, stopOp, &reachL, &reachR);
+			int pointwise = false;                    /* a run of per-base operators neither needs fresh halos nor spoils them */
+			int sharded = shardBases && run_reach (firstOp, stopOp, &reachL, &reachR, &pointwise);
 			int nunits = 0;
-			if (sharded) { to_pieces ();  if ((reachL | reachR) != 0) refresh_halos ();  nunits = numPieces; }
+			if (sharded) { to_pieces ();  if (!pointwise) refresh_halos ();  nunits = numPieces; }
 			else         { to_whole ();  while (chromsSorted[nunits] != NULL) nunits++; }
 			spec** units = (spec**) malloc ((nunits + 1) * sizeof(spec*));
 			if (units == NULL) { fprintf (stderr, "out of memory\n");  exit (EXIT_FAILURE); }
@@ -1870,7 +1874,7 @@ int main (int argc, char** argv)
 				op = runEnd;
 				}
 			free (units);
-			if (sharded && ((reachL | reachR) != 0)) halosFresh = false;     /* pointwise runs leave the halos right */
+			if (sharded && !pointwise) halosFresh = false;     /* (per-base operators transform halo and owner alike) */
 			}
 		if (stopOp == NULL) firstOp = NULL;
 		else
