@@ -734,13 +734,13 @@ static void plan_pieces (void)
 			else if (cut <= at + a)    { d++;  continue; }             /* the share is full */
 			else
 				{
-				b = (u32) (cut - at);
+				b = (u32) (cut - at) & ~1u;                            /* cuts at even bases: what a stretch answers for starts 16-byte aligned (the dense kernels) */
 				if (b - a < stub)         { d++;  continue; }          /* only a stub left of this share: next device */
 				if (s->length - b < stub) b = s->length;               /* only a stub left of the chromosome: take it too */
 				}
 			piece* p = &pieces[numPieces++];
 			p->whole = s;  p->ownStart = a;  p->ownEnd = b;
-			p->extStart = (a > haloCap)? a - haloCap : 0;
+			p->extStart = ((a > haloCap)? a - haloCap : 0) & ~1u;
 			u32 extEnd  = (s->length - b > haloCap)? b + haloCap : s->length;
 			p->x.pub.chrom  = s->chrom;
 			p->x.pub.start  = s->start + p->extStart;
