@@ -353,6 +353,103 @@ void pc_binarize_kernel (const double* __restrict__ v, double* __restrict__ out,
 		}
 	}
 
+// ---- the digits after the first, chained on the device.  A radix select looks at one digit per pass and needs the
+// bucket of the previous pass before the next can start; with the histogram read back and the bucket picked on the
+// host that is a round trip per digit and rank (fourteen of them were two thirds of a 249 Mbp call, more on a box whose
+// host is slow).  Here the state of every rank being looked up -- prefix so far, rank within it, the answer -- lives
+// in HBM: the histogram kernel takes its prefix from there, a one-workgroup kernel picks the bucket from the (all-
+// reduced) histogram, advances the state and clears the histogram for the next pass.  The passes are queued back to
+// back; the host reads the answers once.
+#define PC_CHAIN_MAX (2 * 16)
+struct PcChain { uint64_t prefix[PC_CHAIN_MAX], k[PC_CHAIN_MAX], key[PC_CHAIN_MAX];  uint32_t done[PC_CHAIN_MAX]; };
+
+__global__ __launch_bounds__(PC_THREADS)
+void pc_hist_chain_kernel (const uint64_t* __restrict__ keys, unsigned long long count, uint64_t keyLo, uint64_t keyHi,
+                           int bounded, int shift, int bits, const PcChain* __restrict__ chain, int r,
+                           unsigned long long* __restrict__ hist)
+	{
+	__shared__ uint32_t lb[1 << 13];
+	if (chain->done[r]) return;                                    // (uniform: one word of HBM)
+	const uint64_t prefix = chain->prefix[r];
+	const int      nbins = 1 << bits;
+	const uint64_t mask  = (uint64_t) nbins - 1;
+	const int      above = shift + bits;
+	for (int b=threadIdx.x ; b<nbins ; b+=PC_THREADS) lb[b] = 0;
+	__syncthreads ();
+	uint64_t kmin = ~0ULL, kmax = 0;
+	const size_t stride = (size_t) gridDim.x * PC_THREADS;
+	for (size_t i = (size_t) blockIdx.x * PC_THREADS + threadIdx.x ; i < count ; i += stride)
+		{
+		const uint64_t key = keys[i];
+		if (key == PC_NO_KEY) continue;
+		if (bounded && !((key >= keyLo) && (key <= keyHi))) continue;
+		if ((above < 64) && ((key >> above) != (prefix >> above))) continue;
+		atomicAdd (&lb[(uint32_t) ((key >> shift) & mask)], 1u);
+		if (key < kmin) kmin = key;
+		if (key > kmax) kmax = key;
+		}
+	__syncthreads ();
+	for (int b=threadIdx.x ; b<nbins ; b+=PC_THREADS)
+		{ uint32_t c = lb[b];  if (c) atomicAdd (&hist[b], (unsigned long long) c); }
+	for (int off=32 ; off>0 ; off>>=1)
+		{
+		uint64_t a = __shfl_down ((unsigned long long) kmin, off, 64);
+		uint64_t b = __shfl_down ((unsigned long long) kmax, off, 64);
+		if (a < kmin) kmin = a;
+		if (b > kmax) kmax = b;
+		}
+	if (((threadIdx.x & 63) == 0) && (kmin <= kmax))
+		{
+		atomicMin (&hist[nbins],   (unsigned long long) kmin);
+		atomicMax (&hist[nbins+1], (unsigned long long) kmax);
+		}
+	}
+
+// one workgroup: the bucket of rank chain->k[r] in the histogram (gdsp_select_pick), the state advanced, the histogram
+// cleared (counts 0, smallest key all ones, largest 0: what gdsp_select_hist_init leaves)
+#define PC_PICK_THREADS 1024
+__global__ __launch_bounds__(PC_PICK_THREADS)
+void pc_pick_kernel (unsigned long long* __restrict__ hist, int shift, int bits, int last, PcChain* __restrict__ chain, int r)
+	{
+	__shared__ unsigned long long wsum[PC_PICK_THREADS/64];
+	const int p = threadIdx.x, lane = p & 63, wave = p >> 6;
+	const int nbins = 1 << bits, per = (nbins + PC_PICK_THREADS - 1) / PC_PICK_THREADS;
+	if (!chain->done[r])
+		{
+		const unsigned long long kmin = hist[nbins], kmax = hist[nbins+1], k = chain->k[r];
+		unsigned long long mine = 0;
+		for (int j=0 ; j<per ; j++) { const int b = p * per + j;  if (b < nbins) mine += hist[b]; }
+		unsigned long long incl = mine;
+		for (int d=1 ; d<64 ; d*=2) { const unsigned long long up = __shfl_up (incl, d, 64);  if (lane >= d) incl += up; }
+		if (lane == 63) wsum[wave] = incl;
+		__syncthreads ();
+		unsigned long long before = 0;
+		for (int w=0 ; w<wave ; w++) before += wsum[w];
+		const unsigned long long lo = before + incl - mine, hi = before + incl;      // this thread's bins hold ranks [lo, hi)
+		if (kmin == kmax)                                          // one distinct value left (or nothing: then the key is all ones)
+			{ if (p == 0) { chain->key[r] = kmin;  chain->done[r] = 1; } }
+		else if ((k >= lo) && (k < hi))
+			{
+			unsigned long long seen = lo;
+			for (int j=0 ; j<per ; j++)
+				{
+				const int b = p * per + j;
+				if (b >= nbins) break;
+				if (k < seen + hist[b])
+					{
+					const uint64_t prefix = chain->prefix[r] | (((uint64_t) b) << shift);
+					chain->prefix[r] = prefix;  chain->k[r] = k - seen;
+					if (last) { chain->key[r] = prefix;  chain->done[r] = 1; }
+					break;
+					}
+				seen += hist[b];
+				}
+			}
+		}
+	__syncthreads ();
+	for (int b=p ; b<nbins+2 ; b+=PC_PICK_THREADS) hist[b] = (b == nbins)? ~0ULL : 0ULL;
+	}
+
 // ------------------------------------------------------------- host side ----
 static const int pcShift[] = { 52, 39, 26, 13, 0 };
 static const int pcBits[]  = { 12, 13, 13, 13, 13 };
@@ -369,6 +466,7 @@ struct PcDevice                                               // scratch of one 
 	uint64_t* cand;    size_t candCap;
 	uint32_t* pos;     size_t posCap;     // fused binarize: positions the bracket left open, every source's strip one after the other
 	unsigned long long* posCount;         // one counter per source (PC_MAX_FUSED_SOURCES)
+	PcChain*  chain;                      // ranks being looked up by the chained passes
 	};
 #define PC_MAX_FUSED_SOURCES 256
 #define PC_TMP_WORDS 64
@@ -394,6 +492,7 @@ static int pc_device (int device, size_t sampleCap, size_t candCap, PcDevice** o
 		GDSP_HIP_TRY (hipMalloc ((void**) &d->ctr,  PC_CTR_ALL * sizeof(uint64_t)));
 		GDSP_HIP_TRY (hipMalloc ((void**) &d->tmp,  PC_TMP_WORDS * sizeof(uint64_t)));
 		GDSP_HIP_TRY (hipMalloc ((void**) &d->posCount, PC_MAX_FUSED_SOURCES * sizeof(unsigned long long)));
+		GDSP_HIP_TRY (hipMalloc ((void**) &d->chain, sizeof(PcChain)));
 		}
 	if (d->sampleCap < sampleCap)
 		{
@@ -544,9 +643,92 @@ static int pc_pass (PcJob& J, const PcScope& S, int digit, uint64_t prefix, uint
 	}
 
 // keys of the given 0-based ranks within the scope; `first` is the scope's first-digit histogram
+// the same with the digits after the first chained on the device (see pc_hist_chain_kernel): for key lists, when no host
+// hook has to see the histograms -- one process, its devices' histograms all-reduced in HBM or a single device
+static int pc_select_chained (PcJob& J, const PcScope& S, const std::vector<uint64_t>& first, const std::vector<uint64_t>& ranks,
+                              std::vector<uint64_t>& keys)
+	{
+	const size_t R = ranks.size ();
+	keys.assign (R, 0);
+	PcChain init;
+	memset (&init, 0, sizeof(init));
+	bool anyOpen = false;
+	for (size_t r=0 ; r<R ; r++)
+		{
+		const int nbins0 = 1 << pcBits[0];
+		if (first[nbins0] == first[nbins0+1]) { init.key[r] = first[nbins0];  init.done[r] = 1;  continue; }
+		uint32_t bucket;  uint64_t within;
+		PC_TRY (gdsp_select_pick (first.data (), pcBits[0], ranks[r], &bucket, &within));
+		init.prefix[r] = ((uint64_t) bucket) << pcShift[0];  init.k[r] = within;
+		anyOpen = true;
+		}
+	if (anyOpen)
+		{
+		for (size_t d=0 ; d<J.devices.size () ; d++)
+			{
+			GDSP_HIP_TRY (hipSetDevice (J.devices[d]));
+			GDSP_HIP_TRY (hipMemcpyAsync (J.scratch[d]->chain, &init, sizeof(init), hipMemcpyHostToDevice, gdsp_stream (J.stream[d])));
+			PC_TRY (gdsp_select_hist_init (J.scratch[d]->hist, 13, J.stream[d]));
+			}
+		for (size_t r=0 ; r<R ; r++)
+			{
+			if (init.done[r]) continue;
+			for (int digit=1 ; digit<PC_DIGITS ; digit++)
+				{
+				const int bits = pcBits[digit], nbins = 1 << bits;
+				for (size_t d=0 ; d<J.devices.size () ; d++)
+					{
+					GDSP_HIP_TRY (hipSetDevice (J.devices[d]));
+					const uint64_t* list  = (S.over == PC_OVER_SAMPLE)? J.scratch[d]->sample : J.scratch[d]->cand;
+					const uint64_t  count = (S.over == PC_OVER_SAMPLE)? J.sampleCount[d] : J.candCount[d];
+					if (count == 0) continue;
+					size_t   want   = (count + PC_THREADS*4 - 1) / (PC_THREADS*4);
+					uint32_t blocks = (uint32_t) (want > 1024? 1024 : want);
+					hipLaunchKernelGGL (pc_hist_chain_kernel, dim3(blocks), dim3(PC_THREADS), 0, gdsp_stream (J.stream[d]),
+					                    list, (unsigned long long) count, S.keyLo, S.keyHi, S.bounded, pcShift[digit], bits,
+					                    J.scratch[d]->chain, (int) r, (unsigned long long*) J.scratch[d]->hist);
+					GDSP_LAUNCH_CHECK ();
+					}
+				if (J.comm != NULL)
+					{
+					std::vector<uint64_t*> bins (J.devices.size ()), lo (J.devices.size ()), hi (J.devices.size ());
+					for (size_t d=0 ; d<J.devices.size () ; d++)
+						{ bins[d] = J.scratch[d]->hist;  lo[d] = bins[d] + nbins;  hi[d] = bins[d] + nbins + 1; }
+					PC_TRY (pc_device_allreduce (J, bins, nbins, 0));
+					PC_TRY (pc_device_allreduce (J, lo, 1, 1));
+					PC_TRY (pc_device_allreduce (J, hi, 1, 2));
+					}
+				for (size_t d=0 ; d<J.devices.size () ; d++)
+					{
+					GDSP_HIP_TRY (hipSetDevice (J.devices[d]));
+					hipLaunchKernelGGL (pc_pick_kernel, dim3(1), dim3(PC_PICK_THREADS), 0, gdsp_stream (J.stream[d]),
+					                    (unsigned long long*) J.scratch[d]->hist, pcShift[digit], bits, (int) (digit == PC_DIGITS-1),
+					                    J.scratch[d]->chain, (int) r);
+					GDSP_LAUNCH_CHECK ();
+					}
+				}
+			}
+		PcChain got;
+		GDSP_HIP_TRY (hipSetDevice (J.devices[0]));
+		GDSP_HIP_TRY (hipMemcpyAsync (&got, J.scratch[0]->chain, sizeof(got), hipMemcpyDeviceToHost, gdsp_stream (J.stream[0])));
+		for (size_t d=0 ; d<J.devices.size () ; d++)
+			{ GDSP_HIP_TRY (hipSetDevice (J.devices[d]));  GDSP_HIP_TRY (hipStreamSynchronize (gdsp_stream (J.stream[d]))); }
+		for (size_t r=0 ; r<R ; r++) { if (!init.done[r]) { init.key[r] = got.key[r];  init.done[r] = got.done[r]; } }
+		}
+	for (size_t r=0 ; r<R ; r++)
+		{
+		if (!init.done[r]) { gdsp_set_error ("gdsp_percentiles: a chained select did not finish");  return GDSP_EHIP; }
+		keys[r] = init.key[r];
+		}
+	return GDSP_OK;
+	}
+
 static int pc_select (PcJob& J, const PcScope& S, const std::vector<uint64_t>& first, const std::vector<uint64_t>& ranks,
                       std::vector<uint64_t>& keys)
 	{
+	const bool chainable = (S.over != PC_OVER_VECTORS) && (ranks.size () <= PC_CHAIN_MAX) && (J.reduce == NULL) && (J.dreduce == NULL)
+	                    && ((J.devices.size () == 1) || (J.comm != NULL)) && (getenv ("GDSP_PERCENTILE_CHAIN_OFF") == NULL);
+	if (chainable) return pc_select_chained (J, S, first, ranks, keys);
 	std::vector<uint64_t> h (PC_HIST_WORDS);
 	keys.assign (ranks.size (), 0);
 	for (size_t r=0 ; r<ranks.size () ; r++)
