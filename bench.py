@@ -430,7 +430,9 @@ def other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_base
                 cnt, vals, _outs, one_pass = gd.percentile_binarize([vin[i] for i in mine], [99000], which=0, outs=[tmp[i] for i in mine],
                                                                     device_allreduce=device_allreduce, stream=S)
                 extra["percentile99"], extra["sampled"], extra["binarize_in_one_pass"] = vals[0], cnt, bool(one_pass)
-                extra["percentile_stats"] = gd.percentile_stats()
+                st = gd.percentile_stats()
+                extra["percentile_route"] = {gd.SELECT_RADIX: "radix", gd.SELECT_BRACKET: "bracket"}.get(st["route"])
+                extra["percentile_stats"] = st
                 return
             cnt, vals = gd.percentile([vin[i] for i in mine], [99000], device_allreduce=device_allreduce, stream=S)
             extra["percentile99"], extra["sampled"] = vals[0], cnt
