@@ -12,7 +12,7 @@ import sys
 
 SKIP = ("synth_coverage_kernel", "__amd_rocclr", "fill", "copyBuffer")
 # bytes the operator has to move per base: in + out, or in only for the passes that only read
-ALGORITHMIC = {"peaks_probe_kernel": None, "peaks_exact_kernel": None, "peaks_init_kernel": None, "fir_fixed_extrema_gated_kernel": None,
+ALGORITHMIC = {"pc_fixup_kernel": None, "pc_hist_chain_kernel": None, "pc_pick_kernel": None, "peaks_probe_kernel": None, "peaks_exact_kernel": None, "peaks_init_kernel": None, "fir_fixed_extrema_gated_kernel": None,
                "pc_sample_kernel": 8, "pc_partition_kernel": 8, "cumsum_totals_kernel": 8, "report_count_kernel": 8,
                "report_write_kernel": 8, "clump_chunk_stats_kernel": 8, "clump_write_kernel": 8,
                # launches over a few words per chunk, or whose traffic is not a per-base figure: bytes only

@@ -3,7 +3,7 @@
 usage: python3 tools/prof_op.py <op> [launches] [n]
 ops: clump cumsum sum1000 sum100 slidingsum close open dilate erode localmax bestmax binarize smooth_exact smooth_fma
      smooth_hann smooth_hann1001 smooth_hann2001 peaks_exact peaks_fma morph_fused percentile report select
-     smooth_hann_batch smooth_exact_batch morph_fused_batch binarize_batch peaks_exact_batch   (three vectors of n/2, n/3, n/6
+     smooth_hann_batch smooth_exact_batch smooth_fma_batch morph_fused_batch binarize_batch peaks_exact_batch percentile_binarize   (three vectors of n/2, n/3, n/6
      bases in one launch: the gdsp_*_batch forms, what genodsp_hip and bench.py launch by default)"""
 import ctypes as C
 import os
@@ -62,6 +62,8 @@ RUN = {
     "morph_fused": lambda: gd.dilate_erode(depth, l, r, l, r, binarize=(0.0, False, 1.0, 0.0), out=b),
     "smooth_hann_batch": lambda: gd.smooth_batch(parts_in(real), 101, outs=parts_b, mode=gd.FIR_HANN),
     "smooth_exact_batch": lambda: gd.smooth_batch(parts_in(real), 101, outs=parts_b, mode=gd.FIR_EXACT),
+    "smooth_fma_batch": lambda: gd.smooth_batch(parts_in(real), 101, outs=parts_b, mode=gd.FIR_FMA),
+    "percentile_binarize": lambda: gd.percentile_binarize(parts_in(real), [99000], outs=parts_b),
     "peaks_exact_batch": lambda: gd.smooth_local_extrema_batch(parts_in(real), 101, 11, True, 0.0, outs=parts_b, mode=gd.FIR_EXACT),
     "morph_fused_batch": lambda: gd.dilate_erode_batch(parts_in(depth), l, r, l, r, binarize=(0.0, False, 1.0, 0.0), outs=parts_b),
     "binarize_batch": lambda: (copy(a, depth), gd.binarize_batch(parts_in(a), 10.0)),
