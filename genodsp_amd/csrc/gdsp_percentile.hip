@@ -109,7 +109,8 @@ void pc_sample_kernel (const double* __restrict__ v, uint32_t n, uint32_t window
 // What lies inside the bracket, pivot ties included (0.1 % of real-valued coverage, a few per cent of read depth), is
 // left for pc_fixup_kernel: its position goes to a list (wave-aggregated like the candidates), `zero` is written
 // meanwhile.  8 B read + 8 B written per base for the pair of operators instead of 24.
-struct PcFuse { double vLo, vHi, one, zero;  double* out;  uint32_t* pos;  unsigned long long* posCount;  uint32_t posCap; };
+struct PcFuse { double vLo, vHi, one, zero;  double* out;  uint32_t* pos;  unsigned long long* posCount;  uint32_t posCap;
+                int jLo, jHi; };                              // the bracket's ends as pivots of the counting pass (-1: that side is open)
 
 template <int M, bool BOUNDED, bool DENSE, bool FUSE>
 __global__ __launch_bounds__(PC_THREADS)
@@ -176,9 +177,11 @@ void pc_partition_kernel (const double* __restrict__ v, uint32_t n, uint32_t win
 	auto bump = [] (uint32_t& counter, uint64_t mask)
 		{ asm volatile ("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(counter) : "s"(mask) : "vcc"); };
 
+	uint64_t fuseGeLo = 0, fuseGtHi = 0, fuseOdd = 0;              // of the element counted last: at or above the bracket's low pivot, above its high one, not finite
 	auto count = [&] (double x)
 		{
 		uint64_t keep = 0, above = ~0ULL, gthi = 0;
+		if (FUSE) { fuseGeLo = ~0ULL;  fuseGtHi = 0; }
 		if (BOUNDED)
 			{
 			above = __ballot (x >= lo);  gthi = __ballot (x > hi);
@@ -189,11 +192,13 @@ void pc_partition_kernel (const double* __restrict__ v, uint32_t n, uint32_t win
 			{
 			const uint64_t gt = __ballot (x >  P.val[j]), eq = __ballot (x == P.val[j]);
 			bump (cGt[j], gt);  bump (cEq[j], eq);
+			if (FUSE) { if (j == F.jLo) fuseGeLo = gt | eq;  if (j == F.jHi) fuseGtHi = gt; }       // (scalar selects)
 			keep |= above & ~gt & ~eq & take[j];
 			above = gt;
 			}
 		keep = (keep | (above & take[M])) & ~gthi;             // (with fewer than M pivots the top bin is met inside the loop)
 		const uint64_t odd = __ballot (!__builtin_isfinite (x));
+		if (FUSE) fuseOdd = odd;
 		if (odd != 0)
 			{
 			const bool     nanp = (x != x) && !signbit (x), nann = (x != x) && signbit (x);
@@ -223,10 +228,13 @@ void pc_partition_kernel (const double* __restrict__ v, uint32_t n, uint32_t win
 		uheld = 0;
 		};
 	// the binarized value of x where the bracket decides it, `zero` and a queued position where it does not
+	// (the masks of the element just counted say where it stands: the bracket's ends are pivots of the pass; only an
+	//  element that is not finite is compared again -- an infinity lies beyond an end, a NaN is `zero`)
 	auto settle = [&] (double x, size_t e, bool exists)
 		{
-		const bool isOne = (x > F.vHi);
-		const bool open  = exists && !isOne && !(x < F.vLo) && (x == x);
+		bool isOne = (fuseGtHi >> lane) & 1;
+		bool open  = exists && !isOne && ((fuseGeLo >> lane) & 1);
+		if (fuseOdd != 0) { isOne = (x > F.vHi);  open = exists && !isOne && !(x < F.vLo) && (x == x); }
 		const uint64_t und = __ballot (open);
 		if (und != 0)
 			{
@@ -243,9 +251,12 @@ void pc_partition_kernel (const double* __restrict__ v, uint32_t n, uint32_t win
 		{
 		double2 cur[8];
 		load (tile, cur);
+		if (!FUSE)
+			{
 #pragma unroll
-		for (int u=0 ; u<8 ; u++) { count (cur[u].x);  count (cur[u].y); }
-		if (FUSE)                                                  // (DENSE: element e of the vector is population element e)
+			for (int u=0 ; u<8 ; u++) { count (cur[u].x);  count (cur[u].y); }
+			}
+		else                                                       // (DENSE: element e of the vector is population element e)
 			{
 			const size_t base = (size_t) tile * PC_TILE;
 			const bool   full = (base + PC_TILE <= npop);
@@ -253,7 +264,10 @@ void pc_partition_kernel (const double* __restrict__ v, uint32_t n, uint32_t win
 			for (int u=0 ; u<8 ; u++)
 				{
 				const size_t e = base + 2 * ((size_t) u*PC_THREADS + threadIdx.x);
-				const double r0 = settle (cur[u].x, e, e < npop), r1 = settle (cur[u].y, e + 1, e + 1 < npop);
+				count (cur[u].x);
+				const double r0 = settle (cur[u].x, e, e < npop);
+				count (cur[u].y);
+				const double r1 = settle (cur[u].y, e + 1, e + 1 < npop);
 				if (full) gdsp_st2 (reinterpret_cast<double2*> (F.out + e), make_double2 (r0, r1));
 				else { if (e < npop) F.out[e] = r0;  if (e + 1 < npop) F.out[e + 1] = r1; }
 				}
@@ -971,12 +985,19 @@ static int pc_run (const gdsp_select_source* sources, int nsources, uint32_t win
 	const bool bounded = !((lo <= -DBL_MAX) && (hi >= DBL_MAX));
 	// a fused binarize rests on the bracket of ITS percentile: a NaN end cannot be compared, an open end decides nothing
 	bool fuseUsable = false;
+	int  fuseJLo = -1, fuseJHi = -1;
 	if (J.fuse != NULL)
 		{
 		const int w = J.fuse->which;
 		J.vLo = openLo[w]? -INFINITY : gdsp_value_of (bLo[w]);
 		J.vHi = openHi[w]?  INFINITY : gdsp_value_of (bHi[w]);
 		fuseUsable = (J.vLo == J.vLo) && (J.vHi == J.vHi);
+		for (int j=0 ; j<P.m ; j++)                              // the bracket's ends among the (sorted, distinct) pivots
+			{
+			if (!openLo[w] && (piv[j] == bLo[w])) fuseJLo = j;
+			if (!openHi[w] && (piv[j] == bHi[w])) fuseJHi = j;
+			}
+		if ((!openLo[w] && (fuseJLo < 0)) || (!openHi[w] && (fuseJHi < 0))) fuseUsable = false;
 		}
 	uint64_t   padded  = 0;                                      // elements the kernels count, padding included
 	for (size_t d=0 ; d<J.devices.size () ; d++)
@@ -1001,6 +1022,7 @@ static int pc_run (const gdsp_select_source* sources, int nsources, uint32_t win
 				F.vLo = J.vLo;  F.vHi = J.vHi;  F.one = J.fuse->one;  F.zero = J.fuse->zero;  F.out = J.fuse->d_out[i];
 				F.pos = J.scratch[d]->pos + J.posOffset[i];  F.posCount = J.scratch[d]->posCount + J.fusedSource[i];
 				F.posCap = (uint32_t) J.posCap[i];
+				F.jLo = fuseJLo;  F.jHi = fuseJHi;
 				J.fusedAny = true;
 				}
 			else J.fusedSource[i] = -1;
