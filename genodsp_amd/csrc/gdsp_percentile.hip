@@ -103,6 +103,45 @@ void pc_sample_kernel (const double* __restrict__ v, uint32_t n, uint32_t window
 #define PC_REPL         64
 #define PC_CTR_ALL      (PC_REPL * PC_CTR_WORDS + 1)      // replicas, then the candidate count
 
+// state of the resident route (see pc_res_digit_kernel below)
+#define PC_RES_MAXP   8                                        // percentiles per call
+#define PC_RES_BINS   (1 << 13)
+#define PC_RES_SAMPLE 0
+#define PC_RES_CAND   1
+enum { PC_RES_OK = 0, PC_RES_FEW = 1, PC_RES_PIVOTS = 2, PC_RES_DISAGREE = 3, PC_RES_NOFUSE = 4 };
+struct PcResident
+	{
+	uint32_t status, pad0;
+	uint64_t sTotal;                                           // values of the subsample that qualify
+	uint64_t selPrefix[2], selK[2], selKey[2];                 // the (at most two) ranks the select in flight is chasing
+	uint32_t selDone[2];
+	uint64_t bLo[PC_RES_MAXP], bHi[PC_RES_MAXP];               // per percentile: its bracket's ends as keys
+	uint32_t openLo[PC_RES_MAXP], openHi[PC_RES_MAXP];         // ... or no end on that side
+	uint64_t piv[PC_MAX_PIVOTS];                               // sorted distinct pivots as keys
+	PcPivots P;                                                // ... as the counting pass wants them
+	double   vLo, vHi;                                         // the fused binarize's bracket, and its ends among the pivots
+	int      jLo, jHi;
+	uint64_t N, candCount, overflow;                           // after the counting pass: population, candidates kept, list overflowed
+	uint64_t bins[2*PC_MAX_PIVOTS + 1];
+	uint32_t how[PC_RES_MAXP];                                 // 0: answered (a pivot's ties, or nothing to answer)  1: an order statistic of the candidates  2: needs the plain route
+	uint64_t scopeLo[PC_RES_MAXP], scopeHi[PC_RES_MAXP], rankIn[PC_RES_MAXP], binCount[PC_RES_MAXP];
+	uint32_t candTop[PC_RES_MAXP];                             // the bits of the scope's keys below their common prefix
+	double   values[PC_RES_MAXP];
+#ifdef PC_RES_TIMING
+	unsigned long long dbg[2][5][8];
+#endif
+	};
+#define PC_RES_THREADS 1024
+#define PC_RES_MAXB    32                                      // workgroups of a digit pass, at most
+struct PcResHist                                               // behind the PcResident in one allocation, zeroed with it before a call
+	{
+	unsigned long long notMin[2], max[2];                      // ~(smallest key counted), largest key counted: zero = nothing counted
+	uint32_t ticket, pad[7];
+	uint32_t slab[1][2][PC_RES_BINS];                          // the shared histogram(s) of the pass in flight: zero between passes
+	};
+struct PcPts { uint32_t v[PC_RES_MAXP];  int n; };
+#define PC_RES_STATE_BYTES ((sizeof(PcResident) + 255) / 256 * 256)
+
 // FUSE: `= percentile P = binarize --threshold=percentileP` in the same read (logical.c:216-268 behind percentile.c:392-751).
 // The threshold T -- the percentile -- is not known yet, but its bracket [vLo, vHi] is: a value above vHi is above T, a
 // value below vLo (or a NaN) is not, and both are written as `one` / `zero` right here (16-byte stores, out of place).
@@ -116,9 +155,15 @@ template <int M, bool BOUNDED, bool DENSE, bool FUSE>
 __global__ __launch_bounds__(PC_THREADS)
 void pc_partition_kernel (const double* __restrict__ v, uint32_t n, uint32_t window, double lo, double hi, PcPivots P,
                           unsigned long long* __restrict__ ctr, uint64_t* __restrict__ cand, unsigned long long cap,
-                          uint32_t ntiles, PcFuse F)
+                          uint32_t ntiles, PcFuse F, const PcResident* __restrict__ res)
 	{
 	constexpr int NC = 2*M + 5;                                // counters of this instantiation
+	if (res != NULL)                                           // the resident route: pivots and bracket were decided on the device
+		{
+		if (res->status != PC_RES_OK) return;
+		P = res->P;
+		if (FUSE) { F.vLo = res->vLo;  F.vHi = res->vHi;  F.jLo = res->jLo;  F.jHi = res->jHi; }
+		}
 	__shared__ uint64_t wbuf[PC_THREADS/64][PC_WAVE_BUF];
 	__shared__ uint32_t wcount[PC_THREADS/64][NC];
 	__shared__ uint32_t ubuf[FUSE? PC_THREADS/64 : 1][FUSE? PC_WAVE_BUF : 1];
@@ -464,6 +509,412 @@ void pc_pick_kernel (unsigned long long* __restrict__ hist, int shift, int bits,
 	for (int b=p ; b<nbins+2 ; b+=PC_PICK_THREADS) hist[b] = (b == nbins)? ~0ULL : 0ULL;
 	}
 
+// ---- the resident route: a call on ONE device whose counts nobody else has to see is decided entirely there.  Every
+// step of the bracket route that the host used to take between kernels -- the subsample's size, the ranks either side
+// of a target, the bucket of a digit, the pivots, the bins and ranks after the counting pass, the scope of the
+// candidate select, whether the fused binarize's bracket held -- is taken by the LAST workgroup of the launch whose
+// output it needs (an arrival ticket; nobody waits, so nothing can hang) or by a one-workgroup kernel, and its outcome
+// stays in HBM (PcResident) where the next launch reads it.  The launches are queued back to back (a boundary is
+// 1.5-2 us, cheaper than a grid barrier); the host reads the state ONCE, at the end.  A digit pass chases the two
+// ranks of a bracket together (two histograms in LDS when their prefixes have parted).  Anything the route cannot
+// settle (a subsample too small to place pivots, a NaN pivot, a fused bracket with a NaN end) sets `status` before
+// anything observable has been written: every later kernel returns at once and the host runs the call again the
+// old way.
+__device__ __forceinline__ uint32_t pc_res_rank (uint64_t N, uint32_t pThousandths)     // gdsp_percentile_rank (percentile.c:587-589, :688-710)
+	{
+	const uint32_t numValues = (uint32_t) N;
+	uint32_t k = (uint32_t) (((uint64_t) numValues) * pThousandths / (100.0*1000));
+	if ((numValues != 0) && (k >= numValues)) k = numValues - 1;
+	return k;
+	}
+
+// one digit of a select over a list of keys.  stage SAMPLE: the subsample, ranks either side of percentile `which`'s
+// target (decided after digit 0, when the subsample's size is known), digits at the fixed positions of the plain select;
+// stage CAND: the candidates within the scope the bins kernel set for percentile `which`, one rank, 13-bit digits from
+// the first bit the scope's ends differ in downwards.  count = min(*countPtr, countCap) when countPtr is given.
+// A few big workgroups (<= PC_RES_MAXB of 1024 threads): each counts its share in LDS and adds its non-empty bins to
+// the shared histogram (agent-scope atomics: the XCDs' L2s are not coherent; about 5 per ns, 13 us of a 25-30 us pass
+// over 243 k keys); the workgroup whose ticket is last reads it (32 bytes per thread), picks and clears it.  Measured
+// against it: every workgroup writing its histogram whole to a slab of its own with write-through stores and the last
+// one adding the slabs up -- 3 us to write, but one CU reads the 0.5-1 MB of slabs at 40-65 GB/s: 13-22 us, slower.
+__global__ __launch_bounds__(PC_RES_THREADS)
+void pc_res_digit_kernel (const uint64_t* __restrict__ keys, const unsigned long long* __restrict__ countPtr, unsigned long long countCap,
+                          int stage, int digit, int which, uint32_t pThousandths, PcResident* __restrict__ R, PcResHist* __restrict__ H)
+	{
+	__shared__ uint32_t lb[2][PC_RES_BINS];
+	__shared__ unsigned long long sMin[2][PC_RES_THREADS/64], sMax[2][PC_RES_THREADS/64];
+	__shared__ unsigned long long sK[2], sBucket[2], sWithin[2];
+	__shared__ uint32_t sFound[2], sLast;
+	if (R->status != PC_RES_OK) return;
+	if ((stage == PC_RES_CAND) && (R->how[which] != 1)) return;
+	const bool     a0 = (digit > 0) && !R->selDone[0], a1 = (digit > 0) && !R->selDone[1];
+	if ((digit > 0) && !a0 && !a1) return;
+	int shift, bits;
+	if (stage == PC_RES_SAMPLE) { shift = (digit == 0)? 52 : 52 - 13*digit;  bits = (digit == 0)? 12 : 13; }
+	else
+		{
+		const int top = (int) R->candTop[which] - 13*digit;        // bits not yet looked at (>= 1 at digit 0)
+		if (top <= 0) return;                                      // (every rank is settled by then: selDone says so already)
+		bits = (top < 13)? top : 13;  shift = top - bits;
+		}
+	const int      nbins = 1 << bits, above = shift + bits;
+	const uint64_t mask  = (uint64_t) nbins - 1;
+	const bool     bounded = (stage == PC_RES_CAND);
+	const uint64_t keyLo = bounded? R->scopeLo[which] : 0, keyHi = bounded? R->scopeHi[which] : ~0ULL;
+	// digit 0 counts everything in scope (the candidates' scope shares every bit above its first digit)
+	const uint64_t p0 = (digit == 0)? 0 : R->selPrefix[0] >> (above & 63), p1 = (digit == 0)? 0 : R->selPrefix[1] >> (above & 63);
+	const bool     two = a0 && a1 && (p0 != p1);               // the two ranks have parted: a histogram each
+	const uint64_t pA  = ((digit == 0) || a0)? p0 : p1, pB = p1;   // histogram 0 counts under pA, histogram 1 (when two) under pB
+	unsigned long long count = countCap;
+	if (countPtr != NULL) { const unsigned long long c = *countPtr;  if (c < count) count = c; }
+#ifdef PC_RES_TIMING
+	unsigned long long stamp[8];
+#define PC_STAMP(k) stamp[k] = wall_clock64 ()
+#else
+#define PC_STAMP(k)
+#endif
+	PC_STAMP (0);
+
+	const int p = threadIdx.x, lane = p & 63, wave = p >> 6;
+	for (int b=p ; b<nbins ; b+=PC_RES_THREADS) { lb[0][b] = 0;  if (two) lb[1][b] = 0; }
+	__syncthreads ();
+	uint64_t kminA = ~0ULL, kmaxA = 0, kminB = ~0ULL, kmaxB = 0;
+	auto tally = [&] (uint64_t key)
+		{
+		if (key == PC_NO_KEY) return;
+		if (bounded && !((key >= keyLo) && (key <= keyHi))) return;
+		const uint64_t top = (above < 64)? (key >> above) : 0;
+		if ((digit == 0) || (top == pA))
+			{
+			atomicAdd (&lb[0][(uint32_t) ((key >> shift) & mask)], 1u);
+			if (key < kminA) kminA = key;
+			if (key > kmaxA) kmaxA = key;
+			}
+		else if (two && (top == pB))
+			{
+			atomicAdd (&lb[1][(uint32_t) ((key >> shift) & mask)], 1u);
+			if (key < kminB) kminB = key;
+			if (key > kmaxB) kmaxB = key;
+			}
+		};
+	const size_t stride = (size_t) gridDim.x * PC_RES_THREADS;
+	size_t i = (size_t) blockIdx.x * PC_RES_THREADS + p;
+	for ( ; i < count ; i += 16*stride)                          // sixteen loads in flight (a list of 16 keys per thread: one round)
+		{
+		uint64_t k[16];
+#pragma unroll
+		for (int u=0 ; u<16 ; u++) k[u] = (i + u*stride < count)? keys[i + u*stride] : PC_NO_KEY;
+#pragma unroll
+		for (int u=0 ; u<16 ; u++) tally (k[u]);
+		}
+	__syncthreads ();
+	PC_STAMP (1);
+	// into the shared histogram(s): agent-scope adds of this workgroup's non-empty bins
+	for (int h=0 ; h<(two? 2 : 1) ; h++)
+		for (int b=p ; b<nbins ; b+=PC_RES_THREADS) { const uint32_t c = lb[h][b];  if (c) atomicAdd (&H->slab[0][h][b], c); }
+	for (int off=32 ; off>0 ; off>>=1)
+		{
+		uint64_t a = __shfl_down ((unsigned long long) kminA, off, 64), b = __shfl_down ((unsigned long long) kmaxA, off, 64);
+		if (a < kminA) kminA = a;
+		if (b > kmaxA) kmaxA = b;
+		a = __shfl_down ((unsigned long long) kminB, off, 64);  b = __shfl_down ((unsigned long long) kmaxB, off, 64);
+		if (a < kminB) kminB = a;
+		if (b > kmaxB) kmaxB = b;
+		}
+	if (lane == 0) { sMin[0][wave] = kminA;  sMax[0][wave] = kmaxA;  sMin[1][wave] = kminB;  sMax[1][wave] = kmaxB; }
+	asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");              // every storing wave, before the barrier the ticket waits behind
+	__syncthreads ();
+	PC_STAMP (2);
+	if (p == 0)
+		{
+		for (int h=0 ; h<2 ; h++)
+			{
+			uint64_t lo = ~0ULL, hi = 0;
+			for (int w=0 ; w<PC_RES_THREADS/64 ; w++) { if (sMin[h][w] < lo) lo = sMin[h][w];  if (sMax[h][w] > hi) hi = sMax[h][w]; }
+			if (lo <= hi) { atomicMax (&H->notMin[h], (unsigned long long) ~lo);  atomicMax (&H->max[h], (unsigned long long) hi); }
+			}
+		asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+		const uint32_t t = __hip_atomic_fetch_add (&H->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		sLast = (t == gridDim.x - 1)? 1 : 0;
+		if (sLast) __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "agent");
+		asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+		}
+	__syncthreads ();
+	if (!sLast) return;
+	PC_STAMP (3);
+
+	// ---- the last workgroup: bucket(s) of the rank(s) in the summed histogram(s) (thread p: bins per*p ..), the state
+	// advanced.  What thread 0 needs of the state is fetched now, in one round of latency, not word by word as it goes.
+	const int per = nbins / PC_RES_THREADS;                        // 8, 4 (12 bits) or fewer (a last digit of under 10 bits: threads past nbins idle)
+	const int mineN = (per >= 1)? per : ((p < nbins)? 1 : 0), first = (per >= 1)? per * p : p;
+	uint64_t stK[2] = { 0, 0 }, stPrefix[2] = { 0, 0 }, stMin[2] = { 0, 0 }, stMax[2] = { 0, 0 }, stRank = 0, stBin = 0;
+	if (p == 0)
+		{
+		stK[0] = R->selK[0];  stK[1] = R->selK[1];  stPrefix[0] = R->selPrefix[0];  stPrefix[1] = R->selPrefix[1];
+		stMin[0] = ~H->notMin[0];  stMin[1] = ~H->notMin[1];  stMax[0] = H->max[0];  stMax[1] = H->max[1];
+		if (stage == PC_RES_CAND) { stRank = R->rankIn[which];  stBin = R->binCount[which]; }
+		}
+	uint32_t sum[2][8];
+	for (int h=0 ; h<2 ; h++) { for (int j=0 ; j<8 ; j++) sum[h][j] = 0; }
+	for (int h=0 ; h<(two? 2 : 1) ; h++)
+		{
+		if (per == 8)
+			{
+			const uint4* src = reinterpret_cast<const uint4*> (&H->slab[0][h][8*p]);
+			const uint4 x = src[0], y = src[1];
+			sum[h][0] = x.x;  sum[h][1] = x.y;  sum[h][2] = x.z;  sum[h][3] = x.w;  sum[h][4] = y.x;  sum[h][5] = y.y;  sum[h][6] = y.z;  sum[h][7] = y.w;
+			}
+		else if (per == 4)
+			{
+			const uint4 x = *reinterpret_cast<const uint4*> (&H->slab[0][h][4*p]);
+			sum[h][0] = x.x;  sum[h][1] = x.y;  sum[h][2] = x.z;  sum[h][3] = x.w;
+			}
+		else                                                       // a short last digit: two bins, one or none per thread
+			for (int j=0 ; j<mineN ; j++) sum[h][j] = H->slab[0][h][first + j];
+		}
+	asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+	PC_STAMP (6);
+	// inclusive scans of both histograms in the same rounds
+	__shared__ unsigned long long sW2[2][PC_RES_THREADS/64];
+	unsigned long long mine[2] = { 0, 0 }, incl[2];
+#pragma unroll
+	for (int j=0 ; j<8 ; j++) { mine[0] += sum[0][j];  mine[1] += sum[1][j]; }
+	incl[0] = mine[0];  incl[1] = mine[1];
+	for (int d=1 ; d<64 ; d*=2)
+		{
+		const unsigned long long u0 = __shfl_up (incl[0], d, 64), u1 = __shfl_up (incl[1], d, 64);
+		if (lane >= d) { incl[0] += u0;  incl[1] += u1; }
+		}
+	if (lane == 63) { sW2[0][wave] = incl[0];  sW2[1][wave] = incl[1]; }
+	if (p < 2) sFound[p] = 0;
+	if (p == 0) { sK[0] = (digit > 0)? stK[0] : ~0ULL;  sK[1] = (digit > 0)? stK[1] : ~0ULL; }
+	__syncthreads ();
+	unsigned long long lo[2], hi[2], all[2];
+	for (int h=0 ; h<2 ; h++)
+		{
+		unsigned long long before = 0, t = 0;
+		for (int w=0 ; w<PC_RES_THREADS/64 ; w++) { const unsigned long long x = sW2[h][w];  if (w < wave) before += x;  t += x; }
+		all[h] = t;  lo[h] = before + incl[h] - mine[h];  hi[h] = before + incl[h];
+		}
+	PC_STAMP (7);
+	const int hs[2] = { 0, two? 1 : 0 };                         // the histogram each rank is looked up in
+	bool v0 = false, v1 = false;                                   // digit 0: the ranks exist
+	if (digit == 0)
+		{
+		// how many there are decides the ranks (host: pc_run step 2); both are looked up in the one histogram
+		if (p == 0)
+			{
+			const uint64_t total = all[0];
+			if (stage == PC_RES_SAMPLE)
+				{
+				R->sTotal = total;
+				if (total < 256) R->status = PC_RES_FEW;
+				else
+					{
+					const double pp = pThousandths / 100000.0;
+					const double ks = floor ((double) total * pp);
+					const double dl = ceil (4.0 * sqrt ((double) total * pp * (1.0 - pp))) + 16.0;
+					v0 = (ks - dl >= 0.0);  v1 = (ks + dl <= (double) total - 1);
+					if (v0) sK[0] = (uint64_t) (ks - dl);
+					if (v1) sK[1] = (uint64_t) (ks + dl);
+					}
+				R->openLo[which] = v0? 0 : 1;  R->openHi[which] = v1? 0 : 1;
+				}
+			else
+				{
+				if (total != stBin) R->status = PC_RES_DISAGREE;
+				else { v0 = true;  sK[0] = stRank; }
+				}
+			}
+		__syncthreads ();
+		}
+	for (int r=0 ; r<2 ; r++)
+		{
+		const int h = hs[r];
+		const unsigned long long k = sK[r];
+		if (!((k >= lo[h]) && (k < hi[h]))) continue;
+		unsigned long long seen = lo[h];
+#pragma unroll
+		for (int j=0 ; j<8 ; j++)
+			{
+			if ((j < mineN) && (k >= seen) && (k < seen + sum[h][j])) { sBucket[r] = (unsigned long long) (first + j);  sWithin[r] = k - seen;  sFound[r] = 1; }
+			seen += sum[h][j];
+			}
+		}
+	__syncthreads ();
+	if (p == 0)
+		{
+		const bool lastDigit = (shift == 0);
+		// what every key counted at digit 0 has above it (nothing for the subsample, the scope's common bits for the candidates)
+		const uint64_t common = (above < 64)? ((keyLo >> above) << above) : 0;
+		uint32_t status = (digit == 0)? R->status : PC_RES_OK;       // (digit 0: what the rank decision just wrote)
+		for (int s=0 ; s<2 ; s++)
+			{
+			const bool active = (digit == 0)? (s == 0? v0 : v1) : (s == 0? a0 : a1);
+			if (digit == 0) R->selDone[s] = active? 0 : 1;
+			if (!active || (status != PC_RES_OK)) continue;
+			const int      h = hs[s];
+			const uint64_t kmin = stMin[h], kmax = stMax[h];
+			uint64_t key = 0;
+			bool     done = false;
+			if ((all[h] != 0) && (kmin == kmax)) { key = kmin;  done = true; }         // one distinct value left under this prefix
+			else if (!sFound[s]) { status = PC_RES_DISAGREE;  R->status = status;  continue; }
+			else
+				{
+				const uint64_t prefix = ((digit == 0)? common : stPrefix[s]) | (((uint64_t) sBucket[s]) << shift);
+				R->selPrefix[s] = prefix;  R->selK[s] = sWithin[s];
+				if (lastDigit) { key = prefix;  done = true; }
+				}
+			if (done)                                                  // a rank that has been settled is written where its stage keeps it
+				{
+				R->selKey[s] = key;  R->selDone[s] = 1;
+				if (stage == PC_RES_SAMPLE) { if (s == 0) R->bLo[which] = key;  else R->bHi[which] = key; }
+				else R->values[which] = gdsp_value_of (key);
+				}
+			}
+		}
+	__syncthreads ();
+	PC_STAMP (4);
+	for (int b=p ; b<PC_RES_BINS ; b+=PC_RES_THREADS) { H->slab[0][0][b] = 0;  H->slab[0][1][b] = 0; }
+	if (p == 0) { H->notMin[0] = H->notMin[1] = 0;  H->max[0] = H->max[1] = 0;  H->ticket = 0; }
+	PC_STAMP (5);
+#ifdef PC_RES_TIMING
+	if (p == 0) { for (int k=0 ; k<8 ; k++) R->dbg[stage][digit][k] = stamp[k]; }
+#endif
+	}
+
+// the pivots of the counting pass out of every percentile's bracket (host: pc_run, the end of step 2)
+__global__ void pc_res_pivots_kernel (PcResident* __restrict__ R, int np, int fuseWhich)
+	{
+	if ((threadIdx.x != 0) || (blockIdx.x != 0) || (R->status != PC_RES_OK)) return;
+	uint64_t piv[2*PC_RES_MAXP];
+	int m = 0;
+	for (int i=0 ; i<np ; i++)
+		{
+		if (!R->openLo[i]) piv[m++] = R->bLo[i];
+		if (!R->openHi[i]) piv[m++] = R->bHi[i];
+		}
+	for (int a=1 ; a<m ; a++)                                      // (insertion sort of <= 16 keys)
+		{ const uint64_t x = piv[a];  int b = a;  while ((b > 0) && (piv[b-1] > x)) { piv[b] = piv[b-1];  b--; }  piv[b] = x; }
+	int u = 0;
+	for (int a=0 ; a<m ; a++) { if ((a == 0) || (piv[a] != piv[u-1])) piv[u++] = piv[a]; }
+	m = u;
+	bool usable = (m >= 1);
+	for (int j=0 ; j<PC_MAX_PIVOTS ; j++)
+		{
+		const double val = (j < m)? gdsp_value_of (piv[j]) : NAN;
+		R->P.val[j] = val;  R->piv[j] = (j < m)? piv[j] : 0;
+		if ((j < m) && (val != val)) usable = false;               // a NaN pivot cannot be compared as a double
+		}
+	R->P.m = m;
+	uint64_t collect = 0;
+	for (int j=0 ; j<=m ; j++)                                     // open bin j: above pivot j-1, below pivot j
+		for (int i=0 ; i<np ; i++)
+			{
+			const bool fromBelow = (j == 0)? (R->openLo[i] != 0) : (!R->openLo[i]? (R->bLo[i] <= piv[j-1]) : true);
+			const bool toAbove   = (j == m)? (R->openHi[i] != 0) : (!R->openHi[i]? (piv[j] <= R->bHi[i])   : true);
+			if (fromBelow && toAbove) collect |= (1ULL << j);
+			}
+	R->P.collect = collect;
+	if (!usable) { R->status = PC_RES_PIVOTS;  return; }
+	if (fuseWhich >= 0)
+		{
+		const int w = fuseWhich;
+		const double vLo = R->openLo[w]? -INFINITY : gdsp_value_of (R->bLo[w]);
+		const double vHi = R->openHi[w]?  INFINITY : gdsp_value_of (R->bHi[w]);
+		int jLo = -1, jHi = -1;
+		for (int j=0 ; j<m ; j++)
+			{
+			if (!R->openLo[w] && (piv[j] == R->bLo[w])) jLo = j;
+			if (!R->openHi[w] && (piv[j] == R->bHi[w])) jHi = j;
+			}
+		R->vLo = vLo;  R->vHi = vHi;  R->jLo = jLo;  R->jHi = jHi;
+		if (!((vLo == vLo) && (vHi == vHi)) || (!R->openLo[w] && (jLo < 0)) || (!R->openHi[w] && (jHi < 0))) R->status = PC_RES_NOFUSE;
+		}
+	}
+
+// after the counting pass: the replicas summed, bins, population and ranks (host: pc_run steps 3-4); which percentile is
+// a pivot's tie, which an order statistic of the candidates (and of which), which has to take the plain route
+__global__ __launch_bounds__(PC_THREADS)
+void pc_res_bins_kernel (PcResident* __restrict__ R, const unsigned long long* __restrict__ ctr, unsigned long long candCap,
+                         int bounded, unsigned long long padded, PcPts pts)
+	{
+	__shared__ unsigned long long raw[PC_CTR_WORDS];
+	if (R->status != PC_RES_OK) return;
+	for (int c=threadIdx.x ; c<PC_CTR_WORDS ; c+=PC_THREADS)
+		{
+		unsigned long long t = 0;
+		for (int r=0 ; r<PC_REPL ; r++) t += ctr[(size_t) r * PC_CTR_WORDS + c];
+		raw[c] = t;
+		}
+	__syncthreads ();
+	if (threadIdx.x != 0) return;
+	const int m = R->P.m, nb = 2*m + 1;
+	unsigned long long cands = ctr[(size_t) PC_REPL * PC_CTR_WORDS];
+	const bool overflow = (cands > candCap);
+	if (overflow) cands = candCap;
+	R->candCount = cands;  R->overflow = overflow? 1 : 0;
+	const unsigned long long nans  = raw[PC_CTR_NANPOS] + raw[PC_CTR_NANNEG];
+	const unsigned long long total = bounded? raw[PC_CTR_GELO] - raw[PC_CTR_GTHI] + nans
+	                                        : padded - raw[PC_CTR_GTHI] - raw[PC_CTR_NEGINF];
+	uint64_t* bins = R->bins;
+	for (int j=0 ; j<m ; j++) bins[2*j+1] = raw[PC_CTR_EQ + j];
+	bins[0] = total - (raw[PC_CTR_GT] - raw[PC_CTR_GTHI]) - raw[PC_CTR_EQ] - raw[PC_CTR_NANPOS];
+	for (int j=1 ; j<m ; j++) bins[2*j] = raw[PC_CTR_GT + j-1] - raw[PC_CTR_GT + j] - raw[PC_CTR_EQ + j];
+	bins[2*m] = (raw[PC_CTR_GT + m-1] - raw[PC_CTR_GTHI]) + raw[PC_CTR_NANPOS];
+	unsigned long long N = 0;
+	for (int b=0 ; b<nb ; b++) N += bins[b];
+	R->N = N;
+	for (int i=0 ; i<pts.n ; i++)
+		{
+		R->how[i] = 0;
+		if (N == 0) continue;
+		const unsigned long long k = pc_res_rank (N, pts.v[i]);
+		unsigned long long before = 0;
+		for (int b=0 ; b<nb ; b++)
+			{
+			if ((k >= before) && (k < before + bins[b]))
+				{
+				const int j = b >> 1;
+				if (b & 1) R->values[i] = gdsp_value_of (R->piv[j]);          // the rank lands on a pivot's ties
+				else if (overflow || !((R->P.collect >> j) & 1)) R->how[i] = 2;
+				else
+					{
+					R->how[i] = 1;
+					const uint64_t sLo = (j == 0)? 0 : R->piv[j-1] + 1, sHi = (j == m)? ~0ULL : R->piv[j] - 1;
+					R->scopeLo[i] = sLo;  R->scopeHi[i] = sHi;
+					R->rankIn[i] = k - before;  R->binCount[i] = bins[b];
+					R->candTop[i] = (sLo == sHi)? 1 : (uint32_t) (64 - __clzll ((long long) (sLo ^ sHi)));
+					}
+				break;
+				}
+			before += bins[b];
+			}
+		}
+	}
+
+// the fused binarize's open positions once the threshold is known on the device: nothing when it is not, when it fell
+// outside its bracket or when this source's strip overflowed (the host looks at the same words afterwards and
+// binarizes such a source whole)
+__global__ __launch_bounds__(PC_THREADS)
+void pc_res_fixup_kernel (const double* __restrict__ v, double* __restrict__ out, const uint32_t* __restrict__ pos,
+                          const unsigned long long* __restrict__ posCount, uint32_t cap, const PcResident* __restrict__ R, int which,
+                          int tiesAbove, double one, double zero)
+	{
+	if ((R->status != PC_RES_OK) || (R->N == 0) || (R->how[which] == 2)) return;
+	const double T = R->values[which];
+	if (!((T >= R->vLo) && (T <= R->vHi))) return;
+	const unsigned long long count = *posCount;
+	if (count > cap) return;
+	const size_t stride = (size_t) gridDim.x * PC_THREADS;
+	for (size_t i = (size_t) blockIdx.x * PC_THREADS + threadIdx.x ; i < count ; i += stride)
+		{
+		const uint32_t e = pos[i];
+		const double   x = v[e];
+		out[e] = (tiesAbove? (x >= T) : (x > T))? one : zero;
+		}
+	}
+
 // ------------------------------------------------------------- host side ----
 static const int pcShift[] = { 52, 39, 26, 13, 0 };
 static const int pcBits[]  = { 12, 13, 13, 13, 13 };
@@ -481,6 +932,7 @@ struct PcDevice                                               // scratch of one 
 	uint32_t* pos;     size_t posCap;     // fused binarize: positions the bracket left open, every source's strip one after the other
 	unsigned long long* posCount;         // one counter per source (PC_MAX_FUSED_SOURCES)
 	PcChain*  chain;                      // ranks being looked up by the chained passes
+	PcResident* res;                      // the resident route's state, a PcResHist behind it (one allocation)
 	};
 #define PC_MAX_FUSED_SOURCES 256
 #define PC_TMP_WORDS 64
@@ -507,6 +959,7 @@ static int pc_device (int device, size_t sampleCap, size_t candCap, PcDevice** o
 		GDSP_HIP_TRY (hipMalloc ((void**) &d->tmp,  PC_TMP_WORDS * sizeof(uint64_t)));
 		GDSP_HIP_TRY (hipMalloc ((void**) &d->posCount, PC_MAX_FUSED_SOURCES * sizeof(unsigned long long)));
 		GDSP_HIP_TRY (hipMalloc ((void**) &d->chain, sizeof(PcChain)));
+		GDSP_HIP_TRY (hipMalloc ((void**) &d->res, PC_RES_STATE_BYTES + sizeof(PcResHist)));
 		}
 	if (d->sampleCap < sampleCap)
 		{
@@ -543,6 +996,8 @@ struct PcJob                                                  // one call of gds
 	std::vector<size_t>    posOffset, posCap;                 // per source
 	double                 vLo, vHi;                          // the bracket the fused stores relied on
 	bool                   fusedAny;
+	bool                   fixupsDone;                        // the resident route has patched the open positions already ...
+	std::vector<unsigned long long> queuedHost;               // ... and these are the strips' counts it read back
 	};
 
 #define PC_TRY(call) do { int rc_ = (call);  if (rc_ != GDSP_OK) return rc_; } while (0)
@@ -784,6 +1239,193 @@ static int pc_radix (PcJob& J, const uint32_t* pts, const std::vector<int>& whic
 	return GDSP_OK;
 	}
 
+// the subsample of every source (pc_run step 1): slots of the sources of a device follow one another in its buffer
+static int pc_sample_launch (PcJob& J, uint32_t sstride)
+	{
+	for (size_t d=0 ; d<J.devices.size () ; d++)
+		{
+		GDSP_HIP_TRY (hipSetDevice (J.devices[d]));
+		size_t at = 0;
+		for (int i=0 ; i<J.nsrc ; i++)
+			{
+			if ((J.src[i].device != J.devices[d]) || (J.src[i].n == 0)) continue;
+			const size_t p      = ((size_t) J.src[i].n + J.window - 1) / J.window;
+			const size_t ns     = (p + sstride - 1) / sstride;
+			size_t       want   = (ns + PC_THREADS - 1) / PC_THREADS;
+			uint32_t     blocks = (uint32_t) (want > PC_MAX_BLOCKS? PC_MAX_BLOCKS : want);
+			hipLaunchKernelGGL (pc_sample_kernel, dim3(blocks), dim3(PC_THREADS), 0, gdsp_stream (J.stream[d]),
+			                    J.src[i].d_v, J.src[i].n, J.window, J.lo, J.hi, sstride, J.scratch[d]->sample + at);
+			GDSP_LAUNCH_CHECK ();
+			at += ns;
+			}
+		J.sampleCount[d] = at;                                     // slots; the ones that qualified are counted below
+		}
+	return GDSP_OK;
+	}
+
+// the counting pass over every source of this process (pc_run step 3): counters and position strips cleared, one launch
+// per source.  mUse: the pivots the instantiation has room for (>= P.m).  resident: pivots and the fused bracket are
+// read from the device's PcResident instead of P and the arguments.
+static int pc_count_launch (PcJob& J, const PcPivots& P, int mUse, bool bounded, bool fuseUsable, int fuseJLo, int fuseJHi,
+                            bool resident, uint64_t* padded)
+	{
+	for (size_t d=0 ; d<J.devices.size () ; d++)
+		{
+		GDSP_HIP_TRY (hipSetDevice (J.devices[d]));
+		GDSP_HIP_TRY (hipMemsetAsync (J.scratch[d]->ctr, 0, PC_CTR_ALL * sizeof(uint64_t), gdsp_stream (J.stream[d])));
+		GDSP_HIP_TRY (hipMemsetAsync (J.scratch[d]->posCount, 0, PC_MAX_FUSED_SOURCES * sizeof(unsigned long long), gdsp_stream (J.stream[d])));
+		unsigned long long* ctr = (unsigned long long*) J.scratch[d]->ctr;
+		const PcResident* RES = resident? J.scratch[d]->res : NULL;
+		for (int i=0 ; i<J.nsrc ; i++)
+			{
+			if ((J.src[i].device != J.devices[d]) || (J.src[i].n == 0)) continue;
+			const size_t   p      = ((size_t) J.src[i].n + J.window - 1) / J.window;
+			const uint32_t ntiles = (uint32_t) ((p + PC_TILE - 1) / PC_TILE);
+			const uint32_t perWG  = std::max<uint32_t> (1, std::min<uint32_t> (PC_TILES_PER_WG, ntiles / PC_MIN_WGS));
+			const uint32_t blocks = (ntiles + perWG - 1) / perWG;
+			const bool     dense  = (J.window == 1) && gdsp_aligned16 (J.src[i].d_v);
+			const bool     fused  = (J.fusedSource[i] >= 0) && fuseUsable;
+			PcFuse F;
+			memset (&F, 0, sizeof(F));
+			if (fused)
+				{
+				F.vLo = J.vLo;  F.vHi = J.vHi;  F.one = J.fuse->one;  F.zero = J.fuse->zero;  F.out = J.fuse->d_out[i];
+				F.pos = J.scratch[d]->pos + J.posOffset[i];  F.posCount = J.scratch[d]->posCount + J.fusedSource[i];
+				F.posCap = (uint32_t) J.posCap[i];
+				F.jLo = fuseJLo;  F.jHi = fuseJHi;
+				J.fusedAny = true;
+				}
+			else J.fusedSource[i] = -1;
+#define PC_LAUNCH_B(MM, BB)                                                                                                    \
+			do { if (fused) hipLaunchKernelGGL ((pc_partition_kernel<MM, BB, true, true>),  dim3(blocks), dim3(PC_THREADS), 0,    \
+			                                     gdsp_stream (J.stream[d]), J.src[i].d_v, J.src[i].n, J.window, J.lo, J.hi, P, ctr, \
+			                                     J.scratch[d]->cand, (unsigned long long) J.scratch[d]->candCap, ntiles, F, RES);  \
+			     else if (dense) hipLaunchKernelGGL ((pc_partition_kernel<MM, BB, true, false>),  dim3(blocks), dim3(PC_THREADS), 0, \
+			                                     gdsp_stream (J.stream[d]), J.src[i].d_v, J.src[i].n, J.window, J.lo, J.hi, P, ctr, \
+			                                     J.scratch[d]->cand, (unsigned long long) J.scratch[d]->candCap, ntiles, F, RES);  \
+			     else       hipLaunchKernelGGL ((pc_partition_kernel<MM, BB, false, false>), dim3(blocks), dim3(PC_THREADS), 0,   \
+			                                     gdsp_stream (J.stream[d]), J.src[i].d_v, J.src[i].n, J.window, J.lo, J.hi, P, ctr, \
+			                                     J.scratch[d]->cand, (unsigned long long) J.scratch[d]->candCap, ntiles, F, RES); } while (0)
+#define PC_LAUNCH(MM) do { if (bounded) PC_LAUNCH_B (MM, true);  else PC_LAUNCH_B (MM, false); } while (0)
+			*padded += (uint64_t) ntiles * PC_TILE;
+			if      (mUse <= 2)  PC_LAUNCH (2);
+			else if (mUse <= 4)  PC_LAUNCH (4);
+			else if (mUse <= 8)  PC_LAUNCH (8);
+			else if (mUse <= 16) PC_LAUNCH (16);
+			else                PC_LAUNCH (32);
+#undef PC_LAUNCH_B
+#undef PC_LAUNCH
+			GDSP_LAUNCH_CHECK ();
+			}
+		}
+	return GDSP_OK;
+	}
+
+// the bracket route with every decision taken on the device (see pc_res_digit_kernel): one device, nobody to reduce
+// with.  *took = false: the route declined (its status word says why) before writing anything a caller could see;
+// pc_run then carries on the old way.
+static int pc_resident (PcJob& J, const uint32_t* pThousandths, int np, uint32_t sstride, double* values, uint64_t* count, bool* took)
+	{
+	*took = false;
+	PcDevice*   sc = J.scratch[0];
+	hipStream_t st = gdsp_stream (J.stream[0]);
+	GDSP_HIP_TRY (hipSetDevice (J.devices[0]));
+	PcResident* R = sc->res;
+	PcResHist*  H = reinterpret_cast<PcResHist*> (reinterpret_cast<char*> (sc->res) + PC_RES_STATE_BYTES);
+	GDSP_HIP_TRY (hipMemsetAsync (R, 0, PC_RES_STATE_BYTES + sizeof(PcResHist), st));
+	PcPts pts;
+	memset (&pts, 0, sizeof(pts));
+	pts.n = np;
+	for (int i=0 ; i<np ; i++) pts.v[i] = pThousandths[i];
+
+	// subsample, then the ranks either side of every percentile's target: five digits each, no answer awaited
+	PC_TRY (pc_sample_launch (J, sstride));
+	const unsigned long long slots = J.sampleCount[0];
+	const uint32_t sblocks = (uint32_t) std::min<unsigned long long> (PC_RES_MAXB, std::max<unsigned long long> (1, (slots + 16383) / 16384));
+	for (int i=0 ; i<np ; i++)
+		for (int digit=0 ; digit<PC_DIGITS ; digit++)
+			{
+			hipLaunchKernelGGL (pc_res_digit_kernel, dim3(sblocks), dim3(PC_RES_THREADS), 0, st, sc->sample, (const unsigned long long*) NULL, slots,
+			                    PC_RES_SAMPLE, digit, i, pts.v[i], R, H);
+			GDSP_LAUNCH_CHECK ();
+			}
+	const int fuseWhich = (J.fuse != NULL)? J.fuse->which : -1;
+	hipLaunchKernelGGL (pc_res_pivots_kernel, dim3(1), dim3(64), 0, st, R, np, fuseWhich);
+	GDSP_LAUNCH_CHECK ();
+
+	// the counting pass reads its pivots (and the fused binarize its bracket) from R
+	const bool bounded = !((J.lo <= -DBL_MAX) && (J.hi >= DBL_MAX));
+	PcPivots none;
+	memset (&none, 0, sizeof(none));
+	uint64_t padded = 0;
+	PC_TRY (pc_count_launch (J, none, 2*np, bounded, J.fuse != NULL, -1, -1, true, &padded));
+	const unsigned long long* ctr = (const unsigned long long*) sc->ctr;
+	hipLaunchKernelGGL (pc_res_bins_kernel, dim3(1), dim3(PC_THREADS), 0, st, R, ctr, (unsigned long long) sc->candCap, bounded? 1 : 0,
+	                    (unsigned long long) padded, pts);
+	GDSP_LAUNCH_CHECK ();
+
+	// an order statistic of the candidates for every percentile that landed inside a bracket
+	const uint32_t cblocks = (uint32_t) std::min<size_t> (PC_RES_MAXB, std::max<size_t> (4, sc->candCap / 65536));
+	for (int i=0 ; i<np ; i++)
+		for (int digit=0 ; digit<PC_DIGITS ; digit++)
+			{
+			hipLaunchKernelGGL (pc_res_digit_kernel, dim3(cblocks), dim3(PC_RES_THREADS), 0, st, sc->cand, ctr + (size_t) PC_REPL * PC_CTR_WORDS,
+			                    (unsigned long long) sc->candCap, PC_RES_CAND, digit, i, pts.v[i], R, H);
+			GDSP_LAUNCH_CHECK ();
+			}
+	// the fused binarize's open positions
+	if (J.fusedAny)
+		for (int i=0 ; i<J.nsrc ; i++)
+			{
+			if (J.fusedSource[i] < 0) continue;
+			const uint32_t blocks = (uint32_t) std::min<size_t> (512, std::max<size_t> (1, (size_t) J.src[i].n / 65536));
+			hipLaunchKernelGGL (pc_res_fixup_kernel, dim3(blocks), dim3(PC_THREADS), 0, st, J.src[i].d_v, J.fuse->d_out[i],
+			                    sc->pos + J.posOffset[i], sc->posCount + J.fusedSource[i], (uint32_t) J.posCap[i], R, fuseWhich,
+			                    J.fuse->tiesAbove, J.fuse->one, J.fuse->zero);
+			GDSP_LAUNCH_CHECK ();
+			}
+
+	// ---- the one read-back of the call
+	PcResident got;
+	J.queuedHost.assign (PC_MAX_FUSED_SOURCES, 0);
+	GDSP_HIP_TRY (hipMemcpyAsync (&got, R, sizeof(got), hipMemcpyDeviceToHost, st));
+	if (J.fusedAny)
+		GDSP_HIP_TRY (hipMemcpyAsync (J.queuedHost.data (), sc->posCount, PC_MAX_FUSED_SOURCES * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+	GDSP_HIP_TRY (hipStreamSynchronize (st));
+	pcStats[2] = got.sTotal;
+#ifdef PC_RES_TIMING
+	for (int sg=0 ; sg<2 ; sg++)
+		for (int dg=0 ; dg<5 ; dg++)
+			{
+			fprintf (stderr, "stage %d digit %d:", sg, dg);
+			for (int k=1 ; k<8 ; k++) fprintf (stderr, " %6.2f", (double) (got.dbg[sg][dg][k] - got.dbg[sg][dg][0]) / 100.0);
+			fprintf (stderr, "  us since entry (counted, flushed, ticket, found, cleared, loaded, scanned)\n");
+			}
+#endif
+	if (got.status != PC_RES_OK)
+		{
+		if (got.status == PC_RES_DISAGREE) { gdsp_set_error ("gdsp_percentiles: candidate list and counts disagree");  return GDSP_EHIP; }
+		J.fusedAny = false;                                        // nothing was written: every kernel behind the status word returned at once
+		return GDSP_OK;
+		}
+	*took = true;
+	*count = got.N;
+	J.candCount[0] = got.candCount;
+	J.vLo = got.vLo;  J.vHi = got.vHi;
+	pcStats[1] = got.N;  pcStats[3] = got.candCount;  pcStats[5]++;  pcStats[7] = 1;
+	if (got.N == 0) return GDSP_OK;
+	std::vector<int> fallback;
+	for (int i=0 ; i<np ; i++) { if (got.how[i] == 2) fallback.push_back (i);  else values[i] = got.values[i]; }
+	J.fixupsDone = J.fusedAny && (got.how[fuseWhich < 0? 0 : fuseWhich] != 2);
+	if (!fallback.empty ())
+		{
+		uint64_t again = 0;
+		pcStats[4] = fallback.size ();
+		PC_TRY (pc_radix (J, pThousandths, fallback, values, &again));
+		}
+	return GDSP_OK;
+	}
+
 static int pc_run (const gdsp_select_source* sources, int nsources, uint32_t window, double lo, double hi,
                    const uint32_t* pThousandths, int npercentiles, int strategy, uint32_t sampleTarget,
                    gdsp_reduce_fn reduce, void* reduceCtx, double* values, uint64_t* count, PcJob& J)
@@ -899,6 +1541,18 @@ static int pc_run (const gdsp_select_source* sources, int nsources, uint32_t win
 		}
 	J.sampleCount.assign (J.devices.size (), 0);
 	J.candCount.assign (J.devices.size (), 0);
+	J.fixupsDone = false;
+
+	// one device and nobody to reduce with: the whole route on the device, one read-back
+	const bool resident = bracket && (J.devices.size () == 1) && !pc_on_device (J) && (J.reduce == NULL) && (npercentiles <= PC_RES_MAXP)
+	                   && (J.scratch[0]->candCap < (1ULL << 32)) && (getenv ("GDSP_PERCENTILE_RESIDENT_OFF") == NULL);
+	if (resident)
+		{
+		bool took = false;
+		pcStats[0] = GDSP_SELECT_BRACKET;
+		PC_TRY (pc_resident (J, pThousandths, npercentiles, sstride, values, count, &took));
+		if (took) return GDSP_OK;
+		}
 
 	std::vector<int> all;
 	for (int i=0 ; i<npercentiles ; i++) all.push_back (i);
@@ -908,25 +1562,8 @@ static int pc_run (const gdsp_select_source* sources, int nsources, uint32_t win
 
 	auto finish = [&] (int code) { return code; };
 
-	// ---- 1. subsample (slots of the sources of a device follow one another in its buffer)
-	for (size_t d=0 ; d<J.devices.size () ; d++)
-		{
-		GDSP_HIP_TRY (hipSetDevice (J.devices[d]));
-		size_t at = 0;
-		for (int i=0 ; i<nsources ; i++)
-			{
-			if ((sources[i].device != J.devices[d]) || (sources[i].n == 0)) continue;
-			const size_t p      = ((size_t) sources[i].n + window - 1) / window;
-			const size_t ns     = (p + sstride - 1) / sstride;
-			size_t       want   = (ns + PC_THREADS - 1) / PC_THREADS;
-			uint32_t     blocks = (uint32_t) (want > PC_MAX_BLOCKS? PC_MAX_BLOCKS : want);
-			hipLaunchKernelGGL (pc_sample_kernel, dim3(blocks), dim3(PC_THREADS), 0, gdsp_stream (J.stream[d]),
-			                    sources[i].d_v, sources[i].n, window, lo, hi, sstride, J.scratch[d]->sample + at);
-			GDSP_LAUNCH_CHECK ();
-			at += ns;
-			}
-		J.sampleCount[d] = at;                                     // slots; the ones that qualified are counted below
-		}
+	// ---- 1. subsample
+	PC_TRY (pc_sample_launch (J, sstride));
 	PcScope overSample = { PC_OVER_SAMPLE, 0, 0, 0 };
 	std::vector<uint64_t> sFirst (PC_HIST_WORDS);
 	PC_TRY (pc_pass (J, overSample, 0, 0, sFirst.data ()));
@@ -1000,54 +1637,7 @@ static int pc_run (const gdsp_select_source* sources, int nsources, uint32_t win
 		if ((!openLo[w] && (fuseJLo < 0)) || (!openHi[w] && (fuseJHi < 0))) fuseUsable = false;
 		}
 	uint64_t   padded  = 0;                                      // elements the kernels count, padding included
-	for (size_t d=0 ; d<J.devices.size () ; d++)
-		{
-		GDSP_HIP_TRY (hipSetDevice (J.devices[d]));
-		GDSP_HIP_TRY (hipMemsetAsync (J.scratch[d]->ctr, 0, PC_CTR_ALL * sizeof(uint64_t), gdsp_stream (J.stream[d])));
-		GDSP_HIP_TRY (hipMemsetAsync (J.scratch[d]->posCount, 0, PC_MAX_FUSED_SOURCES * sizeof(unsigned long long), gdsp_stream (J.stream[d])));
-		unsigned long long* ctr = (unsigned long long*) J.scratch[d]->ctr;
-		for (int i=0 ; i<nsources ; i++)
-			{
-			if ((sources[i].device != J.devices[d]) || (sources[i].n == 0)) continue;
-			const size_t   p      = ((size_t) sources[i].n + window - 1) / window;
-			const uint32_t ntiles = (uint32_t) ((p + PC_TILE - 1) / PC_TILE);
-			const uint32_t perWG  = std::max<uint32_t> (1, std::min<uint32_t> (PC_TILES_PER_WG, ntiles / PC_MIN_WGS));
-			const uint32_t blocks = (ntiles + perWG - 1) / perWG;
-			const bool     dense  = (window == 1) && gdsp_aligned16 (sources[i].d_v);
-			const bool     fused  = (J.fusedSource[i] >= 0) && fuseUsable;
-			PcFuse F;
-			memset (&F, 0, sizeof(F));
-			if (fused)
-				{
-				F.vLo = J.vLo;  F.vHi = J.vHi;  F.one = J.fuse->one;  F.zero = J.fuse->zero;  F.out = J.fuse->d_out[i];
-				F.pos = J.scratch[d]->pos + J.posOffset[i];  F.posCount = J.scratch[d]->posCount + J.fusedSource[i];
-				F.posCap = (uint32_t) J.posCap[i];
-				F.jLo = fuseJLo;  F.jHi = fuseJHi;
-				J.fusedAny = true;
-				}
-			else J.fusedSource[i] = -1;
-#define PC_LAUNCH_B(MM, BB)                                                                                                    \
-			do { if (fused) hipLaunchKernelGGL ((pc_partition_kernel<MM, BB, true, true>),  dim3(blocks), dim3(PC_THREADS), 0,    \
-			                                     gdsp_stream (J.stream[d]), sources[i].d_v, sources[i].n, window, lo, hi, P, ctr, \
-			                                     J.scratch[d]->cand, (unsigned long long) J.scratch[d]->candCap, ntiles, F);  \
-			     else if (dense) hipLaunchKernelGGL ((pc_partition_kernel<MM, BB, true, false>),  dim3(blocks), dim3(PC_THREADS), 0, \
-			                                     gdsp_stream (J.stream[d]), sources[i].d_v, sources[i].n, window, lo, hi, P, ctr, \
-			                                     J.scratch[d]->cand, (unsigned long long) J.scratch[d]->candCap, ntiles, F);  \
-			     else       hipLaunchKernelGGL ((pc_partition_kernel<MM, BB, false, false>), dim3(blocks), dim3(PC_THREADS), 0,   \
-			                                     gdsp_stream (J.stream[d]), sources[i].d_v, sources[i].n, window, lo, hi, P, ctr, \
-			                                     J.scratch[d]->cand, (unsigned long long) J.scratch[d]->candCap, ntiles, F); } while (0)
-#define PC_LAUNCH(MM) do { if (bounded) PC_LAUNCH_B (MM, true);  else PC_LAUNCH_B (MM, false); } while (0)
-			padded += (uint64_t) ntiles * PC_TILE;
-			if      (P.m <= 2)  PC_LAUNCH (2);
-			else if (P.m <= 4)  PC_LAUNCH (4);
-			else if (P.m <= 8)  PC_LAUNCH (8);
-			else if (P.m <= 16) PC_LAUNCH (16);
-			else                PC_LAUNCH (32);
-#undef PC_LAUNCH_B
-#undef PC_LAUNCH
-			GDSP_LAUNCH_CHECK ();
-			}
-		}
+	PC_TRY (pc_count_launch (J, P, P.m, bounded, fuseUsable, fuseJLo, fuseJHi, false, &padded));
 	const int nb = 2*P.m + 1;
 	std::vector<uint64_t> raw (PC_CTR_WORDS + 2, 0), part (PC_CTR_ALL);   // + padded count, + an overflowed candidate list anywhere
 	const size_t replicated = (size_t) PC_REPL * PC_CTR_WORDS;    // the candidate count behind them stays per device
@@ -1165,7 +1755,8 @@ static int pc_finish_binarize (PcJob& J, double T, bool* onePass)
 	const bool bracketHolds = J.fusedAny && (T >= J.vLo) && (T <= J.vHi);
 	// positions queued per fused source: one copy per device
 	std::vector<std::vector<unsigned long long> > queued (J.devices.size ());
-	if (bracketHolds)
+	if (bracketHolds && J.fixupsDone) queued[0] = J.queuedHost;    // (the resident route: one device, counts read back already)
+	else if (bracketHolds)
 		{
 		for (size_t d=0 ; d<J.devices.size () ; d++)
 			{
@@ -1189,7 +1780,7 @@ static int pc_finish_binarize (PcJob& J, double T, bool* onePass)
 		if ((slot >= 0) && (queued[d][slot] <= J.posCap[i]))
 			{
 			const unsigned long long count = queued[d][slot];
-			if (count == 0) continue;
+			if ((count == 0) || J.fixupsDone) continue;
 			const uint32_t blocks = (uint32_t) std::min<unsigned long long> (2048, (count + PC_THREADS - 1) / PC_THREADS);
 			hipLaunchKernelGGL (pc_fixup_kernel, dim3(blocks), dim3(PC_THREADS), 0, st, J.src[i].d_v, f->d_out[i],
 			                    J.scratch[d]->pos + J.posOffset[i], J.scratch[d]->posCount + slot, (uint32_t) J.posCap[i],

@@ -12,7 +12,17 @@ gd.set_device(0)
 real = gd.synth_coverage(20240611, 0, 0, n, 1)
 depth = gd.synth_coverage(20240611, 0, 0, n, 0)
 targets = [int(t) for t in os.environ.get("TARGETS", "0").split(",")]
+ROUTES = (("resident", {}), ("chained", {"GDSP_PERCENTILE_RESIDENT_OFF": "1"}),
+          ("host", {"GDSP_PERCENTILE_RESIDENT_OFF": "1", "GDSP_PERCENTILE_CHAIN_OFF": "1"}))
+only = os.environ.get("ROUTES")
+if only:
+    ROUTES = tuple(r for r in ROUTES if r[0] in only.split(","))
 for name, v in (("real", real), ("depth", depth)):
+  for route, env in ROUTES:
+    for k in ("GDSP_PERCENTILE_RESIDENT_OFF", "GDSP_PERCENTILE_CHAIN_OFF"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    os.environ["TAG"] = route
     for target in targets:
         best = 1e30
         for _ in range(reps):
