@@ -69,6 +69,26 @@ void pc_sample_kernel (const double* __restrict__ v, uint32_t n, uint32_t window
 		}
 	}
 
+// the same for up to PC_TAB sources in one launch: blockIdx.y picks the source (a launch per chromosome was 24 launches
+// of a few microseconds each, issued more slowly than they ran)
+#define PC_TAB 32
+struct PcSampleTab { const double* v[PC_TAB];  uint64_t* out[PC_TAB];  uint32_t n[PC_TAB]; };
+__global__ __launch_bounds__(PC_THREADS)
+void pc_sample_tab_kernel (PcSampleTab T, uint32_t window, double lo, double hi, uint32_t sstride)
+	{
+	const double* __restrict__ v = T.v[blockIdx.y];
+	uint64_t* __restrict__ sample = T.out[blockIdx.y];
+	const uint32_t n = T.n[blockIdx.y];
+	const size_t npop   = ((size_t) n + window - 1) / window;
+	const size_t nsamp  = (npop + sstride - 1) / sstride;
+	const size_t stride = (size_t) gridDim.x * PC_THREADS;
+	for (size_t j = (size_t) blockIdx.x * PC_THREADS + threadIdx.x ; j < nsamp ; j += stride)
+		{
+		const double x = v[j * sstride * window];
+		sample[j] = (!(x < lo) && !(x > hi))? gdsp_key_of (x) : PC_NO_KEY;
+		}
+	}
+
 // The counting pass.  Nothing is binned and nothing is masked per element: every lane counts, for
 // each pivot, the values above it and the values equal to it (a v_cmp_f64 and an add-with-carry
 // each), and -- only when the operator has --min/--max bounds -- the values >= lo and > hi.  Counts
@@ -152,7 +172,7 @@ struct PcFuse { double vLo, vHi, one, zero;  double* out;  uint32_t* pos;  unsig
                 int jLo, jHi; };                              // the bracket's ends as pivots of the counting pass (-1: that side is open)
 
 template <int M, bool BOUNDED, bool DENSE, bool FUSE>
-__global__ __launch_bounds__(PC_THREADS)
+__global__ __launch_bounds__(PC_THREADS, (M <= 2)? 5 : 1)     // two pivots: five workgroups per CU (the fused form takes 98 registers otherwise: 4 waves per SIMD)
 void pc_partition_kernel (const double* __restrict__ v, uint32_t n, uint32_t window, double lo, double hi, PcPivots P,
                           unsigned long long* __restrict__ ctr, uint64_t* __restrict__ cand, unsigned long long cap,
                           uint32_t ntiles, PcFuse F, const PcResident* __restrict__ res)
@@ -222,6 +242,25 @@ void pc_partition_kernel (const double* __restrict__ v, uint32_t n, uint32_t win
 	auto bump = [] (uint32_t& counter, uint64_t mask)
 		{ asm volatile ("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(counter) : "s"(mask) : "vcc"); };
 
+	// The compares.  A double that is finite and not negative orders like its bit pattern, and so does a pivot above zero:
+	// "above pivot j" is then a 32-bit integer compare of the high words, settled by the low words only in the waves where
+	// some lane's high word equals the pivot's (ties of read depth; one wave in thousands on real-valued coverage).  A
+	// wave with a lane that is negative, an infinity or a NaN (one integer compare says so: high word >= 0x7FF00000) takes
+	// the FP64 compares, and so does every wave when a pivot is not above zero.  v_cmp_*_f64 issues at half the rate of
+	// the 32-bit compares and these were 5 of the ~25 vector instructions per value.
+	// (Up to four pivots -- two percentiles: beyond that the pivots' words no longer fit the scalar registers.)
+	constexpr bool INTS = (M <= 4);
+	uint32_t pH[INTS? M : 1], pL[INTS? M : 1];
+	bool intOK = INTS;
+	if (INTS)
+		{
+#pragma unroll
+		for (int j=0 ; j<M ; j++)
+			{
+			pH[j] = (uint32_t) __double2hiint (P.val[j]);  pL[j] = (uint32_t) __double2loint (P.val[j]);
+			if ((j < P.m) && !((P.val[j] > 0.0) && (P.val[j] <= DBL_MAX))) intOK = false;
+			}
+		}
 	uint64_t fuseGeLo = 0, fuseGtHi = 0, fuseOdd = 0;              // of the element counted last: at or above the bracket's low pivot, above its high one, not finite
 	auto count = [&] (double x)
 		{
@@ -232,17 +271,27 @@ void pc_partition_kernel (const double* __restrict__ v, uint32_t n, uint32_t win
 			above = __ballot (x >= lo);  gthi = __ballot (x > hi);
 			bump (cGeLo, above);  bump (cGtHi, gthi);
 			}
+		const uint32_t xh = (uint32_t) __double2hiint (x), xl = (uint32_t) __double2loint (x);
+		const uint64_t special = __ballot (xh >= 0x7FF00000u);     // negative, infinite or NaN somewhere in the wave
+		const bool     fast = intOK && (special == 0);
 #pragma unroll
 		for (int j=0 ; j<M ; j++)
 			{
-			const uint64_t gt = __ballot (x >  P.val[j]), eq = __ballot (x == P.val[j]);
+			uint64_t gt, eq;
+			if (INTS && fast)
+				{
+				gt = __ballot (xh > pH[INTS? j : 0]);  eq = 0;
+				const uint64_t eqH = __ballot (xh == pH[INTS? j : 0]);
+				if (eqH != 0) { gt |= eqH & __ballot (xl > pL[INTS? j : 0]);  eq = eqH & __ballot (xl == pL[INTS? j : 0]); }
+				}
+			else { gt = __ballot (x >  P.val[j]);  eq = __ballot (x == P.val[j]); }
 			bump (cGt[j], gt);  bump (cEq[j], eq);
 			if (FUSE) { if (j == F.jLo) fuseGeLo = gt | eq;  if (j == F.jHi) fuseGtHi = gt; }       // (scalar selects)
 			keep |= above & ~gt & ~eq & take[j];
 			above = gt;
 			}
 		keep = (keep | (above & take[M])) & ~gthi;             // (with fewer than M pivots the top bin is met inside the loop)
-		const uint64_t odd = __ballot (!__builtin_isfinite (x));
+		const uint64_t odd = (special == 0)? 0 : __ballot (!__builtin_isfinite (x));
 		if (FUSE) fuseOdd = odd;
 		if (odd != 0)
 			{
@@ -272,27 +321,42 @@ void pc_partition_kernel (const double* __restrict__ v, uint32_t n, uint32_t win
 		for (uint32_t i=lane ; i<uheld ; i+=64) { if (base + i < F.posCap) F.pos[base + i] = ubuf[wave][i]; }
 		uheld = 0;
 		};
-	// the binarized value of x where the bracket decides it, `zero` and a queued position where it does not
-	// (the masks of the element just counted say where it stands: the bracket's ends are pivots of the pass; only an
-	//  element that is not finite is compared again -- an infinity lies beyond an end, a NaN is `zero`)
-	auto settle = [&] (double x, size_t e, bool exists)
+	// the binarized value of x where the bracket decides it, `zero` and a queued position where it does not.  The masks of
+	// the element just counted say where every lane stands (the bracket's ends are pivots of the pass): the value written is
+	// a select on the "above the high end" mask itself, the undecided lanes are mask arithmetic; only a wave with an element
+	// that is not finite compares again -- an infinity lies beyond an end, a NaN is `zero`.
+	const uint32_t oneLo = (uint32_t) __double2loint (F.one),  oneHi = (uint32_t) __double2hiint (F.one);
+	const uint32_t zeroLo = (uint32_t) __double2loint (F.zero), zeroHi = (uint32_t) __double2hiint (F.zero);
+	auto by_mask = [] (uint64_t mask, uint32_t ifSet, uint32_t ifClear)     // per lane: its bit of the mask picks
 		{
-		bool isOne = (fuseGtHi >> lane) & 1;
-		bool open  = exists && !isOne && ((fuseGeLo >> lane) & 1);
-		if (fuseOdd != 0) { isOne = (x > F.vHi);  open = exists && !isOne && !(x < F.vLo) && (x == x); }
-		const uint64_t und = __ballot (open);
+		uint32_t r;
+		const uint64_t m = ((uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane ((int) (mask >> 32)) << 32)      // (wave uniform already:
+		                 | (uint32_t) __builtin_amdgcn_readfirstlane ((int) (uint32_t) mask);                      //  this only tells the compiler)
+		asm ("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(ifClear), "v"(ifSet), "s"(m));
+		return r;
+		};
+	auto settle = [&] (double x, size_t e, uint64_t exists)
+		{
+		uint64_t isOne = fuseGtHi, und = exists & ~fuseGtHi & fuseGeLo;
+		if (fuseOdd != 0)
+			{
+			const bool one = (x > F.vHi);
+			isOne = __ballot (one);
+			und = exists & __ballot (!one && !(x < F.vLo) && (x == x));
+			}
 		if (und != 0)
 			{
-			if (open) ubuf[wave][uheld + __popcll (und & ((1ULL << lane) - 1))] = (uint32_t) e;
+			if ((und >> lane) & 1) ubuf[wave][uheld + __popcll (und & ((1ULL << lane) - 1))] = (uint32_t) e;
 			uheld += (uint32_t) __popcll (und);
 			__builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");
 			__builtin_amdgcn_wave_barrier ();
 			if (uheld > PC_WAVE_BUF - 64) uflush ();
 			}
-		return isOne? F.one : F.zero;
+		return __hiloint2double ((int) by_mask (isOne, oneHi, zeroHi), (int) by_mask (isOne, oneLo, zeroLo));
 		};
 
-	for (uint32_t tile=blockIdx.x ; tile<ntiles ; tile+=step)
+	// one tile through the generic loads (a strided or unaligned source, the ragged last tile)
+	auto tile_plain = [&] (uint32_t tile)
 		{
 		double2 cur[8];
 		load (tile, cur);
@@ -304,20 +368,68 @@ void pc_partition_kernel (const double* __restrict__ v, uint32_t n, uint32_t win
 		else                                                       // (DENSE: element e of the vector is population element e)
 			{
 			const size_t base = (size_t) tile * PC_TILE;
-			const bool   full = (base + PC_TILE <= npop);
 #pragma unroll
 			for (int u=0 ; u<8 ; u++)
 				{
 				const size_t e = base + 2 * ((size_t) u*PC_THREADS + threadIdx.x);
 				count (cur[u].x);
-				const double r0 = settle (cur[u].x, e, e < npop);
+				const double r0 = settle (cur[u].x, e, __ballot (e < npop));
 				count (cur[u].y);
-				const double r1 = settle (cur[u].y, e + 1, e + 1 < npop);
-				if (full) gdsp_st2 (reinterpret_cast<double2*> (F.out + e), make_double2 (r0, r1));
-				else { if (e < npop) F.out[e] = r0;  if (e + 1 < npop) F.out[e + 1] = r1; }
+				const double r1 = settle (cur[u].y, e + 1, __ballot (e + 1 < npop));
+				if (e < npop) F.out[e] = r0;
+				if (e + 1 < npop) F.out[e + 1] = r1;
 				}
 			}
+		};
+	if (DENSE)
+		{
+		// whole tiles in two halves: while one half is counted the other half's loads (of this tile, then of the next) are in
+		// flight, so a workgroup always has 16 KiB on its way without holding more than one tile in registers (all eight
+		// loads up front and none while counting: 3-6 % slower).  Measured on the fused form, 24 chromosomes, same box
+		// (tools/exp_kernel.sh): as it stands 388 us per launch = 5.3 TB/s on the 16 B/base it moves; without the counting
+		// (load, one compare, store) 365 us, without the stores 253 us -- so it is the read + write streams, not the
+		// arithmetic, that set the pace; three halves in flight at 4 workgroups per CU 395 us; each XCD walking its own
+		// eighth of the vector 406 us; plain stores 404 us, plain loads 399 us (both are non-temporal here)
+		auto load_half = [&] (uint32_t tile, int half, double2 (&d)[4])
+			{
+			const double2* p = reinterpret_cast<const double2*> (v + (size_t) tile * PC_TILE) + threadIdx.x + half * 4 * PC_THREADS;
+#pragma unroll
+			for (int u=0 ; u<4 ; u++) d[u] = gdsp_ld2 (&p[u*PC_THREADS]);
+			};
+		auto work_half = [&] (uint32_t tile, int half, double2 (&d)[4])
+			{
+#pragma unroll
+			for (int u=0 ; u<4 ; u++)
+				{
+				if (!FUSE) { count (d[u].x);  count (d[u].y); }
+				else
+					{
+					const size_t e = (size_t) tile * PC_TILE + 2 * ((size_t) (half*4 + u) * PC_THREADS + threadIdx.x);
+					count (d[u].x);
+					const double r0 = settle (d[u].x, e, ~0ULL);
+					count (d[u].y);
+					const double r1 = settle (d[u].y, e + 1, ~0ULL);
+					gdsp_st2 (reinterpret_cast<double2*> (F.out + e), make_double2 (r0, r1));
+					}
+				}
+			};
+		const uint32_t whole = (uint32_t) (npop / PC_TILE);
+		uint32_t tile = blockIdx.x;
+		double2 A[4], B[4];
+		if (tile < whole) load_half (tile, 0, A);
+		while (tile < whole)
+			{
+			load_half (tile, 1, B);
+			work_half (tile, 0, A);
+			const uint32_t next = tile + step;
+			if (next < whole) load_half (next, 0, A);
+			work_half (tile, 1, B);
+			tile = next;
+			}
+		if ((whole < ntiles) && (whole % step == blockIdx.x)) tile_plain (whole);
 		}
+	else
+		for (uint32_t tile=blockIdx.x ; tile<ntiles ; tile+=step) tile_plain (tile);
 	if (held) flush ();
 	if (FUSE && uheld) uflush ();
 
@@ -915,6 +1027,28 @@ void pc_res_fixup_kernel (const double* __restrict__ v, double* __restrict__ out
 		}
 	}
 
+// ... for up to PC_TAB sources in one launch (blockIdx.y picks the source)
+struct PcFixTab { const double* v[PC_TAB];  double* out[PC_TAB];  const uint32_t* pos[PC_TAB];  const unsigned long long* posCount[PC_TAB];  uint32_t cap[PC_TAB]; };
+__global__ __launch_bounds__(PC_THREADS)
+void pc_res_fixup_tab_kernel (PcFixTab T, const PcResident* __restrict__ R, int which, int tiesAbove, double one, double zero)
+	{
+	if ((R->status != PC_RES_OK) || (R->N == 0) || (R->how[which] == 2)) return;
+	const double thr = R->values[which];
+	if (!((thr >= R->vLo) && (thr <= R->vHi))) return;
+	const double* __restrict__ v = T.v[blockIdx.y];
+	double* __restrict__ out = T.out[blockIdx.y];
+	const uint32_t* __restrict__ pos = T.pos[blockIdx.y];
+	const unsigned long long count = *T.posCount[blockIdx.y];
+	if (count > T.cap[blockIdx.y]) return;
+	const size_t stride = (size_t) gridDim.x * PC_THREADS;
+	for (size_t i = (size_t) blockIdx.x * PC_THREADS + threadIdx.x ; i < count ; i += stride)
+		{
+		const uint32_t e = pos[i];
+		const double   x = v[e];
+		out[e] = (tiesAbove? (x >= thr) : (x > thr))? one : zero;
+		}
+	}
+
 // ------------------------------------------------------------- host side ----
 static const int pcShift[] = { 52, 39, 26, 13, 0 };
 static const int pcBits[]  = { 12, 13, 13, 13, 13 };
@@ -1246,18 +1380,32 @@ static int pc_sample_launch (PcJob& J, uint32_t sstride)
 		{
 		GDSP_HIP_TRY (hipSetDevice (J.devices[d]));
 		size_t at = 0;
+		PcSampleTab T;
+		int    k = 0;
+		size_t most = 0;
+		auto go = [&] ()
+			{
+			if (k == 0) return;
+			const size_t   want   = (most + PC_THREADS - 1) / PC_THREADS;
+			const uint32_t blocks = (uint32_t) std::min<size_t> (std::max<size_t> (1, PC_MAX_BLOCKS / k), want);
+			if (k == 1) hipLaunchKernelGGL (pc_sample_kernel, dim3(blocks), dim3(PC_THREADS), 0, gdsp_stream (J.stream[d]),
+			                                T.v[0], T.n[0], J.window, J.lo, J.hi, sstride, T.out[0]);
+			else        hipLaunchKernelGGL (pc_sample_tab_kernel, dim3(blocks, k), dim3(PC_THREADS), 0, gdsp_stream (J.stream[d]),
+			                                T, J.window, J.lo, J.hi, sstride);
+			k = 0;  most = 0;
+			};
 		for (int i=0 ; i<J.nsrc ; i++)
 			{
 			if ((J.src[i].device != J.devices[d]) || (J.src[i].n == 0)) continue;
-			const size_t p      = ((size_t) J.src[i].n + J.window - 1) / J.window;
-			const size_t ns     = (p + sstride - 1) / sstride;
-			size_t       want   = (ns + PC_THREADS - 1) / PC_THREADS;
-			uint32_t     blocks = (uint32_t) (want > PC_MAX_BLOCKS? PC_MAX_BLOCKS : want);
-			hipLaunchKernelGGL (pc_sample_kernel, dim3(blocks), dim3(PC_THREADS), 0, gdsp_stream (J.stream[d]),
-			                    J.src[i].d_v, J.src[i].n, J.window, J.lo, J.hi, sstride, J.scratch[d]->sample + at);
-			GDSP_LAUNCH_CHECK ();
+			const size_t p  = ((size_t) J.src[i].n + J.window - 1) / J.window;
+			const size_t ns = (p + sstride - 1) / sstride;
+			T.v[k] = J.src[i].d_v;  T.n[k] = J.src[i].n;  T.out[k] = J.scratch[d]->sample + at;
+			most = std::max (most, ns);
 			at += ns;
+			if (++k == PC_TAB) { go ();  GDSP_LAUNCH_CHECK (); }
 			}
+		go ();
+		GDSP_LAUNCH_CHECK ();
 		J.sampleCount[d] = at;                                     // slots; the ones that qualified are counted below
 		}
 	return GDSP_OK;
@@ -1279,6 +1427,7 @@ static int pc_count_launch (PcJob& J, const PcPivots& P, int mUse, bool bounded,
 		for (int i=0 ; i<J.nsrc ; i++)
 			{
 			if ((J.src[i].device != J.devices[d]) || (J.src[i].n == 0)) continue;
+			hipStream_t st = gdsp_stream (J.stream[d]);
 			const size_t   p      = ((size_t) J.src[i].n + J.window - 1) / J.window;
 			const uint32_t ntiles = (uint32_t) ((p + PC_TILE - 1) / PC_TILE);
 			const uint32_t perWG  = std::max<uint32_t> (1, std::min<uint32_t> (PC_TILES_PER_WG, ntiles / PC_MIN_WGS));
@@ -1298,13 +1447,13 @@ static int pc_count_launch (PcJob& J, const PcPivots& P, int mUse, bool bounded,
 			else J.fusedSource[i] = -1;
 #define PC_LAUNCH_B(MM, BB)                                                                                                    \
 			do { if (fused) hipLaunchKernelGGL ((pc_partition_kernel<MM, BB, true, true>),  dim3(blocks), dim3(PC_THREADS), 0,    \
-			                                     gdsp_stream (J.stream[d]), J.src[i].d_v, J.src[i].n, J.window, J.lo, J.hi, P, ctr, \
+			                                     st, J.src[i].d_v, J.src[i].n, J.window, J.lo, J.hi, P, ctr, \
 			                                     J.scratch[d]->cand, (unsigned long long) J.scratch[d]->candCap, ntiles, F, RES);  \
 			     else if (dense) hipLaunchKernelGGL ((pc_partition_kernel<MM, BB, true, false>),  dim3(blocks), dim3(PC_THREADS), 0, \
-			                                     gdsp_stream (J.stream[d]), J.src[i].d_v, J.src[i].n, J.window, J.lo, J.hi, P, ctr, \
+			                                     st, J.src[i].d_v, J.src[i].n, J.window, J.lo, J.hi, P, ctr, \
 			                                     J.scratch[d]->cand, (unsigned long long) J.scratch[d]->candCap, ntiles, F, RES);  \
 			     else       hipLaunchKernelGGL ((pc_partition_kernel<MM, BB, false, false>), dim3(blocks), dim3(PC_THREADS), 0,   \
-			                                     gdsp_stream (J.stream[d]), J.src[i].d_v, J.src[i].n, J.window, J.lo, J.hi, P, ctr, \
+			                                     st, J.src[i].d_v, J.src[i].n, J.window, J.lo, J.hi, P, ctr, \
 			                                     J.scratch[d]->cand, (unsigned long long) J.scratch[d]->candCap, ntiles, F, RES); } while (0)
 #define PC_LAUNCH(MM) do { if (bounded) PC_LAUNCH_B (MM, true);  else PC_LAUNCH_B (MM, false); } while (0)
 			*padded += (uint64_t) ntiles * PC_TILE;
@@ -1375,15 +1524,31 @@ static int pc_resident (PcJob& J, const uint32_t* pThousandths, int np, uint32_t
 			}
 	// the fused binarize's open positions
 	if (J.fusedAny)
+		{
+		PcFixTab T;
+		int    k = 0;
+		size_t most = 0;
+		auto go = [&] ()
+			{
+			if (k == 0) return;
+			const uint32_t blocks = (uint32_t) std::min<size_t> (std::max<size_t> (1, 2048 / k), std::max<size_t> (1, most / 65536));
+			if (k == 1) hipLaunchKernelGGL (pc_res_fixup_kernel, dim3(blocks), dim3(PC_THREADS), 0, st, T.v[0], T.out[0], T.pos[0], T.posCount[0],
+			                                T.cap[0], R, fuseWhich, J.fuse->tiesAbove, J.fuse->one, J.fuse->zero);
+			else        hipLaunchKernelGGL (pc_res_fixup_tab_kernel, dim3(blocks, k), dim3(PC_THREADS), 0, st, T, R, fuseWhich,
+			                                J.fuse->tiesAbove, J.fuse->one, J.fuse->zero);
+			k = 0;  most = 0;
+			};
 		for (int i=0 ; i<J.nsrc ; i++)
 			{
 			if (J.fusedSource[i] < 0) continue;
-			const uint32_t blocks = (uint32_t) std::min<size_t> (512, std::max<size_t> (1, (size_t) J.src[i].n / 65536));
-			hipLaunchKernelGGL (pc_res_fixup_kernel, dim3(blocks), dim3(PC_THREADS), 0, st, J.src[i].d_v, J.fuse->d_out[i],
-			                    sc->pos + J.posOffset[i], sc->posCount + J.fusedSource[i], (uint32_t) J.posCap[i], R, fuseWhich,
-			                    J.fuse->tiesAbove, J.fuse->one, J.fuse->zero);
-			GDSP_LAUNCH_CHECK ();
+			T.v[k] = J.src[i].d_v;  T.out[k] = J.fuse->d_out[i];  T.pos[k] = sc->pos + J.posOffset[i];
+			T.posCount[k] = sc->posCount + J.fusedSource[i];  T.cap[k] = (uint32_t) J.posCap[i];
+			most = std::max<size_t> (most, J.src[i].n);
+			if (++k == PC_TAB) { go ();  GDSP_LAUNCH_CHECK (); }
 			}
+		go ();
+		GDSP_LAUNCH_CHECK ();
+		}
 
 	// ---- the one read-back of the call
 	PcResident got;
