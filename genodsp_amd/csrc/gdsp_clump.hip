@@ -14,19 +14,21 @@
 // Round 1 ran this as six whole-vector scans over f64 arrays, ~290 B of HBM traffic per base.  Here the
 // only f64 array that is materialised is R; everything else is either recomputed from v in flight or
 // lives as one BIT per base:
-//   pass 1  (read v)            per 4096-base chunk: the sum of val and the smallest / largest prefix sum
-//                               relative to the chunk's start; one small kernel then turns those into each
-//                               chunk's offset, the running minimum before it and the running maximum after it
-//   pass 2  (read v, write R)   R[t], chunk by chunk (prefix sums rebuilt in LDS, suffix maximum inside the
-//                               chunk joined with the maximum of the chunks to its right)
-//   pass 3  (read v, read R shifted by L)   P and Q rebuilt the same way; three bits per base:
+//   pass 1  (read v, write R')  per 4096-base chunk: the sum of val and the smallest / largest prefix sum relative to
+//                               the chunk's start, and R'[t] = the largest prefix sum from t to the end of the chunk, also
+//                               relative to its start (prefix sums built in LDS); one small kernel then turns the
+//                               chunk figures into each chunk's offset, the running minimum before it and the running
+//                               maximum after it.  R[t] = max (offset[chunk] + R'[t], maximum after the chunk) is formed
+//                               where it is used (rounding is monotone: the largest of offset + x is offset + the largest
+//                               x), so the pass that wrote R from a second read of v (round 2: 48 B/base) is gone
+//   pass 2  (read v, read R' shifted by L)  P and Q rebuilt the same way; three bits per base:
 //                               g[j] = good[j],  a[k] = (Q[k] <= R[k+L+1])  (the first test, for t = k+L+1),
 //                               s[k] = base k is on the right side of the threshold
 //   bits    marked[t] = a[t-L-1] | any g in [t-L, t-1];  trimming = "the last event at or before t and the
 //                               first at or after t are on-side bases of the same marked run": index-of-
 //                               last/first-set-bit scans over 64-bit words (n/64 of them)
-//   pass 4  (write v)           one / zero from the final bit
-// 48 B of HBM traffic per base plus ~1 B for the bit arrays.
+//   pass 3  (write v)           one / zero from the final bit
+// 40 B of HBM traffic per base plus ~1 B for the bit arrays.
 //
 // One definition of P serves every pass: P[k] = offset[chunk] + rel[k], rel = the chunk-relative prefix sum
 // built by chunk_prefix() (16 consecutive bases per thread, then lanes, then waves, always in that order),
@@ -104,28 +106,64 @@ __device__ __forceinline__ void cl_chunk_prefix (const double* turn, double* wav
 
 template <bool MAX> __device__ __forceinline__ double cl_pick (double a, double b) { return MAX? fmax (a, b) : fmin (a, b); }
 
-// ---- pass 1: per chunk, the total and the smallest / largest relative prefix sum
+// ---- pass 1: per chunk, the total and the smallest / largest relative prefix sum, and R' (the largest relative prefix sum
+//      from each base to the end of its chunk)
 __global__ __launch_bounds__(CL_THREADS)
 void clump_chunk_stats_kernel (const double* __restrict__ v, size_t n, double avg, int above,
-                               double* __restrict__ total, double* __restrict__ lowest, double* __restrict__ highest)
+                               double* __restrict__ total, double* __restrict__ lowest, double* __restrict__ highest,
+                               double* __restrict__ Rrel)
 	{
 	__shared__ __attribute__((aligned(16))) double turn[CL_THREADS * CL_PITCH];
 	__shared__ double waveTot[4], waveLo[4], waveHi[4];
 	const size_t k0 = (size_t) blockIdx.x * CL_CHUNK;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	cl_stage_vals (turn, v, n, k0, avg, above);
 	double rel[CL_PER];
 	cl_chunk_prefix (turn, waveTot, rel);
-	double lo = rel[0], hi = rel[0];
+	double lo = rel[0];
 #pragma unroll
-	for (int i=1 ; i<CL_PER ; i++) { lo = fmin (lo, rel[i]);  hi = fmax (hi, rel[i]); }
-	for (int off=32 ; off>0 ; off>>=1) { lo = fmin (lo, __shfl_down (lo, off, 64));  hi = fmax (hi, __shfl_down (hi, off, 64)); }
-	if ((threadIdx.x & 63) == 0) { waveLo[threadIdx.x >> 6] = lo;  waveHi[threadIdx.x >> 6] = hi; }
+	for (int i=1 ; i<CL_PER ; i++) lo = fmin (lo, rel[i]);
 	if (threadIdx.x == CL_THREADS-1) total[blockIdx.x] = rel[CL_PER-1];
-	__syncthreads ();
+	double m = -INFINITY;
+#pragma unroll
+	for (int i=CL_PER-1 ; i>=0 ; i--) { m = fmax (m, rel[i]);  rel[i] = m; }         // maximum from base i to the thread's last
+	double incl = m;                                               // ... then over the lanes to the right, the waves to the right
+	for (int d=1 ; d<64 ; d*=2)
+		{
+		const double dn = __shfl_down (incl, d, 64);
+		if (lane + d < 64) incl = fmax (dn, incl);
+		}
+	double excl = __shfl_down (incl, 1, 64);
+	if (lane == 63) excl = -INFINITY;
+	for (int off=32 ; off>0 ; off>>=1) lo = fmin (lo, __shfl_down (lo, off, 64));
+	if (lane == 0) { waveLo[wave] = lo;  waveHi[wave] = incl; }
+	__syncthreads ();                                              // (also: every read of the staged values is done)
 	if (threadIdx.x == 0)
 		{
 		lowest[blockIdx.x]  = fmin (fmin (waveLo[0], waveLo[1]), fmin (waveLo[2], waveLo[3]));
 		highest[blockIdx.x] = fmax (fmax (waveHi[0], waveHi[1]), fmax (waveHi[2], waveHi[3]));
+		}
+	double beyond = excl;
+	for (int w=3 ; w>wave ; w--) beyond = fmax (beyond, waveHi[w]);
+	double* mine = turn + threadIdx.x * CL_PITCH;
+#pragma unroll
+	for (int i=0 ; i<CL_PER ; i++) mine[i] = fmax (rel[i], beyond);
+	__syncthreads ();
+	if ((k0 + CL_CHUNK <= n) && gdsp_aligned16 (Rrel))
+		{
+		double2* dst = reinterpret_cast<double2*> (Rrel + k0);
+#pragma unroll
+		for (int u=0 ; u<CL_PER/2 ; u++)
+			{
+			const int e = 2 * (u*CL_THREADS + (int) threadIdx.x);
+			const double* src = turn + e + (e >> 4);
+			gdsp_st2 (&dst[u*CL_THREADS + threadIdx.x], make_double2 (src[0], src[1]));
+			}
+		}
+	else
+		{
+		for (int e=threadIdx.x ; e<CL_CHUNK ; e+=CL_THREADS)
+			{ if (k0 + e < n) Rrel[k0 + e] = turn[e + (e >> 4)]; }
 		}
 	}
 
@@ -236,57 +274,6 @@ void clump_chunk_scan_kernel (double* __restrict__ total, double* __restrict__ l
 		}
 	}
 
-// ---- pass 2: R[t] = max of P[t .. n-1]
-__global__ __launch_bounds__(CL_THREADS)
-void clump_suffix_max_kernel (const double* __restrict__ v, size_t n, double avg, int above,
-                              const double* __restrict__ offset, const double* __restrict__ after, double* __restrict__ R)
-	{
-	__shared__ __attribute__((aligned(16))) double turn[CL_THREADS * CL_PITCH];
-	__shared__ double waveTot[4], waveHi[4];
-	const size_t k0 = (size_t) blockIdx.x * CL_CHUNK;
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	cl_stage_vals (turn, v, n, k0, avg, above);
-	double P[CL_PER];
-	cl_chunk_prefix (turn, waveTot, P);
-	const double off = offset[blockIdx.x];
-	double m = -INFINITY;
-#pragma unroll
-	for (int i=CL_PER-1 ; i>=0 ; i--) { m = fmax (m, off + P[i]);  P[i] = m; }       // maximum from base i to the thread's last
-	double incl = m;                                               // ... then over the lanes to the right, the waves to the right
-	for (int d=1 ; d<64 ; d*=2)
-		{
-		const double dn = __shfl_down (incl, d, 64);
-		if (lane + d < 64) incl = fmax (dn, incl);
-		}
-	double excl = __shfl_down (incl, 1, 64);
-	if (lane == 63) excl = -INFINITY;
-	if (lane == 0) waveHi[wave] = incl;
-	__syncthreads ();                                              // (also: every read of the staged values is done)
-	double beyond = after[blockIdx.x];
-	for (int w=3 ; w>wave ; w--) beyond = fmax (beyond, waveHi[w]);
-	beyond = fmax (beyond, excl);
-	double* mine = turn + threadIdx.x * CL_PITCH;
-#pragma unroll
-	for (int i=0 ; i<CL_PER ; i++) mine[i] = fmax (P[i], beyond);
-	__syncthreads ();
-	if ((k0 + CL_CHUNK <= n) && gdsp_aligned16 (R))
-		{
-		double2* dst = reinterpret_cast<double2*> (R + k0);
-#pragma unroll
-		for (int u=0 ; u<CL_PER/2 ; u++)
-			{
-			const int e = 2 * (u*CL_THREADS + (int) threadIdx.x);
-			const double* src = turn + e + (e >> 4);
-			gdsp_st2 (&dst[u*CL_THREADS + threadIdx.x], make_double2 (src[0], src[1]));
-			}
-		}
-	else
-		{
-		for (int e=threadIdx.x ; e<CL_CHUNK ; e+=CL_THREADS)
-			{ if (k0 + e < n) R[k0 + e] = turn[e + (e >> 4)]; }
-		}
-	}
-
 // 16 flags of a thread (bit i = base 16p+i) -> 64-bit words of four neighbouring lanes; lanes with p%4 == 0 hold them
 __device__ __forceinline__ unsigned long long cl_pack (uint32_t bits16)
 	{
@@ -296,12 +283,13 @@ __device__ __forceinline__ unsigned long long cl_pack (uint32_t bits16)
 	return w;
 	}
 
-// ---- pass 3: the three flags of every base.  R[k0+L ..] is fetched into registers before anything else and goes
+// ---- pass 2: the three flags of every base.  R'[k0+L ..] is fetched into registers before anything else and goes
 //      through the LDS image once the staged values have been consumed (35 KiB of LDS: four workgroups per CU)
 #define CL_AHEAD ((CL_CHUNK / 2 + 2 + CL_THREADS - 1) / CL_THREADS)      // 16-byte words of R per thread: 9
 __global__ __launch_bounds__(CL_THREADS)
 void clump_flags_kernel (const double* __restrict__ v, size_t n, double avg, int above, uint64_t L,
-                         const double* __restrict__ offset, const double* __restrict__ before, const double* __restrict__ R,
+                         const double* __restrict__ offset, const double* __restrict__ before, const double* __restrict__ after,
+                         const double* __restrict__ R, uint32_t nchunks,
                          unsigned long long* __restrict__ gBits, unsigned long long* __restrict__ aBits,
                          unsigned long long* __restrict__ sBits, size_t nwords)
 	{
@@ -353,6 +341,14 @@ void clump_flags_kernel (const double* __restrict__ v, size_t n, double avg, int
 	for (int w=0 ; w<wave ; w++) sofar = fmin (sofar, waveLo[w]);
 	sofar = fmin (sofar, excl);
 
+	// R = max (offset + R', maximum after the chunk), with the figures of the chunk each staged element lies in: two
+	// chunks, three when k0+L falls on a chunk's last bases and the +1 / +2 look into the one after
+	const uint32_t c1 = (uint32_t) (rBase / CL_CHUNK);
+	const int      eb1 = (int) ((uint64_t) (c1 + 1) * CL_CHUNK - rBase), eb2 = eb1 + CL_CHUNK;     // first staged element of chunks c1+1, c1+2
+	const double   off1 = (c1     < nchunks)? offset[c1]     : 0.0, aft1 = (c1     < nchunks)? after[c1]     : -INFINITY;
+	const double   off2 = (c1 + 1 < nchunks)? offset[c1 + 1] : 0.0, aft2 = (c1 + 1 < nchunks)? after[c1 + 1] : -INFINITY;
+	const double   off3 = (c1 + 2 < nchunks)? offset[c1 + 2] : 0.0, aft3 = (c1 + 2 < nchunks)? after[c1 + 2] : -INFINITY;
+#define CL_WHOLE(e, x) fmax ((((e) < eb1)? off1 : (((e) < eb2)? off2 : off3)) + (x), ((e) < eb1)? aft1 : (((e) < eb2)? aft2 : aft3))
 	if (rFast)
 		{
 #pragma unroll
@@ -360,14 +356,15 @@ void clump_flags_kernel (const double* __restrict__ v, size_t n, double avg, int
 			{
 			const int q = u*CL_THREADS + (int) threadIdx.x;
 			if (q < CL_CHUNK/2 + 2)
-				{ const int e = 2*q;  turn[e + (e >> 4)] = ahead[u].x;  turn[(e+1) + ((e+1) >> 4)] = ahead[u].y; }
+				{ const int e = 2*q;  turn[e + (e >> 4)] = CL_WHOLE (e, ahead[u].x);  turn[(e+1) + ((e+1) >> 4)] = CL_WHOLE (e + 1, ahead[u].y); }
 			}
 		}
 	else
 		{
 		for (int e=threadIdx.x ; e<CL_CHUNK + 4 ; e+=CL_THREADS)
-			turn[e + (e >> 4)] = (rBase + e < n)? R[rBase + e] : 0.0;   // (never compared: the index tests below come first)
+			turn[e + (e >> 4)] = (rBase + e < n)? CL_WHOLE (e, R[rBase + e]) : 0.0;   // (never compared: the index tests below come first)
 		}
+#undef CL_WHOLE
 	__syncthreads ();
 
 	uint32_t g = 0, a = 0;
@@ -500,7 +497,8 @@ __device__ __forceinline__ unsigned long long cb_window (const unsigned long lon
 __global__ __launch_bounds__(CB_THREADS)
 void clump_mark_kernel (const unsigned long long* __restrict__ gBits, const unsigned long long* __restrict__ aBits,
                         const unsigned long long* __restrict__ sBits, const long long* __restrict__ lastGBefore,
-                        const double* __restrict__ R, size_t n, size_t nwords, uint64_t L,
+                        const double* __restrict__ R, const double* __restrict__ offset, const double* __restrict__ after,
+                        size_t n, size_t nwords, uint64_t L,
                         unsigned long long* __restrict__ mBits, unsigned long long* __restrict__ uBits,
                         unsigned long long* __restrict__ oBits)
 	{
@@ -512,8 +510,9 @@ void clump_mark_kernel (const unsigned long long* __restrict__ gBits, const unsi
 	long long last = cb_block_exclusive<true, false> (cb_last_in (g, base), part);
 	last = max (last, lastGBefore[blockIdx.x]);
 	if (w >= nwords) return;
-	const bool gm1 = (L >= 1) && (L - 1 < n) && (0.0 <= R[L - 1]);           // good[-1]: P[-1] = 0 against R[L-1]
-	const bool am1 = (L < n) && (0.0 <= R[L]);                                // first test at t = L: Q = P[-1] = 0
+	auto whole = [&] (uint64_t i) { const uint64_t c = i / CL_CHUNK;  return fmax (offset[c] + R[i], after[c]); };   // R from R'
+	const bool gm1 = (L >= 1) && (L - 1 < n) && (0.0 <= whole (L - 1));      // good[-1]: P[-1] = 0 against R[L-1]
+	const bool am1 = (L < n) && (0.0 <= whole (L));                           // first test at t = L: Q = P[-1] = 0
 	unsigned long long marked = cb_window (aBits, nwords, base - (long long) L - 1);
 	if ((base <= (long long) L) && ((long long) L < base + 64) && am1) marked |= 1ull << (L - base);
 	for (int b=0 ; b<64 ; b++)
@@ -625,14 +624,13 @@ int gdsp_clump (double* d_v, uint32_t n, double average, uint32_t minLength, int
 	long long* lastO  = firstU + nwblocks + 2;
 	long long* firstO = lastO + nwblocks + 2;
 
-	hipLaunchKernelGGL (clump_chunk_stats_kernel, dim3(nchunks), dim3(CL_THREADS), 0, s, d_v, N, average, above, offset, lowest, highest);
+	hipLaunchKernelGGL (clump_chunk_stats_kernel, dim3(nchunks), dim3(CL_THREADS), 0, s, d_v, N, average, above, offset, lowest, highest, R);
 	hipLaunchKernelGGL (clump_chunk_scan_kernel,  dim3(1), dim3(CS_THREADS), 0, s, offset, lowest, highest, nchunks);
-	hipLaunchKernelGGL (clump_suffix_max_kernel,  dim3(nchunks), dim3(CL_THREADS), 0, s, d_v, N, average, above, offset, highest, R);
-	hipLaunchKernelGGL (clump_flags_kernel,       dim3(nchunks), dim3(CL_THREADS), 0, s, d_v, N, average, above, L, offset, lowest, R,
-	                    gBits, aBits, sBits, nwords);
+	hipLaunchKernelGGL (clump_flags_kernel,       dim3(nchunks), dim3(CL_THREADS), 0, s, d_v, N, average, above, L, offset, lowest, highest, R,
+	                    nchunks, gBits, aBits, sBits, nwords);
 	hipLaunchKernelGGL (clump_bits_extent_kernel, dim3(nwblocks), dim3(CB_THREADS), 0, s, gBits, nwords, lastG, (long long*) NULL);
 	hipLaunchKernelGGL (clump_bits_scan_kernel,   dim3(1), dim3(1024), 0, s, lastG, (long long*) NULL, nwblocks);
-	hipLaunchKernelGGL (clump_mark_kernel,        dim3(nwblocks), dim3(CB_THREADS), 0, s, gBits, aBits, sBits, lastG, R, N, nwords, L,
+	hipLaunchKernelGGL (clump_mark_kernel,        dim3(nwblocks), dim3(CB_THREADS), 0, s, gBits, aBits, sBits, lastG, R, offset, highest, N, nwords, L,
 	                    mBits, uBits, oBits);
 	hipLaunchKernelGGL (clump_bits_extent_kernel, dim3(nwblocks), dim3(CB_THREADS), 0, s, uBits, nwords, lastU, firstU);
 	hipLaunchKernelGGL (clump_bits_extent_kernel, dim3(nwblocks), dim3(CB_THREADS), 0, s, oBits, nwords, lastO, firstO);

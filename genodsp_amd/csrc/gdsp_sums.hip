@@ -697,7 +697,16 @@ void cumsum_apply_kernel (double* __restrict__ v, uint32_t n, uint32_t nchunks, 
 // value and flag, waited for in ticket order).  Bit-identical results, but each hop through an agent-scope atomic
 // store and its polling loads costs microseconds on this part: a workgroup per 4096-base chunk with a binary tree took
 // 1.41 ms per 249 Mbp, a wave per 1024-base chunk with a 32-ary tree 2.83 ms, against 1.05 ms for the three launches
-// below; with the waits removed (wrong sums) the first form ran in 0.81 ms, so even free waits would buy little.)
+// below; with the waits removed (wrong sums) the first form ran in 0.81 ms, so even free waits would buy little.
+// Round 3 tried it once more with a flat scheme -- groups of 512 chunks, subgroups of 32, a chunk polling one word per
+// lane (its subgroup's earlier totals, its group's earlier subgroup sums, the running sum in front of its group from one
+// of 64 copies) so that a chunk waits for ONE hop of the chain over groups: bit-identical again, 2.49 ms.  What it
+// showed on the way: handing chunks out through one ticket counter costs 4.3 ms by itself (60 k atomic adds with return
+// on one word queue at its memory channel, 40-70 ns each); 31 M uncached 8-byte polls cost as much (the memory side
+// serves ~5 requests per ns, whatever their size); and with both gone a hop still takes ~20 us, because every small
+// request of the chain queues behind the streaming traffic of 1024 workgroups while LDS capacity caps what is in
+// flight at 32 MiB -- two groups.  An order-free sum (the chunk totals kept exactly, in a wide fixed-point word, so
+// that any look-back grouping rounds to the same double) is the form that could still work; not built.)
 
 // one flag per window for the two passes above, kept per (device, stream): calls on one stream follow one another,
 // calls on different streams must not share them
