@@ -556,10 +556,11 @@ def rccl_version():
 
 def percentile_stats():
     """What the last percentile() did: route (SELECT_RADIX / SELECT_BRACKET), population, subsample size,
-    candidates kept on this rank, percentiles that fell back, histogram passes over the population."""
+    candidates kept on this rank, percentiles that fell back, histogram passes over the population, whether a fused
+    binarize was settled in the counting pass, whether the call was decided on the device (one read-back)."""
     out = (C.c_uint64 * 8)()
     lib().gdsp_percentiles_stats(out)
-    keys = ("route", "population", "sample", "candidates", "fallbacks", "population_passes", "binarize_in_one_pass")
+    keys = ("route", "population", "sample", "candidates", "fallbacks", "population_passes", "binarize_in_one_pass", "resident")
     return dict(zip(keys, [int(x) for x in out]))
 
 

@@ -649,6 +649,14 @@ __device__ __forceinline__ uint32_t pc_res_rank (uint64_t N, uint32_t pThousandt
 // over 243 k keys); the workgroup whose ticket is last reads it (32 bytes per thread), picks and clears it.  Measured
 // against it: every workgroup writing its histogram whole to a slab of its own with write-through stores and the last
 // one adding the slabs up -- 3 us to write, but one CU reads the 0.5-1 MB of slabs at 40-65 GB/s: 13-22 us, slower.
+// Where the time of a pass goes (stamps: -DPC_RES_TIMING prints them per digit): 5-10 us counting, 3 us adding, 2 us
+// ticket, 9 us for the last workgroup -- each phase several times its instruction count at 2.4 GHz; seven such passes are
+// most of what a 249 Mbp call spends outside its counting pass.  A form with fewer dependent steps, not built: select
+// in ONE workgroup's LDS among a strided 16 k of the keys (two ranks, 11-bit digits) for a bracket of the wanted ranks,
+// then ONE multi-workgroup pass that counts the keys below / on / between a grid of 64 values across that bracket (a
+// few counters per workgroup, no histogram to merge) and keeps each cell's smallest and largest key: the subsample's
+// pivots are then the extreme keys of the cells the ranks fall in (any value brackets), the candidates' answer an
+// LDS select over the one cell that holds the rank.
 __global__ __launch_bounds__(PC_RES_THREADS)
 void pc_res_digit_kernel (const uint64_t* __restrict__ keys, const unsigned long long* __restrict__ countPtr, unsigned long long countCap,
                           int stage, int digit, int which, uint32_t pThousandths, PcResident* __restrict__ R, PcResHist* __restrict__ H)

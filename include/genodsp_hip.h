@@ -309,7 +309,8 @@ int gdsp_percentiles_binarize (const gdsp_select_source* sources, int nsources, 
 /* what the last gdsp_percentiles call of this process did: [0] route taken (GDSP_SELECT_RADIX or
  * _BRACKET), [1] population, [2] subsample size, [3] candidates kept on this rank, [4] percentiles
  * that fell back to the radix route, [5] histogram passes over the population, [6] 1 when a fused binarize
- * was settled in the counting pass for every source, [7] unused */
+ * was settled in the counting pass for every source, [7] 1 when the call was decided on the device with one read-back
+ * (one device, nothing to reduce with; GDSP_PERCENTILE_RESIDENT_OFF forbids it) */
 void gdsp_percentiles_stats (uint64_t out[8]);
 
 /* ---- genodsp.c read_intervals / add.c / multiply.c ------------------------------ */
