@@ -207,70 +207,102 @@ __device__ __forceinline__ double cs_block_exclusive (double x, double carry, do
 	return cs_op<OP> (before, excl);
 	}
 
+// The scan over the chunks in three launches of one workgroup per tile of 8192 chunks (one workgroup walking the tiles
+// one after the other, forwards and back, took 195 us for the 60 k chunks of a 249 Mbp chromosome: sixteen dependent
+// steps of loads, two block scans and stores on a single CU):
+//   A  the sum of each tile's totals
+//   B  offsets (the tiles before summed in order, then the tile's own exclusive scan), the smallest / largest P of every
+//      chunk, and each tile's smallest / largest of those
+//   C  the running minimum before every chunk (P[-1] = 0 included) and the running maximum after it
 __global__ __launch_bounds__(CS_THREADS)
-void clump_chunk_scan_kernel (double* __restrict__ total, double* __restrict__ lowest, double* __restrict__ highest, uint32_t nchunks)
+void clump_scan_sums_kernel (const double* __restrict__ total, uint32_t nchunks, double* __restrict__ tileSum)
 	{
 	__shared__ double part[CS_THREADS/64];
-	double carrySum = 0.0, carryMin = 0.0;                         // P[-1] = 0 is part of the running minimum
-	for (uint32_t t0=0 ; t0<nchunks ; t0+=CS_TILE)
+	const uint32_t c0 = blockIdx.x * CS_TILE + threadIdx.x * CS_PER;
+	double sum = 0.0;
+#pragma unroll
+	for (int i=0 ; i<CS_PER ; i++) sum += (c0 + i < nchunks)? total[c0 + i] : 0.0;
+	double all;
+	(void) cs_block_exclusive<0, false> (sum, 0.0, part, &all);
+	if (threadIdx.x == 0) tileSum[blockIdx.x] = all;
+	}
+
+__global__ __launch_bounds__(CS_THREADS)
+void clump_scan_offsets_kernel (double* __restrict__ total, double* __restrict__ lowest, double* __restrict__ highest, uint32_t nchunks,
+                                const double* __restrict__ tileSum, double* __restrict__ tileMin, double* __restrict__ tileMax)
+	{
+	__shared__ double part[CS_THREADS/64];
+	double carry = 0.0;
+	for (uint32_t t=0 ; t<blockIdx.x ; t++) carry += tileSum[t];    // (uniform: at most a few hundred tiles)
+	const uint32_t c0 = blockIdx.x * CS_TILE + threadIdx.x * CS_PER;
+	double T[CS_PER], lo[CS_PER], hi[CS_PER];
+#pragma unroll
+	for (int i=0 ; i<CS_PER ; i++)
 		{
-		const uint32_t c0 = t0 + threadIdx.x * CS_PER;
-		double T[CS_PER], lo[CS_PER], hi[CS_PER];
-#pragma unroll
-		for (int i=0 ; i<CS_PER ; i++)
-			{
-			const bool in = (c0 + i < nchunks);
-			T[i]  = in? total[c0 + i]   : 0.0;
-			lo[i] = in? lowest[c0 + i]  : INFINITY;
-			hi[i] = in? highest[c0 + i] : -INFINITY;
-			}
-		double sum = 0.0;
-#pragma unroll
-		for (int i=0 ; i<CS_PER ; i++) sum += T[i];
-		double run = cs_block_exclusive<0, false> (sum, carrySum, part, &carrySum);
-		double m = INFINITY;
-#pragma unroll
-		for (int i=0 ; i<CS_PER ; i++)
-			{
-			const double t = T[i];
-			T[i]  = run;                                           // offset of the chunk
-			lo[i] = run + lo[i];                                   // smallest P in it
-			hi[i] = run + hi[i];                                   // largest P in it
-			run  += t;
-			m = fmin (m, lo[i]);
-			}
-		double before = cs_block_exclusive<1, false> (m, carryMin, part, &carryMin);
-#pragma unroll
-		for (int i=0 ; i<CS_PER ; i++)
-			{
-			if (c0 + i >= nchunks) break;
-			total[c0 + i]   = T[i];
-			highest[c0 + i] = hi[i];
-			const double t = lo[i];
-			lowest[c0 + i] = before;
-			before = fmin (before, t);
-			}
+		const bool in = (c0 + i < nchunks);
+		T[i]  = in? total[c0 + i]   : 0.0;
+		lo[i] = in? lowest[c0 + i]  : INFINITY;
+		hi[i] = in? highest[c0 + i] : -INFINITY;
 		}
-	__syncthreads ();
-	__threadfence_block ();
-	double carryMax = -INFINITY;
-	const uint32_t ntiles = (nchunks + CS_TILE - 1) / CS_TILE;
-	for (uint32_t tile=ntiles ; tile>0 ; tile--)
+	double sum = 0.0;
+#pragma unroll
+	for (int i=0 ; i<CS_PER ; i++) sum += T[i];
+	double all;
+	double run = cs_block_exclusive<0, false> (sum, carry, part, &all);
+	double mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+	for (int i=0 ; i<CS_PER ; i++)
 		{
-		const uint32_t c0 = (tile - 1) * CS_TILE + threadIdx.x * CS_PER;
-		double hi[CS_PER];
-		double m = -INFINITY;
-#pragma unroll
-		for (int i=0 ; i<CS_PER ; i++) { hi[i] = (c0 + i < nchunks)? highest[c0 + i] : -INFINITY;  m = fmax (m, hi[i]); }
-		double after = cs_block_exclusive<2, true> (m, carryMax, part, &carryMax);
-#pragma unroll
-		for (int i=CS_PER-1 ; i>=0 ; i--)
+		if (c0 + i < nchunks)
 			{
-			if (c0 + i >= nchunks) continue;
-			const double t = hi[i];
-			highest[c0 + i] = after;
-			after = fmax (after, t);
+			total[c0 + i]   = run;                                 // offset of the chunk
+			lo[i] = run + lo[i];  lowest[c0 + i]  = lo[i];          // smallest P in it
+			hi[i] = run + hi[i];  highest[c0 + i] = hi[i];          // largest P in it
+			mn = fmin (mn, lo[i]);  mx = fmax (mx, hi[i]);
 			}
+		run += T[i];
+		}
+	double allMin, allMax;
+	(void) cs_block_exclusive<1, false> (mn, INFINITY, part, &allMin);
+	(void) cs_block_exclusive<2, false> (mx, -INFINITY, part, &allMax);
+	if (threadIdx.x == 0) { tileMin[blockIdx.x] = allMin;  tileMax[blockIdx.x] = allMax; }
+	}
+
+__global__ __launch_bounds__(CS_THREADS)
+void clump_scan_extremes_kernel (double* __restrict__ lowest, double* __restrict__ highest, uint32_t nchunks, uint32_t ntiles,
+                                 const double* __restrict__ tileMin, const double* __restrict__ tileMax)
+	{
+	__shared__ double part[CS_THREADS/64];
+	double carryMin = 0.0, carryMax = -INFINITY;                   // P[-1] = 0 is part of the running minimum
+	for (uint32_t t=0 ; t<blockIdx.x ; t++) carryMin = fmin (carryMin, tileMin[t]);
+	for (uint32_t t=blockIdx.x+1 ; t<ntiles ; t++) carryMax = fmax (carryMax, tileMax[t]);
+	const uint32_t c0 = blockIdx.x * CS_TILE + threadIdx.x * CS_PER;
+	double lo[CS_PER], hi[CS_PER];
+	double mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+	for (int i=0 ; i<CS_PER ; i++)
+		{
+		const bool in = (c0 + i < nchunks);
+		lo[i] = in? lowest[c0 + i]  : INFINITY;
+		hi[i] = in? highest[c0 + i] : -INFINITY;
+		mn = fmin (mn, lo[i]);  mx = fmax (mx, hi[i]);
+		}
+	double unused;
+	double before = cs_block_exclusive<1, false> (mn, carryMin, part, &unused);
+	double after  = cs_block_exclusive<2, true>  (mx, carryMax, part, &unused);
+#pragma unroll
+	for (int i=0 ; i<CS_PER ; i++)
+		{
+		if (c0 + i >= nchunks) break;
+		lowest[c0 + i] = before;
+		before = fmin (before, lo[i]);
+		}
+#pragma unroll
+	for (int i=CS_PER-1 ; i>=0 ; i--)
+		{
+		if (c0 + i >= nchunks) continue;
+		highest[c0 + i] = after;
+		after = fmax (after, hi[i]);
 		}
 	}
 
@@ -444,40 +476,40 @@ void clump_bits_extent_kernel (const unsigned long long* __restrict__ B, size_t 
 	if (threadIdx.x == 0) blockFirst[blockIdx.x] = min (min (part[0], part[1]), min (part[2], part[3]));
 	}
 
-// one workgroup: blockLast -> last set bit before each workgroup's words; blockFirst (if given) -> first after them
+// one workgroup: blockLast -> last set bit before each workgroup's words; blockFirst (if given) -> first after them.
+// Thread p takes `per` consecutive entries; across the 1024 threads the scans are wave shuffles plus one pass over the
+// sixteen waves' results (the log-step scan through LDS this kernel began with, twenty barriers per direction, took 42 us
+// for the 15 k entries of a 249 Mbp chromosome, three times per clump).
 __global__ __launch_bounds__(1024)
 void clump_bits_scan_kernel (long long* __restrict__ blockLast, long long* __restrict__ blockFirst, uint32_t nblocks)
 	{
-	__shared__ long long a[1024];
+	__shared__ long long part[16];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const uint32_t per = (nblocks + 1023) / 1024;
 	const uint32_t lo = min (threadIdx.x * per, nblocks), hi = min (lo + per, nblocks);
 	long long m = -1;
 	for (uint32_t b=lo ; b<hi ; b++) m = max (m, blockLast[b]);
-	a[threadIdx.x] = m;
+	long long incl = m;
+	for (int d=1 ; d<64 ; d*=2) { const long long o = __shfl_up (incl, d, 64);  if (lane >= d) incl = max (incl, o); }
+	long long excl = __shfl_up (incl, 1, 64);
+	if (lane == 0) excl = -1;
+	if (lane == 63) part[wave] = incl;
 	__syncthreads ();
-	for (int d=1 ; d<1024 ; d*=2)
-		{
-		const long long up = ((int) threadIdx.x >= d)? a[threadIdx.x - d] : -1;
-		__syncthreads ();
-		a[threadIdx.x] = max (up, a[threadIdx.x]);
-		__syncthreads ();
-		}
-	m = (threadIdx.x > 0)? a[threadIdx.x - 1] : -1;
+	for (int w=0 ; w<wave ; w++) excl = max (excl, part[w]);
+	m = excl;
 	for (uint32_t b=lo ; b<hi ; b++) { const long long t = blockLast[b];  blockLast[b] = m;  m = max (m, t); }
 	if (blockFirst == NULL) return;
 	__syncthreads ();
 	long long f = NOBIT;
 	for (uint32_t b=lo ; b<hi ; b++) f = min (f, blockFirst[b]);
-	a[threadIdx.x] = f;
+	incl = f;
+	for (int d=1 ; d<64 ; d*=2) { const long long o = __shfl_down (incl, d, 64);  if (lane + d < 64) incl = min (incl, o); }
+	excl = __shfl_down (incl, 1, 64);
+	if (lane == 63) excl = NOBIT;
+	if (lane == 0) part[wave] = incl;
 	__syncthreads ();
-	for (int d=1 ; d<1024 ; d*=2)
-		{
-		const long long dn = ((int) threadIdx.x + d < 1024)? a[threadIdx.x + d] : NOBIT;
-		__syncthreads ();
-		a[threadIdx.x] = min (dn, a[threadIdx.x]);
-		__syncthreads ();
-		}
-	f = (threadIdx.x < 1023)? a[threadIdx.x + 1] : NOBIT;
+	for (int w=wave+1 ; w<16 ; w++) excl = min (excl, part[w]);
+	f = excl;
 	for (uint32_t b=hi ; b>lo ; b--) { const long long t = blockFirst[b-1];  blockFirst[b-1] = f;  f = min (f, t); }
 	}
 
@@ -515,13 +547,24 @@ void clump_mark_kernel (const unsigned long long* __restrict__ gBits, const unsi
 	const bool am1 = (L < n) && (0.0 <= whole (L));                           // first test at t = L: Q = P[-1] = 0
 	unsigned long long marked = cb_window (aBits, nwords, base - (long long) L - 1);
 	if ((base <= (long long) L) && ((long long) L < base + 64) && am1) marked |= 1ull << (L - base);
-	for (int b=0 ; b<64 ; b++)
+	if (L >= 64)
 		{
-		const long long t = base + b;
-		// `last` = last j <= t-1 with good[j]
-		if (((last >= 0) && (last >= t - (long long) L)) || (gm1 && (t <= (long long) L - 1))) marked |= 1ull << b;
-		if ((g >> b) & 1) last = t;
+		// closed form: a good base inside the word is less than L behind every later base of the word; before the word's
+		// first good base what counts is the last good base in front of the word
+		auto upto = [] (long long q) { return (q < 0)? 0ull : ((q >= 63)? ~0ull : ((2ull << q) - 1)); };      // bits 0..q
+		const int firstGood = (g != 0)? __builtin_ctzll (g) : 64;
+		if (firstGood < 63) marked |= ~0ull << (firstGood + 1);
+		if (last >= 0) marked |= upto (last - base + (long long) L) & upto ((firstGood < 64)? firstGood : 63);
+		if (gm1) marked |= upto ((long long) L - 1 - base);
 		}
+	else
+		for (int b=0 ; b<64 ; b++)
+			{
+			const long long t = base + b;
+			// `last` = last j <= t-1 with good[j]
+			if (((last >= 0) && (last >= t - (long long) L)) || (gm1 && (t <= (long long) L - 1))) marked |= 1ull << b;
+			if ((g >> b) & 1) last = t;
+			}
 	const long long left = (long long) n - base;                   // bases in this word
 	const unsigned long long valid = (left >= 64)? ~0ull : ((1ull << left) - 1);
 	marked &= valid;
@@ -590,7 +633,7 @@ static size_t clump_chunks (size_t n)  { return (n + CL_CHUNK - 1) / CL_CHUNK; }
 size_t gdsp_clump_work (uint32_t n)
 	{
 	const size_t N = n;
-	return ((N + 8) + 3 * (clump_chunks (N) + 2)) * sizeof(double)
+	return ((N + 8) + 3 * (clump_chunks (N) + 2) + 3 * (clump_chunks (N) / CS_TILE + 4)) * sizeof(double)
 	     + (6 * (clump_words (N) + 2)) * sizeof(unsigned long long) + (5 * (clump_wblocks (N) + 2)) * sizeof(long long) + 64;
 	}
 
@@ -612,7 +655,11 @@ int gdsp_clump (double* d_v, uint32_t n, double average, uint32_t minLength, int
 	double* offset  = R + ((N + 8) & ~(size_t) 1);
 	double* lowest  = offset + nchunks + 2;
 	double* highest = lowest + nchunks + 2;
-	unsigned long long* gBits = (unsigned long long*) (highest + nchunks + 2);
+	const uint32_t nscan = (nchunks + CS_TILE - 1) / CS_TILE;
+	double* tileSum = highest + nchunks + 2;
+	double* tileMin = tileSum + nscan + 2;
+	double* tileMax = tileMin + nscan + 2;
+	unsigned long long* gBits = (unsigned long long*) (highest + nchunks + 2 + 3 * ((size_t) nchunks / CS_TILE + 4));
 	unsigned long long* aBits = gBits + nwords + 2;
 	unsigned long long* sBits = aBits + nwords + 2;
 	unsigned long long* mBits = sBits + nwords + 2;
@@ -625,7 +672,9 @@ int gdsp_clump (double* d_v, uint32_t n, double average, uint32_t minLength, int
 	long long* firstO = lastO + nwblocks + 2;
 
 	hipLaunchKernelGGL (clump_chunk_stats_kernel, dim3(nchunks), dim3(CL_THREADS), 0, s, d_v, N, average, above, offset, lowest, highest, R);
-	hipLaunchKernelGGL (clump_chunk_scan_kernel,  dim3(1), dim3(CS_THREADS), 0, s, offset, lowest, highest, nchunks);
+	hipLaunchKernelGGL (clump_scan_sums_kernel,     dim3(nscan), dim3(CS_THREADS), 0, s, offset, nchunks, tileSum);
+	hipLaunchKernelGGL (clump_scan_offsets_kernel,  dim3(nscan), dim3(CS_THREADS), 0, s, offset, lowest, highest, nchunks, tileSum, tileMin, tileMax);
+	hipLaunchKernelGGL (clump_scan_extremes_kernel, dim3(nscan), dim3(CS_THREADS), 0, s, lowest, highest, nchunks, nscan, tileMin, tileMax);
 	hipLaunchKernelGGL (clump_flags_kernel,       dim3(nchunks), dim3(CL_THREADS), 0, s, d_v, N, average, above, L, offset, lowest, highest, R,
 	                    nchunks, gBits, aBits, sBits, nwords);
 	hipLaunchKernelGGL (clump_bits_extent_kernel, dim3(nwblocks), dim3(CB_THREADS), 0, s, gBits, nwords, lastG, (long long*) NULL);

@@ -801,7 +801,7 @@ def test_windows_beyond_one_lds_tile(n, W, gd):
 
 # ------------------------------------------------------------------- clump ----
 @pytest.mark.parametrize("n", [1, 2, 100, 4095, 4096, 4097, 100003, 5000011])
-@pytest.mark.parametrize("L", [1, 7, 100, 5000])
+@pytest.mark.parametrize("L", [1, 7, 63, 64, 100, 5000])
 def test_clump_anticlump_bit_exact(n, L, gd):
     """clump.c:494-736 by whole-vector scans; depth against a dyadic threshold keeps every running sum exact.
     n = 5000011 needs more than 1024 scan chunks (two totals per thread in the offsets pass)."""
