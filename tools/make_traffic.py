@@ -14,9 +14,9 @@ SKIP = ("synth_coverage_kernel", "__amd_rocclr", "fill", "copyBuffer")
 # bytes the operator has to move per base: in + out, or in only for the passes that only read
 ALGORITHMIC = {"pc_fixup_kernel": None, "pc_hist_chain_kernel": None, "pc_pick_kernel": None, "peaks_probe_kernel": None, "peaks_exact_kernel": None, "peaks_init_kernel": None, "fir_fixed_extrema_gated_kernel": None,
                "pc_sample_kernel": 8, "pc_partition_kernel": 8, "cumsum_totals_kernel": 8, "report_count_kernel": 8,
-               "report_write_kernel": 8, "clump_chunk_stats_kernel": 8, "clump_write_kernel": 8,
+               "report_write_kernel": 8, "clump_write_kernel": 8,        # (clump_chunk_stats_kernel reads the signal and writes R': the default 16)
                # launches over a few words per chunk, or whose traffic is not a per-base figure: bytes only
-               "clump_chunk_scan_kernel": None, "clump_bits_": None, "report_scan_kernel": None, "pc_hist_keys_kernel": None,
+               "clump_scan_": None, "clump_bits_": None, "clump_mark_kernel": None, "pc_res_": None, "pc_sample_tab_kernel": 8, "report_scan_kernel": None, "pc_hist_keys_kernel": None,
                "cumsum_offsets_kernel": None, "hf_": None, "window_sum_rows_kernel": None}
 
 lib = sys.argv[1]
@@ -44,11 +44,19 @@ for path in sorted(glob.glob(os.path.join(root, tag + "_prof_*.txt"))):
         for key, val in ALGORITHMIC.items():
             if name.startswith(key):
                 per_base = val
+        if name.startswith("pc_partition_kernel") and name.endswith("true, true>"):
+            per_base = 16                 # the fused form writes the binarized signal too
+        launch_bases = bases
+        if m.group(1).endswith("_batch") or m.group(1) == "percentile_binarize":
+            # tools/prof_op.py runs these operators over three vectors of n/2, n/3 and n/6 bases; the `_batch` kernels
+            # cover the three in one launch, the per-source kernels of percentile_binarize average a third of n per launch
+            if "tab_kernel" not in name and "batch" not in name and name.startswith("pc_"):
+                launch_bases = bases // 3
         entry = {"source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; tools/prof_any.sh)" % os.path.basename(path),
-                 "library": lib, "bases_per_launch": bases, "fetch_bytes": fetch, "write_bytes": write}
+                 "library": lib, "bases_per_launch": launch_bases, "fetch_bytes": fetch, "write_bytes": write}
         if per_base is not None:
-            entry["algorithmic_bytes"] = per_base * bases
-            entry["hbm_bytes_over_algorithmic"] = round((fetch + write) / (per_base * bases), 4)
+            entry["algorithmic_bytes"] = per_base * launch_bases
+            entry["hbm_bytes_over_algorithmic"] = round((fetch + write) / (per_base * launch_bases), 4)
         kernels[name] = entry
 note = ("HBM bytes per launch over algorithmic bytes, from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (gfx950 "
         "corrections of MI355X_MICROARCH.md applied: FETCH_SIZE doubled, KiB -> bytes); `library` = git hash of the build that was "
