@@ -389,7 +389,8 @@ void pc_partition_kernel (const double* __restrict__ v, uint32_t n, uint32_t win
 		// (tools/exp_kernel.sh): as it stands 388 us per launch = 5.3 TB/s on the 16 B/base it moves; without the counting
 		// (load, one compare, store) 365 us, without the stores 253 us -- so it is the read + write streams, not the
 		// arithmetic, that set the pace; three halves in flight at 4 workgroups per CU 395 us; each XCD walking its own
-		// eighth of the vector 406 us; plain stores 404 us, plain loads 399 us (both are non-temporal here)
+		// eighth of the vector 406 us; plain stores 404 us, plain loads 399 us (both are non-temporal here); the four
+		// stores of a half issued together behind its counting 388-390 us against 385
 		auto load_half = [&] (uint32_t tile, int half, double2 (&d)[4])
 			{
 			const double2* p = reinterpret_cast<const double2*> (v + (size_t) tile * PC_TILE) + threadIdx.x + half * 4 * PC_THREADS;
