@@ -210,7 +210,9 @@ void sliding_blocks_kernel (const double* __restrict__ in, double* __restrict__ 
 
 // -------------------------------------------------------------- window sum ----
 #define WS_TILE_MAX_W 1024               // windows up to this long go through the tiled kernel, longer ones through the rows kernel
+#ifndef WS_TILE_BASES
 #define WS_TILE_BASES 8192               // bases staged per workgroup (whole windows only)
+#endif
 
 // Tiled form: a workgroup stages K whole windows with coalesced 16-byte loads, one thread
 // then sums one window from LDS in ascending order (bit-identical to sum.c:230-249), and
