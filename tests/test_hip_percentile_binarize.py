@@ -98,3 +98,27 @@ def test_the_three_routes_of_a_one_device_call_agree(n, gd, monkeypatch):
                 assert got[0] == ref[0] and got[2] == ref[2] and bits_equal(got[1], ref[1]) and bits_equal(got[3], ref[3]), (name, pts, kw, route)
                 for a, b in zip(got[4], ref[4]):
                     assert bits_equal(a, b), (name, pts, kw, route)
+
+
+def test_resident_route_gives_way_when_it_cannot_settle_a_call(gd):
+    """What the resident route cannot settle raises its status word before anything observable is written, and the call
+    runs again the old way: a subsample too small to place pivots (an explicit sample target of 100 values), a pivot that
+    is a NaN (a signal whose top two per cent are NaNs), more percentiles than its state holds (nine)."""
+    x = cpu.synth_coverage(20240611, 5, 0, 1_500_000, 1)
+    v = gd.DeviceVector.from_numpy(x)
+    want = gd.percentile([v], [99000], strategy=gd.SELECT_RADIX)
+    got = gd.percentile([v], [99000], strategy=gd.SELECT_BRACKET, sample_target=100)
+    assert got[0] == want[0] and bits_equal(np.array(got[1]), np.array(want[1]))
+    c, vals, outs, one_pass = gd.percentile_binarize([v], [99000], strategy=gd.SELECT_BRACKET, sample_target=100)
+    assert c == want[0] and bits_equal(np.array(vals), np.array(want[1])) and bits_equal(outs[0].numpy(), cpu.binarize(x, vals[0], False, 1.0, 0.0))
+    y = x.copy()
+    y[::50] = np.nan
+    w = gd.DeviceVector.from_numpy(y)
+    want = gd.percentile([w], [99500], strategy=gd.SELECT_RADIX)
+    got = gd.percentile([w], [99500])
+    assert got[0] == want[0] and bits_equal(np.array(got[1]), np.array(want[1]))
+    nine = [10000 * k for k in range(1, 10)]
+    want = gd.percentile([v], nine, strategy=gd.SELECT_RADIX)
+    got = gd.percentile([v], nine)
+    assert gd.percentile_stats()["resident"] == 0
+    assert got[0] == want[0] and bits_equal(np.array(got[1]), np.array(want[1]))
