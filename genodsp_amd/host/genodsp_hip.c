@@ -1704,7 +1704,7 @@ static void parse_options (int _argc, char** _argv)            /* genodsp.c:284-
 		 || (strcmp (arg, "--debug=operations") == 0))
 			{ trackOperations = true;  continue; }
 		if (strcmp (arg, "--version") == 0)
-			{ fprintf (stderr, "%s (version %s)\n", programName, programVersion);  exit (EXIT_SUCCESS); }
+			{ fprintf (stderr, "%s (version %s; %s)\n", programName, programVersion, gdsp_version ());  exit (EXIT_SUCCESS); }
 		if (strcmp (arg, "--debug=input") == 0)   { dbgInput   = true;  continue; }
 		if (strcmp (arg, "--debug=pipe") == 0)    { dbgPipe    = true;  continue; }
 		if (strcmp (arg, "--debug=globals") == 0) { dbgGlobals = true;  continue; }

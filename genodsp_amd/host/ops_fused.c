@@ -118,9 +118,13 @@ int batch_apply_on_device (dspop* op, dspop* stopOp, spec** units, int nunits, i
 		u32 N;  int wantMax;  valtype fill;
 		op_local_describe (op, &N, &wantMax, &fill);
 		rc = gdsp_local_extrema_batch (items, nunits, N, wantMax, fill, st);
+		if (rc == GDSP_EINVAL) goto one_by_one;              /* neighbourhood beyond one LDS tile */
 		}
 	else if ((f == op_best_local_max_apply) || (f == op_best_local_min_apply))
+		{
 		rc = gdsp_best_extrema_batch (items, nunits, op_best_window (op), f == op_best_local_max_apply, st);
+		if (rc == GDSP_EINVAL) goto one_by_one;              /* window beyond one LDS tile */
+		}
 	else if ((f == op_dilate_apply) || (f == op_erode_apply))
 		{
 		u32 l, r;  valtype T, one, zero;
@@ -144,12 +148,7 @@ int batch_apply_on_device (dspop* op, dspop* stopOp, spec** units, int nunits, i
 			{
 			rc = (f == op_dilate_apply)? gdsp_dilate_batch (items, nunits, l, r, T, one, zero, st)
 			                           : gdsp_erode_batch  (items, nunits, l, r, T, one, zero, st);
-			if (rc == GDSP_EINVAL)                             /* reach beyond one LDS tile: the operator's own whole-vector route */
-				{
-				free (items);
-				for (int i=0 ; i<nunits ; i++) apply_to_unit (op, units[i]);
-				return 1;
-				}
+			if (rc == GDSP_EINVAL) goto one_by_one;            /* reach beyond one LDS tile */
 			}
 		}
 	else
@@ -176,4 +175,11 @@ int batch_apply_on_device (dspop* op, dspop* stopOp, spec** units, int nunits, i
 	check_gdsp (rc, op->name);
 	if (outOfPlace) { for (int i=0 ; i<nunits ; i++) flip_spec (units[i]); }
 	return consumed;
+
+	/* no tiled kernel takes this window: the operator's own apply, vector by vector, which goes on to its
+	 * whole-vector route (gdsp_*_any); nothing has been flipped, whatever a refused batch call wrote went to partners */
+one_by_one:
+	free (items);
+	for (int i=0 ; i<nunits ; i++) apply_to_unit (op, units[i]);
+	return 1;
 	}

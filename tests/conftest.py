@@ -63,3 +63,27 @@ def first_diff(a, b):
     b = np.asarray(b).view(np.uint64)
     idx = np.flatnonzero(a != b)
     return None if idx.size == 0 else int(idx[0])
+
+
+@pytest.fixture(autouse=True)
+def _forget_cli_runs():
+    """tests/cli_compare.py remembers what every run() of a test did; start each test with an empty list"""
+    import cli_compare
+    del cli_compare.RUNS[:]
+    yield
+
+
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_makereport(item, call):
+    """a failing CLI test leaves argv, environment, library id, stdin, stdout and stderr of its runs under
+    gpurun_out/artifacts/ (the directory gpurun brings back from the GPU box)"""
+    outcome = yield
+    report = outcome.get_result()
+    if report.when == "call" and report.failed:
+        try:
+            import cli_compare
+            where = cli_compare.write_artifacts(item.nodeid)
+            if where:
+                report.sections.append(("artifacts", "kept under " + where))
+        except Exception as e:                      # noqa: BLE001
+            report.sections.append(("artifacts", "could not be written: %r" % (e,)))

@@ -480,6 +480,63 @@ RUNNING_SUM_SEEDS = (1044, 1125, 1380, 1411, 1455, 1522)
 for k in RUNNING_SUM_SEEDS:
     random_cli_case(k, 1, into=seams, keep_stdout=True)
     seams[-1]["kind"] = "cli_running_sum"
+
+
+def long_window_case(k, into):
+    """windows beyond what one LDS tile of the HIP kernels holds (8190 bases for the extrema, 4001 taps for the
+    block-sum smooth, the tiled sums' 8192): the whole-vector routes (gdsp_*_any), which the driver must reach from
+    its batched and from its per-chromosome order alike.  Islands of coverage 3-14 kbp long and 3-14 kbp apart, so
+    that reaches of 8-20 kbp join some and not others; signal kept 15 000 bases away from the ends and `erode` only
+    behind a longer `dilate`, so that none of the reference's out-of-bounds reads is provoked."""
+    r = np.random.default_rng(SEED + 9000 + k)
+    lens = [int(r.integers(120000, 150000)), int(r.integers(90000, 110000))]
+    chroms_text = "".join("chr%s %d\n" % ("LM"[i], n) for i, n in enumerate(lens))
+    lines = []
+    for i, n in enumerate(lens):
+        a = 15000
+        while True:
+            z = a + int(r.integers(3000, 14000))
+            if z > n - 15600:
+                break
+            lines.append("chr%s\t%d\t%d\t1" % ("LM"[i], a, z))
+            for _ in range(int(r.integers(20, 80))):
+                b = int(r.integers(a, z - 1))
+                lines.append("chr%s\t%d\t%d\t%d" % ("LM"[i], b, min(z, b + int(r.integers(1, 900))), int(r.integers(1, 7))))
+            a = z + int(r.integers(3000, 14000))
+    stdin = "\n".join(lines[j] for j in r.permutation(len(lines))) + "\n"
+    menu = [lambda: [["bestmax", "W=%d" % int(r.choice([8193, 20001, 30000]))]],
+            lambda: [["bestmin", "W=%d" % int(r.choice([9001, 16384]))]],
+            lambda: [["localmax", "N=%d" % int(r.choice([8200, 20001]))]],
+            lambda: [["localmin", "N=12001", "--infinity=50"]],
+            lambda: [["dilate", "%d" % int(r.choice([9000, 20001]))]],
+            lambda: [["dilate", "20001"], ["erode", "%d" % int(r.choice([8200, 15001]))]],
+            lambda: [["close", "9000"]],
+            lambda: [["open", "8500", "--threshold=1"]],
+            lambda: [["smooth", "W=%d" % int(r.choice([4801, 10001]))]],
+            lambda: [["slidingsum", "W=20001"]],
+            lambda: [["sum", "W=9000"]]]
+    args = ["--precision=%d" % int(r.integers(0, 5))] + (["--uncovered:show"] if r.random() < 0.3 else [])
+    for _ in range(int(r.integers(1, 3))):
+        for op in menu[int(r.integers(0, len(menu)))]():
+            args += ["="] + op
+    name = "cli_long_window_%02d" % k
+    chrom_path = "/tmp/golden_%s.chroms" % name
+    with open(chrom_path, "w") as f:
+        f.write(chroms_text)
+    rc, out, err = ref.run_cli(["--chromosomes=" + chrom_path] + args, stdin)
+    body = out.splitlines()
+    if (rc != 0) or (len(body) < 3):                  # (stopped by the reference itself, or everything erased: says nothing)
+        return False
+    into.append({"name": name, "kind": "cli_digest", "chroms_text": chroms_text, "args": args, "files": {},
+                 "stdin": stdin, "returncode": rc, "sha256": hashlib.sha256(out.encode()).hexdigest(),
+                 "lines": len(body), "head": body[:5], "tail": body[-3:], "stderr_percentile": []})
+    return True
+
+
+k, kept = 0, 0
+while kept < 16:
+    kept += long_window_case(k, seams)
+    k += 1
 with gzip.GzipFile(os.path.join(HERE, "golden_seams.json.gz"), "wb", mtime=0) as f:
     f.write(json.dumps({"seed": SEED, "cases": seams}).encode())
 

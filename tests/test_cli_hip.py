@@ -9,6 +9,7 @@ import subprocess
 
 import pytest
 
+import cli_compare
 from conftest import ROOT, golden
 
 pytestmark = pytest.mark.gpu
@@ -34,6 +35,7 @@ def run(args, stdin_text="", chroms_text=None, tmp_path=None, files=None):
             f.write(chroms_text)
         args = ["--chromosomes=" + path] + list(args)
     p = subprocess.run([BIN] + list(args), input=stdin_text, capture_output=True, text=True, timeout=300)
+    cli_compare.remember([BIN] + list(args), None, stdin_text, p.returncode, p.stdout, p.stderr, files)
     return p.returncode, p.stdout, p.stderr
 
 
@@ -43,11 +45,19 @@ def built():
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "genodsp_amd", "host")])
 
 
+# the driver runs batchable stretches of a pipeline operator-major, one launch per operator per device; --nobatch keeps
+# the reference's order (every operator of the run on one chromosome, then the next: genodsp.c:909-921)
+ORDERS = {"batch": [], "nobatch": ["--nobatch"]}
+
+
+@pytest.mark.parametrize("order", list(ORDERS))
 @pytest.mark.parametrize("case", CLI_CASES, ids=[c["name"] for c in CLI_CASES])
-def test_cli_stdout_matches_reference(case, tmp_path):
+def test_cli_stdout_matches_reference(case, order, tmp_path):
     if case["returncode"] != 0:
         pytest.skip("reference itself failed on this input")
-    rc, out, err = run(case["args"], case["stdin"], case["chroms_text"], tmp_path, case.get("files"))
+    if order == "nobatch" and "--debug=pipe" in case["args"]:
+        pytest.skip("--debug=pipe echoes the arguments")
+    rc, out, err = run(ORDERS[order] + case["args"], case["stdin"], case["chroms_text"], tmp_path, case.get("files"))
     assert rc == 0, err
     if case["name"] in ("cli_percentile99", "cli_percentile_extremes_0_map"):
         # the reference prints its sort-scrambled signal after percentile (percentile.c:34-36);
@@ -72,20 +82,15 @@ def test_cli_stdout_matches_reference(case, tmp_path):
 DIGEST_CASES = [c for c in golden().meta["cases"] if c["kind"] == "cli_digest"]
 
 
+@pytest.mark.parametrize("order", list(ORDERS))
 @pytest.mark.parametrize("case", DIGEST_CASES, ids=[c["name"] for c in DIGEST_CASES])
-def test_cli_random_pipelines_match_the_reference_binary(case, tmp_path):
+def test_cli_random_pipelines_match_the_reference_binary(case, order, tmp_path):
     """48 random command lines (global flags, one to five random operators, shuffled valued intervals over two
     chromosomes) recorded from the reference binary as a digest of its stdout: the whole driver -- ingest,
     operators, named variables, report -- must print the same bytes."""
-    import hashlib
     assert case["returncode"] == 0
-    rc, out, err = run(case["args"], case["stdin"], case["chroms_text"], tmp_path, case.get("files"))
-    assert rc == 0, err
-    body = out.splitlines()
-    assert body[:5] == case["head"] and body[-3:] == case["tail"] and len(body) == case["lines"], (case["args"], body[:5], case["head"])
-    assert hashlib.sha256(out.encode()).hexdigest() == case["sha256"], case["args"]
-    for line in case["stderr_percentile"]:
-        assert line in err.splitlines()
+    rc, out, err = run(ORDERS[order] + case["args"], case["stdin"], case["chroms_text"], tmp_path, case.get("files"))
+    assert cli_compare.assert_matches_reference(case, rc, out, err) == "digest"
 
 
 def test_named_variable_feeds_threshold(tmp_path):
