@@ -32,6 +32,7 @@ _pf = C.POINTER(C.c_float)
 SIGNATURES = {
     "gdsp_last_error": (C.c_char_p, []),
     "gdsp_version": (C.c_char_p, []),
+    "gdsp_poison": (_int, [C.POINTER(_f64)]),
     "gdsp_device_count": (_int, [C.POINTER(_int)]),
     "gdsp_get_device": (_int, [_vp]),
     "gdsp_set_device": (_int, [_int]),

@@ -5,6 +5,7 @@
 
 #include <stdarg.h>
 #include <string.h>
+#include <stdlib.h>
 #include "gdsp_common.h"
 
 static thread_local char gdsp_error_text[512] = "";
@@ -47,12 +48,45 @@ int gdsp_get_device (int* device)
 	return GDSP_OK;
 	}
 
+// GDSP_POISON=<double|nan>: a debugging aid.  Every device allocation is filled with that value before it is handed
+// out (a fresh box hands out zeros, which hides a kernel that reads memory nobody wrote: with a poison that wins every
+// comparison -- 1e300 for the maxima, -1e300 for the minima, nan for arithmetic -- such a read changes the output).
+// The driver poisons a vector's partner after every flip as well (genodsp_hip.c: flip_vector).
+int gdsp_poison (double* value)
+	{
+	static int    known = -1;
+	static double pattern = 0;
+	if (known < 0)
+		{
+		const char* e = getenv ("GDSP_POISON");
+		known = ((e != NULL) && (e[0] != 0))? 1 : 0;
+		if (known) pattern = (strcmp (e, "nan") == 0)? __builtin_nan ("") : strtod (e, NULL);
+		}
+	if (value != NULL) *value = pattern;
+	return known;
+	}
+} // extern "C"
+
+__global__ void poison_kernel (uint64_t* __restrict__ p, size_t words, uint64_t bits)
+	{
+	for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x ; i < words ; i += (size_t) gridDim.x * blockDim.x) p[i] = bits;
+	}
+
+extern "C" {
+
 int gdsp_malloc (void** d_ptr, size_t bytes)
 	{
 	GDSP_REQUIRE (d_ptr != NULL, "d_ptr is NULL");
 	hipError_t e = hipMalloc (d_ptr, bytes? bytes : 16);
 	if (e == hipErrorOutOfMemory) { gdsp_set_error ("hipMalloc(%zu) out of memory", bytes);  return GDSP_ENOMEM; }
 	GDSP_HIP_TRY (e);
+	double pattern;
+	if (gdsp_poison (&pattern) && (bytes >= 8))
+		{
+		uint64_t bits;  memcpy (&bits, &pattern, 8);
+		hipLaunchKernelGGL (poison_kernel, dim3(1024), dim3(256), 0, 0, (uint64_t*) *d_ptr, bytes / 8, bits);
+		GDSP_HIP_TRY (hipDeviceSynchronize ());
+		}
 	return GDSP_OK;
 	}
 

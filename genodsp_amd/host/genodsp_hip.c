@@ -443,17 +443,26 @@ valtype* partner_vector (char* vName)
 	return (s == NULL)? NULL : ((xspec*) s)->partner;
 	}
 
+valtype* partner_of (spec* s) { return ((xspec*) s)->partner; }
+
+/* the output an operator wrote into the partner becomes the signal; what was the signal is nobody's data any more
+ * (GDSP_POISON: and is overwritten to prove it -- a later kernel that still reads it changes the output) */
+void flip_spec (spec* s)
+	{
+	valtype* t = s->valVector;  s->valVector = ((xspec*) s)->partner;  ((xspec*) s)->partner = t;
+	valtype poison;
+	if (gdsp_poison (&poison))
+		{
+		select_device_of (s);
+		check_gdsp (gdsp_fill (t, s->length, poison, op_stream ()), "poison the partner");
+		}
+	}
+
 void flip_vector (char* vName)
 	{
 	spec* s = vector_spec (vName);
-	if (s == NULL) return;
-	valtype* t = s->valVector;  s->valVector = ((xspec*) s)->partner;  ((xspec*) s)->partner = t;
+	if (s != NULL) flip_spec (s);
 	}
-
-valtype* partner_of (spec* s) { return ((xspec*) s)->partner; }
-
-void flip_spec (spec* s)
-	{ valtype* t = s->valVector;  s->valVector = ((xspec*) s)->partner;  ((xspec*) s)->partner = t; }
 
 valtype* get_scratch_vector (void)                        /* genodsp.c:1904-1940, on the current device */
 	{

@@ -50,12 +50,16 @@ extern "C" {
 
 const char* gdsp_last_error (void);
 const char* gdsp_version    (void);
+/* debugging aid: 1 and *value = the pattern when the environment holds GDSP_POISON=<double|nan>, else 0.  Every gdsp_malloc
+ * is then filled with it, and the driver refills a vector's partner after every flip: a kernel that reads memory nobody
+ * wrote changes the output (tests/test_cli_hip.py::test_no_operator_reads_memory_nobody_wrote). */
+int gdsp_poison (double* value);
 
 /* ---- runtime plumbing (what genodsp.c:865-878 / :1890-2037 do with calloc) ---- */
 int gdsp_device_count   (int* count);
 int gdsp_set_device     (int device);
 int gdsp_get_device     (int* device);
-int gdsp_malloc         (void** d_ptr, size_t bytes);
+int gdsp_malloc         (void** d_ptr, size_t bytes);      /* (filled with GDSP_POISON when that is set, see gdsp_poison) */
 int gdsp_free           (void* d_ptr);
 int gdsp_host_alloc     (void** h_ptr, size_t bytes);          /* pinned staging  */
 int gdsp_host_free      (void* h_ptr);

@@ -20,6 +20,7 @@ typedef struct item { const double* in;  double* out;  uint32_t n; } item;
 
 const char* gdsp_last_error (void) { return "host-only sanitizer build"; }
 const char* gdsp_version    (void) { return "host-only sanitizer build (no GPU code)"; }
+int gdsp_poison (double* value) { if (value != NULL) *value = 0;  return 0; }
 
 int gdsp_device_count (int* count) { *count = 1;  return OK; }
 int gdsp_set_device (int d) { (void) d;  return OK; }

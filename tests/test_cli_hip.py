@@ -399,3 +399,19 @@ def test_percentile_feeding_binarize_runs_in_one_read_of_the_signal(tmp_path, mo
                 got[tuple(extra)] = (out, err)
             assert got[()] == got[("--nofuse",)] == got[("--gpus=2",)], ops
             assert len(got[()][0].splitlines()) > 100 and "[binarize] using percentile" in got[()][1]
+
+
+POISONS = ["1e300", "-1e300", "nan"]
+
+
+@pytest.mark.parametrize("poison", POISONS)
+@pytest.mark.parametrize("case", DIGEST_CASES, ids=[c["name"] for c in DIGEST_CASES])
+def test_no_operator_reads_memory_nobody_wrote(case, poison, tmp_path, monkeypatch):
+    """GDSP_POISON: every device allocation is filled with the value before it is handed out and a vector's partner is
+    refilled after every flip (gdsp_runtime.hip, genodsp_hip.c: flip_spec).  A fresh box hands out zeros, which hides a
+    kernel that reads a base nobody wrote (the tail of an odd-length vector, a partner, a workspace); with a value that
+    wins every maximum (1e300), every minimum (-1e300) or spoils every sum (nan) such a read changes the output.  The
+    reference binary's digest must still be met."""
+    monkeypatch.setenv("GDSP_POISON", poison)
+    rc, out, err = run(case["args"], case["stdin"], case["chroms_text"], tmp_path, case.get("files"))
+    assert cli_compare.assert_matches_reference(case, rc, out, err) == "digest"
