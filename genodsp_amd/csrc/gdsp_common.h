@@ -52,6 +52,10 @@ void gdsp_morph_blocks (const double* d_in, double* d_out, uint32_t n, uint32_t 
 bool gdsp_morph_blocks_batch (const gdsp_batch_item* items, int nitems, uint32_t left, uint32_t right, int erode,
                               double T, double one, double zero, void* stream);      // false: some vector needs another kernel
 
+// gdsp_fir_slide.hip: `smooth W=101` in the reference's arithmetic with every product computed once (sliding accumulators)
+bool gdsp_fir_slide_wanted (uint64_t bases);
+int  gdsp_fir_slide_batch (const gdsp_batch_item* items, int nitems, const double* h_taps, void* stream);
+
 static inline hipStream_t gdsp_stream (void* s) { return (hipStream_t) s; }
 
 __host__ __device__ static inline bool gdsp_aligned16 (const void* p) { return (((uintptr_t) p) & 15) == 0; }

@@ -248,15 +248,26 @@ void fir_fixed_extrema_batch_kernel (GdspBatch B, FirTaps<W> taps, int h, double
 
 // the same over a table of vectors, gated (gdsp_peaks.hip): a block works only when its vector takes the direct route --
 // the probe of the filtered route chose it, or the filter's queue overflowed; otherwise it leaves at once
+// A block answers for FIR_GATED_TILES consecutive tiles of its vector (the table B counts such groups): on the filtered
+// route every block of this launch leaves at once, and leaving costs what dispatching it costs -- 1.35 M single-tile
+// blocks per genome were 0.66 ms of nothing; groups of sixteen are 84 k blocks.
+#define FIR_GATED_TILES 16
 template <int W, int R, bool FMA, bool MAX>
 __global__ __launch_bounds__(FIR_THREADS)
 void fir_fixed_extrema_gated_kernel (GdspBatch B, const GdspPeaksCtl* __restrict__ ctl, FirTaps<W> taps, int h, double fill)
 	{
 	const double* in;  double* out;  uint32_t n, v;
-	const uint32_t tile = gdsp_batch_tile (B, in, out, n, &v);
+	const uint32_t group = gdsp_batch_tile (B, in, out, n, &v);
 	const GdspPeaksCtl c = ctl[v];
 	if (!gdsp_peaks_takes_direct (c) && (c.overflow == 0)) return;
-	fir_fixed_extrema_tile<W, R, FMA, MAX> (in, out, n, tile, taps, h, fill);
+	const uint32_t stride = FIR_THREADS * R - 2 * (uint32_t) h;
+	for (uint32_t k=0 ; k<FIR_GATED_TILES ; k++)
+		{
+		const uint32_t tile = group * FIR_GATED_TILES + k;
+		if ((uint64_t) tile * stride >= n) break;
+		if (k != 0) __syncthreads ();                              // (the previous tile's last reads of the LDS image)
+		fir_fixed_extrema_tile<W, R, FMA, MAX> (in, out, n, tile, taps, h, fill);
+		}
 	}
 
 // --------------------------------------------------------- run-time W kernel ----
@@ -414,6 +425,11 @@ int gdsp_fir_apply (const gdsp_fir_plan* plan, const double* d_in, double* d_out
 	const uint32_t ntiles = (uint32_t) (((uint64_t) n + T - 1) / T);
 	hipStream_t    s = gdsp_stream (stream);
 
+	if ((plan->W == 101) && (mode == GDSP_FIR_EXACT) && gdsp_fir_slide_wanted (n))
+		{
+		const gdsp_batch_item one = { d_in, d_out, n };
+		return gdsp_fir_slide_batch (&one, 1, plan->h_taps, stream);
+		}
 	if (plan->W == 101)
 		{
 		FirTaps<101> taps;
@@ -570,6 +586,10 @@ extern "C" int gdsp_smooth_batch (const gdsp_batch_item* items, int nitems, uint
 	constexpr int T = FIR_THREADS * FIR_R;
 	hipStream_t   s = gdsp_stream (stream);
 	auto tilesOf = [] (uint32_t n) { return ((uint64_t) n + T - 1) / T; };
+	uint64_t total = 0;
+	for (int i=0 ; i<nitems ; i++) total += items[i].n;
+	if ((W == 101) && (mode == GDSP_FIR_EXACT) && gdsp_fir_slide_wanted (total))
+		return gdsp_fir_slide_batch (items, nitems, plan->h_taps, stream);
 	if (W == 101)
 		{
 		FirTaps<101> taps;
@@ -613,7 +633,7 @@ int gdsp_fir_extrema_gated_launch (const gdsp_batch_item* items, int count, cons
 	memcpy (taps.w, h_taps, sizeof(taps.w));
 	const int stride = FIR_THREADS*FIR_R - 2*h;
 	GdspBatch B;
-	gdsp_batch_make (B, items, count, [=] (uint32_t n) { return ((uint64_t) n + stride - 1) / stride; });
+	gdsp_batch_make (B, items, count, [=] (uint32_t n) { return (((uint64_t) n + stride - 1) / stride + FIR_GATED_TILES - 1) / FIR_GATED_TILES; });
 	hipStream_t s = gdsp_stream (stream);
 	const dim3 grid (B.tile0[GDSP_BATCH_MAX]), block (FIR_THREADS);
 	if (fma) { if (wantMax) hipLaunchKernelGGL ((fir_fixed_extrema_gated_kernel<101, FIR_R, true,  true>),  grid, block, 0, s, B, d_ctl, taps, h, fill);

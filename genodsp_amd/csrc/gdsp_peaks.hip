@@ -66,6 +66,12 @@ __global__ void peaks_init_kernel (GdspPeaksCtl* ctl, GdspBatch B, uint32_t stri
 // reference's order.  Only bases that tie or nearly tie with a neighbour -- the comparison itself needs exact values --
 // go to the tile's strip in HBM for the exact kernel.
 #define PK_SURE_CAP 256                                       // certain peaks a tile evaluates in place (one lane each); more go to the strip
+// A tile with no more than PK_NEED_INPLACE undecided bases (the usual case on real-valued coverage: a flat top here and
+// there) settles them itself as well: one lane per neighbour evaluates its exact value in the same pass as the certain
+// peaks (the chain of 101 multiply-adds costs a wave the same whether 40 or 250 of its lanes run it), the comparison of
+// minmax.c:1195-1216 follows on those values.  Such a tile is not listed for the exact kernel, which round 3 measured at
+// 54 us per 145 Mbp for visiting nearly every tile of a chromosome for one or two bases each.
+#define PK_NEED_INPLACE 12
 template <int W, bool FMA, bool MAX, int HH, bool PROBE>
 __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t tile,
                                                    const HannConsts<W>& K, const double* __restrict__ d_taps, double fill, GdspPeaksCtl* ctl,
@@ -84,6 +90,8 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 	__shared__ double   edgeLo[NW][HH], edgeHi[NW][HH];            // a wave's first block's first HH values, its last block's last HH
 	__shared__ uint32_t zeroBits[HN_THREADS/2], sureBits[HN_THREADS/2];   // per block of 16 outputs (16 bits each): exact zeros; peaks evaluated in place
 	__shared__ uint16_t sureList[PK_SURE_CAP];
+	__shared__ uint16_t needList[PK_NEED_INPLACE];                 // the first undecided bases: settled in place when there are no more than these
+	__shared__ double   exactVal[PK_NEED_INPLACE * (2*HH + 1)];    // ... from the exact values of their neighbourhoods
 	__shared__ double   tapsLds[W];                                // the window, for the exact values (as scalar operands its 202 words crowd out the block sums' constants)
 	__shared__ uint32_t nsure, queued;
 
@@ -360,6 +368,7 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 				const int u = __ffs ((int) word) - 1;
 				word &= word - 1;
 				if (at < cap) strip[at] = (uint16_t) (blk * HN_G + u);
+				if (at < PK_NEED_INPLACE) needList[at] = (uint16_t) (blk * HN_G + u);
 				at++;
 				}
 			}
@@ -370,21 +379,28 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 		reinterpret_cast<uint16_t*> (sureBits)[blk] = (uint16_t) (direct? 0u : isSure);
 		}
 	__syncthreads ();
+	const int  sure    = (int) ((nsure < PK_SURE_CAP)? nsure : PK_SURE_CAP);
+	const int  nq      = (int) queued;
+	// (cap < PK_NEED_INPLACE only under the tests' GDSP_PEAKS_QUEUE_CAP: they want the strips and their overflow exercised)
+	const bool inPlace = !direct && (nq != 0) && (nq <= PK_NEED_INPLACE) && (sure + nq * (2*HH + 1) <= HN_THREADS) && (cap >= PK_NEED_INPLACE);
 	if (p == 0)
 		{
-		const uint32_t q = direct? PK_WHOLE_TILE : queued;
+		const uint32_t q = direct? PK_WHOLE_TILE : inPlace? 0u : queued;
 		*tileCount = q;
 		if (q != 0) tileList[atomicAdd (&ctl->count, 1u)] = gt;    // (few tiles have anything for the exact kernel)
 		if (!direct && (queued > cap)) ctl->overflow = 1;          // more undecided bases than a strip holds: the vector goes through the direct kernel
 		}
 
-	// ---- exact values of the certain peaks, one lane each, from the staged inputs: tap by tap in the reference's order
-	//      (sum.c:655-663); the base is written by the lane that evaluated it
-	const int sure = (int) ((nsure < PK_SURE_CAP)? nsure : PK_SURE_CAP);
-	if (p < sure)
+	// ---- exact values of the certain peaks -- and of the neighbourhoods of the undecided bases settled in place -- one
+	//      lane each, from the staged inputs: tap by tap in the reference's order (sum.c:655-663); a certain peak is written
+	//      by the lane that evaluated it
+	const int evals = sure + (inPlace? nq * (2*HH + 1) : 0);
+	if (p < evals)
 		{
-		const int c = sureList[p];
-		const int e = G::LO + c;                                   // the window's first staged element
+		const int  mine = (p < sure)? 0 : (p - sure) / (2*HH + 1);
+		const int  c = (p < sure)? (int) sureList[p] : (int) needList[mine] - HH + ((p - sure) - mine * (2*HH + 1));
+		const bool inside = (c >= validLo) && (c < validHi);       // (a neighbour outside the vector beats nothing; c is within the computed stretch either way)
+		const int e = G::LO + (inside? c : validLo);               // the window's first staged element
 		// element e+k sits at e+k + ((e+k) >> 4) in the image: with e = 16 q + r that is 17 q + r + k + ((r + k) >> 4), and
 		// (r + k) >> 4 = (k >> 4) + ((k & 15) >= 16 - r).  Sixteen addresses per lane, one for each k & 15, leave every
 		// tap's read with a compile-time offset.
@@ -398,7 +414,22 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 			const double x = at16[k & 15][k + (k >> 4)];
 			a = FMA? __builtin_fma (tapsLds[k], x, a) : a + tapsLds[k] * x;
 			}
-		out[compStart + c] = a;
+		if (p < sure) out[compStart + c] = a;
+		else          exactVal[p - sure] = inside? a : (MAX? -INFINITY : INFINITY);
+		}
+	if (inPlace)                                                   // (uniform over the workgroup)
+		{
+		if (p < nq) atomicOr (&sureBits[needList[p] >> 5], 1u << (needList[p] & 31));    // the store loop below leaves these to their lanes
+		__syncthreads ();
+		if (p < nq)
+			{
+			const double* v = &exactVal[p * (2*HH + 1)];
+			const double centre = v[HH];
+			double ext = MAX? -INFINITY : INFINITY;
+#pragma unroll
+			for (int t=0 ; t<2*HH+1 ; t++) { if (t != HH) ext = MAX? fmax (ext, v[t]) : fmin (ext, v[t]); }
+			out[compStart + needList[p]] = (MAX? (ext > centre) : (ext < centre))? fill : centre;
+			}
 		}
 
 	// ---- the tile's other outputs: zero where an exact zero stands, `fill` elsewhere (a queued base is rewritten by the

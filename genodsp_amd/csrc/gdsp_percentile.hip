@@ -122,6 +122,7 @@ void pc_sample_tab_kernel (PcSampleTab T, uint32_t window, double lo, double hi,
 #define PC_MIN_WGS      1024
 #define PC_REPL         64
 #define PC_CTR_ALL      (PC_REPL * PC_CTR_WORDS + 1)      // replicas, then the candidate count
+#define PC_CTR_SPLIT    (PC_CTR_ALL + 2)                  // split resident route, summed over ranks with the rest: padded elements, lists that overflowed
 
 // state of the resident route (see pc_res_digit_kernel below)
 #define PC_RES_MAXP   8                                        // percentiles per call
@@ -156,7 +157,9 @@ struct PcResident
 struct PcResHist                                               // behind the PcResident in one allocation, zeroed with it before a call
 	{
 	unsigned long long notMin[2], max[2];                      // ~(smallest key counted), largest key counted: zero = nothing counted
-	uint32_t ticket, pad[7];
+	uint32_t ticket, pad0;
+	unsigned long long localCand;                              // split route: candidates THIS device kept (the counter itself is summed over ranks)
+	uint32_t pad[4];
 	uint32_t slab[1][2][PC_RES_BINS];                          // the shared histogram(s) of the pass in flight: zero between passes
 	};
 struct PcPts { uint32_t v[PC_RES_MAXP];  int n; };
@@ -658,9 +661,16 @@ __device__ __forceinline__ uint32_t pc_res_rank (uint64_t N, uint32_t pThousandt
 // few counters per workgroup, no histogram to merge) and keeps each cell's smallest and largest key: the subsample's
 // pivots are then the extreme keys of the cells the ranks fall in (any value brackets), the candidates' answer an
 // LDS select over the one cell that holds the rank.
+// mode WHOLE: as described.  Across ranks (several devices of a process with a communicator, or a process per GPU with a
+// device-side reduction hook) a pass is cut at its reduction: mode COUNT adds this device's keys to its histogram(s) and
+// stops; the caller all-reduces the histogram words where they lie (a sum of 64 KiB queued on the stream); mode PICK,
+// one workgroup, does what the last workgroup does.  Every device then holds the same histogram and the same state, so
+// every device takes the same decision; the smallest / largest key seen are left out (they only end a select early).
+enum { PC_RES_WHOLE = 0, PC_RES_COUNT = 1, PC_RES_PICK = 2 };
 __global__ __launch_bounds__(PC_RES_THREADS)
 void pc_res_digit_kernel (const uint64_t* __restrict__ keys, const unsigned long long* __restrict__ countPtr, unsigned long long countCap,
-                          int stage, int digit, int which, uint32_t pThousandths, PcResident* __restrict__ R, PcResHist* __restrict__ H)
+                          int stage, int digit, int which, uint32_t pThousandths, PcResident* __restrict__ R, PcResHist* __restrict__ H,
+                          int mode)
 	{
 	__shared__ uint32_t lb[2][PC_RES_BINS];
 	__shared__ unsigned long long sMin[2][PC_RES_THREADS/64], sMax[2][PC_RES_THREADS/64];
@@ -697,6 +707,8 @@ void pc_res_digit_kernel (const uint64_t* __restrict__ keys, const unsigned long
 	PC_STAMP (0);
 
 	const int p = threadIdx.x, lane = p & 63, wave = p >> 6;
+	if (mode != PC_RES_PICK)
+	{
 	for (int b=p ; b<nbins ; b+=PC_RES_THREADS) { lb[0][b] = 0;  if (two) lb[1][b] = 0; }
 	__syncthreads ();
 	uint64_t kminA = ~0ULL, kmaxA = 0, kminB = ~0ULL, kmaxB = 0;
@@ -733,6 +745,7 @@ void pc_res_digit_kernel (const uint64_t* __restrict__ keys, const unsigned long
 	// into the shared histogram(s): agent-scope adds of this workgroup's non-empty bins
 	for (int h=0 ; h<(two? 2 : 1) ; h++)
 		for (int b=p ; b<nbins ; b+=PC_RES_THREADS) { const uint32_t c = lb[h][b];  if (c) atomicAdd (&H->slab[0][h][b], c); }
+	if (mode == PC_RES_COUNT) return;                              // (the kernel boundary publishes the adds)
 	for (int off=32 ; off>0 ; off>>=1)
 		{
 		uint64_t a = __shfl_down ((unsigned long long) kminA, off, 64), b = __shfl_down ((unsigned long long) kmaxA, off, 64);
@@ -754,14 +767,16 @@ void pc_res_digit_kernel (const uint64_t* __restrict__ keys, const unsigned long
 			for (int w=0 ; w<PC_RES_THREADS/64 ; w++) { if (sMin[h][w] < lo) lo = sMin[h][w];  if (sMax[h][w] > hi) hi = sMax[h][w]; }
 			if (lo <= hi) { atomicMax (&H->notMin[h], (unsigned long long) ~lo);  atomicMax (&H->max[h], (unsigned long long) hi); }
 			}
-		asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
-		const uint32_t t = __hip_atomic_fetch_add (&H->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		// release: the adds of every wave of this workgroup (ordered before this point by the barrier) are visible at
+		// agent scope before the ticket is; acquire: the last arrival sees every earlier workgroup's
+		__threadfence ();
+		const uint32_t t = __hip_atomic_fetch_add (&H->ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
 		sLast = (t == gridDim.x - 1)? 1 : 0;
-		if (sLast) __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "agent");
-		asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
 		}
 	__syncthreads ();
 	if (!sLast) return;
+	__builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "agent");            // every reading wave, not only the one that drew the ticket
+	}
 	PC_STAMP (3);
 
 	// ---- the last workgroup: bucket(s) of the rank(s) in the summed histogram(s) (thread p: bins per*p ..), the state
@@ -772,7 +787,7 @@ void pc_res_digit_kernel (const uint64_t* __restrict__ keys, const unsigned long
 	if (p == 0)
 		{
 		stK[0] = R->selK[0];  stK[1] = R->selK[1];  stPrefix[0] = R->selPrefix[0];  stPrefix[1] = R->selPrefix[1];
-		stMin[0] = ~H->notMin[0];  stMin[1] = ~H->notMin[1];  stMax[0] = H->max[0];  stMax[1] = H->max[1];
+		stMin[0] = ~H->notMin[0];  stMin[1] = ~H->notMin[1];  stMax[0] = H->max[0];  stMax[1] = H->max[1];     // (split route: never written, ~0 and 0)
 		if (stage == PC_RES_CAND) { stRank = R->rankIn[which];  stBin = R->binCount[which]; }
 		}
 	uint32_t sum[2][8];
@@ -956,9 +971,24 @@ __global__ void pc_res_pivots_kernel (PcResident* __restrict__ R, int np, int fu
 
 // after the counting pass: the replicas summed, bins, population and ranks (host: pc_run steps 3-4); which percentile is
 // a pivot's tie, which an order statistic of the candidates (and of which), which has to take the plain route
+// split route, before the counters are summed over ranks: what has to stay local is put aside (the candidates THIS device
+// kept: the digit passes over its list read the count from H), what the ranks have to agree on joins the sum (candidates
+// kept, elements counted with their padding, lists that overflowed)
+__global__ void pc_res_local_kernel (unsigned long long* __restrict__ ctr, unsigned long long candCap, unsigned long long padded,
+                                     PcResHist* __restrict__ H)
+	{
+	if ((threadIdx.x != 0) || (blockIdx.x != 0)) return;
+	unsigned long long* tail = ctr + (size_t) PC_REPL * PC_CTR_WORDS;
+	unsigned long long c = tail[0];
+	const bool over = (c > candCap);
+	if (over) c = candCap;
+	H->localCand = c;
+	tail[0] = c;  tail[1] = padded;  tail[2] = over? 1 : 0;
+	}
+
 __global__ __launch_bounds__(PC_THREADS)
 void pc_res_bins_kernel (PcResident* __restrict__ R, const unsigned long long* __restrict__ ctr, unsigned long long candCap,
-                         int bounded, unsigned long long padded, PcPts pts)
+                         int bounded, unsigned long long padded, PcPts pts, int split)
 	{
 	__shared__ unsigned long long raw[PC_CTR_WORDS];
 	if (R->status != PC_RES_OK) return;
@@ -971,9 +1001,11 @@ void pc_res_bins_kernel (PcResident* __restrict__ R, const unsigned long long* _
 	__syncthreads ();
 	if (threadIdx.x != 0) return;
 	const int m = R->P.m, nb = 2*m + 1;
-	unsigned long long cands = ctr[(size_t) PC_REPL * PC_CTR_WORDS];
-	const bool overflow = (cands > candCap);
+	const unsigned long long* tail = ctr + (size_t) PC_REPL * PC_CTR_WORDS;
+	unsigned long long cands = tail[0];
+	bool overflow = (cands > candCap);
 	if (overflow) cands = candCap;
+	if (split) { cands = tail[0];  padded = tail[1];  overflow = (tail[2] != 0); }     // (pc_res_local_kernel, summed over ranks)
 	R->candCount = cands;  R->overflow = overflow? 1 : 0;
 	const unsigned long long nans  = raw[PC_CTR_NANPOS] + raw[PC_CTR_NANNEG];
 	const unsigned long long total = bounded? raw[PC_CTR_GELO] - raw[PC_CTR_GTHI] + nans
@@ -1098,7 +1130,7 @@ static int pc_device (int device, size_t sampleCap, size_t candCap, PcDevice** o
 		memset (d, 0, sizeof(*d));
 		d->device = device;
 		GDSP_HIP_TRY (hipMalloc ((void**) &d->hist, PC_HIST_WORDS * sizeof(uint64_t)));
-		GDSP_HIP_TRY (hipMalloc ((void**) &d->ctr,  PC_CTR_ALL * sizeof(uint64_t)));
+		GDSP_HIP_TRY (hipMalloc ((void**) &d->ctr,  PC_CTR_SPLIT * sizeof(uint64_t)));
 		GDSP_HIP_TRY (hipMalloc ((void**) &d->tmp,  PC_TMP_WORDS * sizeof(uint64_t)));
 		GDSP_HIP_TRY (hipMalloc ((void**) &d->posCount, PC_MAX_FUSED_SOURCES * sizeof(unsigned long long)));
 		GDSP_HIP_TRY (hipMalloc ((void**) &d->chain, sizeof(PcChain)));
@@ -1140,7 +1172,7 @@ struct PcJob                                                  // one call of gds
 	double                 vLo, vHi;                          // the bracket the fused stores relied on
 	bool                   fusedAny;
 	bool                   fixupsDone;                        // the resident route has patched the open positions already ...
-	std::vector<unsigned long long> queuedHost;               // ... and these are the strips' counts it read back
+	std::vector<std::vector<unsigned long long> > queuedHost; // ... and these are the strips' counts it read back, per device
 	};
 
 #define PC_TRY(call) do { int rc_ = (call);  if (rc_ != GDSP_OK) return rc_; } while (0)
@@ -1429,7 +1461,7 @@ static int pc_count_launch (PcJob& J, const PcPivots& P, int mUse, bool bounded,
 	for (size_t d=0 ; d<J.devices.size () ; d++)
 		{
 		GDSP_HIP_TRY (hipSetDevice (J.devices[d]));
-		GDSP_HIP_TRY (hipMemsetAsync (J.scratch[d]->ctr, 0, PC_CTR_ALL * sizeof(uint64_t), gdsp_stream (J.stream[d])));
+		GDSP_HIP_TRY (hipMemsetAsync (J.scratch[d]->ctr, 0, PC_CTR_SPLIT * sizeof(uint64_t), gdsp_stream (J.stream[d])));
 		GDSP_HIP_TRY (hipMemsetAsync (J.scratch[d]->posCount, 0, PC_MAX_FUSED_SOURCES * sizeof(unsigned long long), gdsp_stream (J.stream[d])));
 		unsigned long long* ctr = (unsigned long long*) J.scratch[d]->ctr;
 		const PcResident* RES = resident? J.scratch[d]->res : NULL;
@@ -1479,37 +1511,86 @@ static int pc_count_launch (PcJob& J, const PcPivots& P, int mUse, bool bounded,
 	return GDSP_OK;
 	}
 
-// the bracket route with every decision taken on the device (see pc_res_digit_kernel): one device, nobody to reduce
-// with.  *took = false: the route declined (its status word says why) before writing anything a caller could see;
-// pc_run then carries on the old way.
+// the bracket route with every decision taken on the device (see pc_res_digit_kernel).  One device and nobody to reduce
+// with: whole digit passes, the last workgroup of each picking.  Across ranks -- the devices of a communicator, or one
+// device here and a device-side reduction hook that reaches the other processes -- every pass is cut at its reduction
+// (count, all-reduce of the histogram words queued on the stream, pick) and so is the counting pass (counters summed
+// before the bins are read): every rank queues the same launches and the same collectives whatever its data, every
+// device ends with the same state, and the host reads ONE device's copy ONCE at any world size (percentile.c:547-683
+// is the sort this replaces).  *took = false: the route declined (its status word says why, the same on every rank)
+// before writing anything a caller could see; pc_run then carries on the old way.
 static int pc_resident (PcJob& J, const uint32_t* pThousandths, int np, uint32_t sstride, double* values, uint64_t* count, bool* took)
 	{
 	*took = false;
-	PcDevice*   sc = J.scratch[0];
-	hipStream_t st = gdsp_stream (J.stream[0]);
-	GDSP_HIP_TRY (hipSetDevice (J.devices[0]));
-	PcResident* R = sc->res;
-	PcResHist*  H = reinterpret_cast<PcResHist*> (reinterpret_cast<char*> (sc->res) + PC_RES_STATE_BYTES);
-	GDSP_HIP_TRY (hipMemsetAsync (R, 0, PC_RES_STATE_BYTES + sizeof(PcResHist), st));
+	const size_t ND    = J.devices.size ();
+	const bool   split = pc_on_device (J);
+	std::vector<PcResident*> R (ND);
+	std::vector<PcResHist*>  H (ND);
+	std::vector<hipStream_t> st (ND);
+	for (size_t d=0 ; d<ND ; d++)
+		{
+		GDSP_HIP_TRY (hipSetDevice (J.devices[d]));
+		st[d] = gdsp_stream (J.stream[d]);
+		R[d]  = J.scratch[d]->res;
+		H[d]  = reinterpret_cast<PcResHist*> (reinterpret_cast<char*> (J.scratch[d]->res) + PC_RES_STATE_BYTES);
+		GDSP_HIP_TRY (hipMemsetAsync (R[d], 0, PC_RES_STATE_BYTES + sizeof(PcResHist), st[d]));
+		}
 	PcPts pts;
 	memset (&pts, 0, sizeof(pts));
 	pts.n = np;
 	for (int i=0 ; i<np ; i++) pts.v[i] = pThousandths[i];
 
-	// subsample, then the ranks either side of every percentile's target: five digits each, no answer awaited
-	PC_TRY (pc_sample_launch (J, sstride));
-	const unsigned long long slots = J.sampleCount[0];
-	const uint32_t sblocks = (uint32_t) std::min<unsigned long long> (PC_RES_MAXB, std::max<unsigned long long> (1, (slots + 16383) / 16384));
-	for (int i=0 ; i<np ; i++)
-		for (int digit=0 ; digit<PC_DIGITS ; digit++)
+	// one digit pass over every device's list: whole, or count / all-reduce / pick
+	auto digit_pass = [&] (int stage, int digit, int which) -> int
+		{
+		for (size_t d=0 ; d<ND ; d++)
 			{
-			hipLaunchKernelGGL (pc_res_digit_kernel, dim3(sblocks), dim3(PC_RES_THREADS), 0, st, sc->sample, (const unsigned long long*) NULL, slots,
-			                    PC_RES_SAMPLE, digit, i, pts.v[i], R, H);
+			GDSP_HIP_TRY (hipSetDevice (J.devices[d]));
+			PcDevice* sc = J.scratch[d];
+			uint32_t blocks;
+			const uint64_t* keys;  const unsigned long long* countPtr;  unsigned long long cap;
+			if (stage == PC_RES_SAMPLE)
+				{
+				const unsigned long long slots = J.sampleCount[d];
+				blocks = (uint32_t) std::min<unsigned long long> (PC_RES_MAXB, std::max<unsigned long long> (1, (slots + 16383) / 16384));
+				keys = sc->sample;  countPtr = NULL;  cap = slots;
+				}
+			else
+				{
+				blocks = (uint32_t) std::min<size_t> (PC_RES_MAXB, std::max<size_t> (4, sc->candCap / 65536));
+				keys = sc->cand;  cap = (unsigned long long) sc->candCap;
+				countPtr = split? &H[d]->localCand : (const unsigned long long*) sc->ctr + (size_t) PC_REPL * PC_CTR_WORDS;
+				}
+			hipLaunchKernelGGL (pc_res_digit_kernel, dim3(blocks), dim3(PC_RES_THREADS), 0, st[d], keys, countPtr, cap,
+			                    stage, digit, which, pts.v[which], R[d], H[d], split? PC_RES_COUNT : PC_RES_WHOLE);
 			GDSP_LAUNCH_CHECK ();
 			}
+		if (!split) return GDSP_OK;
+		// both histograms as 64-bit words: pairs of 32-bit counts whose sums stay below 2^32 (pc_run checks the totals)
+		std::vector<uint64_t*> slabs (ND);
+		for (size_t d=0 ; d<ND ; d++) slabs[d] = reinterpret_cast<uint64_t*> (&H[d]->slab[0][0][0]);
+		PC_TRY (pc_device_allreduce (J, slabs, (size_t) 2 * PC_RES_BINS / 2, 0));
+		for (size_t d=0 ; d<ND ; d++)
+			{
+			GDSP_HIP_TRY (hipSetDevice (J.devices[d]));
+			hipLaunchKernelGGL (pc_res_digit_kernel, dim3(1), dim3(PC_RES_THREADS), 0, st[d], (const uint64_t*) NULL,
+			                    (const unsigned long long*) NULL, 0ULL, stage, digit, which, pts.v[which], R[d], H[d], PC_RES_PICK);
+			GDSP_LAUNCH_CHECK ();
+			}
+		return GDSP_OK;
+		};
+
+	// subsample, then the ranks either side of every percentile's target: five digits each, no answer awaited
+	PC_TRY (pc_sample_launch (J, sstride));
+	for (int i=0 ; i<np ; i++)
+		for (int digit=0 ; digit<PC_DIGITS ; digit++) PC_TRY (digit_pass (PC_RES_SAMPLE, digit, i));
 	const int fuseWhich = (J.fuse != NULL)? J.fuse->which : -1;
-	hipLaunchKernelGGL (pc_res_pivots_kernel, dim3(1), dim3(64), 0, st, R, np, fuseWhich);
-	GDSP_LAUNCH_CHECK ();
+	for (size_t d=0 ; d<ND ; d++)
+		{
+		GDSP_HIP_TRY (hipSetDevice (J.devices[d]));
+		hipLaunchKernelGGL (pc_res_pivots_kernel, dim3(1), dim3(64), 0, st[d], R[d], np, fuseWhich);
+		GDSP_LAUNCH_CHECK ();
+		}
 
 	// the counting pass reads its pivots (and the fused binarize its bracket) from R
 	const bool bounded = !((J.lo <= -DBL_MAX) && (J.hi >= DBL_MAX));
@@ -1517,55 +1598,83 @@ static int pc_resident (PcJob& J, const uint32_t* pThousandths, int np, uint32_t
 	memset (&none, 0, sizeof(none));
 	uint64_t padded = 0;
 	PC_TRY (pc_count_launch (J, none, 2*np, bounded, J.fuse != NULL, -1, -1, true, &padded));
-	const unsigned long long* ctr = (const unsigned long long*) sc->ctr;
-	hipLaunchKernelGGL (pc_res_bins_kernel, dim3(1), dim3(PC_THREADS), 0, st, R, ctr, (unsigned long long) sc->candCap, bounded? 1 : 0,
-	                    (unsigned long long) padded, pts);
-	GDSP_LAUNCH_CHECK ();
-
-	// an order statistic of the candidates for every percentile that landed inside a bracket
-	const uint32_t cblocks = (uint32_t) std::min<size_t> (PC_RES_MAXB, std::max<size_t> (4, sc->candCap / 65536));
-	for (int i=0 ; i<np ; i++)
-		for (int digit=0 ; digit<PC_DIGITS ; digit++)
-			{
-			hipLaunchKernelGGL (pc_res_digit_kernel, dim3(cblocks), dim3(PC_RES_THREADS), 0, st, sc->cand, ctr + (size_t) PC_REPL * PC_CTR_WORDS,
-			                    (unsigned long long) sc->candCap, PC_RES_CAND, digit, i, pts.v[i], R, H);
-			GDSP_LAUNCH_CHECK ();
-			}
-	// the fused binarize's open positions
-	if (J.fusedAny)
+	if (split)
 		{
-		PcFixTab T;
-		int    k = 0;
-		size_t most = 0;
-		auto go = [&] ()
+		std::vector<uint64_t*> ctrs (ND);
+		for (size_t d=0 ; d<ND ; d++)
 			{
-			if (k == 0) return;
-			const uint32_t blocks = (uint32_t) std::min<size_t> (std::max<size_t> (1, 2048 / k), std::max<size_t> (1, most / 65536));
-			if (k == 1) hipLaunchKernelGGL (pc_res_fixup_kernel, dim3(blocks), dim3(PC_THREADS), 0, st, T.v[0], T.out[0], T.pos[0], T.posCount[0],
-			                                T.cap[0], R, fuseWhich, J.fuse->tiesAbove, J.fuse->one, J.fuse->zero);
-			else        hipLaunchKernelGGL (pc_res_fixup_tab_kernel, dim3(blocks, k), dim3(PC_THREADS), 0, st, T, R, fuseWhich,
-			                                J.fuse->tiesAbove, J.fuse->one, J.fuse->zero);
-			k = 0;  most = 0;
-			};
-		for (int i=0 ; i<J.nsrc ; i++)
-			{
-			if (J.fusedSource[i] < 0) continue;
-			T.v[k] = J.src[i].d_v;  T.out[k] = J.fuse->d_out[i];  T.pos[k] = sc->pos + J.posOffset[i];
-			T.posCount[k] = sc->posCount + J.fusedSource[i];  T.cap[k] = (uint32_t) J.posCap[i];
-			most = std::max<size_t> (most, J.src[i].n);
-			if (++k == PC_TAB) { go ();  GDSP_LAUNCH_CHECK (); }
+			unsigned long long mine = 0;                               // what this device's launches counted, padding included
+			for (int i=0 ; i<J.nsrc ; i++)
+				{
+				if ((J.src[i].device != J.devices[d]) || (J.src[i].n == 0)) continue;
+				const size_t pp = ((size_t) J.src[i].n + J.window - 1) / J.window;
+				mine += (unsigned long long) ((pp + PC_TILE - 1) / PC_TILE) * PC_TILE;
+				}
+			GDSP_HIP_TRY (hipSetDevice (J.devices[d]));
+			hipLaunchKernelGGL (pc_res_local_kernel, dim3(1), dim3(64), 0, st[d], (unsigned long long*) J.scratch[d]->ctr,
+			                    (unsigned long long) J.scratch[d]->candCap, mine, H[d]);
+			GDSP_LAUNCH_CHECK ();
+			ctrs[d] = J.scratch[d]->ctr;
 			}
-		go ();
+		PC_TRY (pc_device_allreduce (J, ctrs, PC_CTR_SPLIT, 0));
+		}
+	for (size_t d=0 ; d<ND ; d++)
+		{
+		GDSP_HIP_TRY (hipSetDevice (J.devices[d]));
+		hipLaunchKernelGGL (pc_res_bins_kernel, dim3(1), dim3(PC_THREADS), 0, st[d], R[d], (const unsigned long long*) J.scratch[d]->ctr,
+		                    (unsigned long long) J.scratch[d]->candCap, bounded? 1 : 0, (unsigned long long) padded, pts, split? 1 : 0);
 		GDSP_LAUNCH_CHECK ();
 		}
 
-	// ---- the one read-back of the call
-	PcResident got;
-	J.queuedHost.assign (PC_MAX_FUSED_SOURCES, 0);
-	GDSP_HIP_TRY (hipMemcpyAsync (&got, R, sizeof(got), hipMemcpyDeviceToHost, st));
+	// an order statistic of the candidates for every percentile that landed inside a bracket
+	for (int i=0 ; i<np ; i++)
+		for (int digit=0 ; digit<PC_DIGITS ; digit++) PC_TRY (digit_pass (PC_RES_CAND, digit, i));
+	// the fused binarize's open positions
 	if (J.fusedAny)
-		GDSP_HIP_TRY (hipMemcpyAsync (J.queuedHost.data (), sc->posCount, PC_MAX_FUSED_SOURCES * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-	GDSP_HIP_TRY (hipStreamSynchronize (st));
+		{
+		for (size_t d=0 ; d<ND ; d++)
+			{
+			GDSP_HIP_TRY (hipSetDevice (J.devices[d]));
+			PcDevice* sc = J.scratch[d];
+			PcFixTab T;
+			int    k = 0;
+			size_t most = 0;
+			auto go = [&] ()
+				{
+				if (k == 0) return;
+				const uint32_t blocks = (uint32_t) std::min<size_t> (std::max<size_t> (1, 2048 / k), std::max<size_t> (1, most / 65536));
+				if (k == 1) hipLaunchKernelGGL (pc_res_fixup_kernel, dim3(blocks), dim3(PC_THREADS), 0, st[d], T.v[0], T.out[0], T.pos[0], T.posCount[0],
+				                                T.cap[0], R[d], fuseWhich, J.fuse->tiesAbove, J.fuse->one, J.fuse->zero);
+				else        hipLaunchKernelGGL (pc_res_fixup_tab_kernel, dim3(blocks, k), dim3(PC_THREADS), 0, st[d], T, R[d], fuseWhich,
+				                                J.fuse->tiesAbove, J.fuse->one, J.fuse->zero);
+				k = 0;  most = 0;
+				};
+			for (int i=0 ; i<J.nsrc ; i++)
+				{
+				if ((J.fusedSource[i] < 0) || (J.src[i].device != J.devices[d])) continue;
+				T.v[k] = J.src[i].d_v;  T.out[k] = J.fuse->d_out[i];  T.pos[k] = sc->pos + J.posOffset[i];
+				T.posCount[k] = sc->posCount + J.fusedSource[i];  T.cap[k] = (uint32_t) J.posCap[i];
+				most = std::max<size_t> (most, J.src[i].n);
+				if (++k == PC_TAB) { go ();  GDSP_LAUNCH_CHECK (); }
+				}
+			go ();
+			GDSP_LAUNCH_CHECK ();
+			}
+		}
+
+	// ---- the one read-back of the call: the state from one device (every device's is the same), each device's strips' counts
+	PcResident got;
+	J.queuedHost.assign (ND, std::vector<unsigned long long> (PC_MAX_FUSED_SOURCES, 0));
+	GDSP_HIP_TRY (hipSetDevice (J.devices[0]));
+	GDSP_HIP_TRY (hipMemcpyAsync (&got, R[0], sizeof(got), hipMemcpyDeviceToHost, st[0]));
+	if (J.fusedAny)
+		for (size_t d=0 ; d<ND ; d++)
+			{
+			GDSP_HIP_TRY (hipSetDevice (J.devices[d]));
+			GDSP_HIP_TRY (hipMemcpyAsync (J.queuedHost[d].data (), J.scratch[d]->posCount, PC_MAX_FUSED_SOURCES * sizeof(unsigned long long),
+			                              hipMemcpyDeviceToHost, st[d]));
+			}
+	for (size_t d=0 ; d<ND ; d++) { GDSP_HIP_TRY (hipSetDevice (J.devices[d]));  GDSP_HIP_TRY (hipStreamSynchronize (st[d])); }
 	pcStats[2] = got.sTotal;
 #ifdef PC_RES_TIMING
 	for (int sg=0 ; sg<2 ; sg++)
@@ -1718,8 +1827,13 @@ static int pc_run (const gdsp_select_source* sources, int nsources, uint32_t win
 	J.fixupsDone = false;
 
 	// one device and nobody to reduce with: the whole route on the device, one read-back
-	const bool resident = bracket && (J.devices.size () == 1) && !pc_on_device (J) && (J.reduce == NULL) && (npercentiles <= PC_RES_MAXP)
-	                   && (J.scratch[0]->candCap < (1ULL << 32)) && (getenv ("GDSP_PERCENTILE_RESIDENT_OFF") == NULL);
+	// (or across ranks with the reductions queued on the streams: a communicator, or a device-side hook.  The conditions are
+	// the same on every rank: global quantities only -- a bound on any rank's candidate list in place of its own capacity.)
+	const double   sGlobal  = (double) std::max<uint64_t> (1, pop / sstride);
+	const double   candsTop = (double) pop * std::min (1.0, npercentiles * 8.0 * 0.5 / sqrt (sGlobal)) * 2 + 65536.0 * 64;
+	const bool resident = bracket && ((J.devices.size () == 1) || (J.comm != NULL)) && (J.reduce == NULL) && (npercentiles <= PC_RES_MAXP)
+	                   && (candsTop < 4294967296.0) && (pop / sstride + 64 * 64 < (1ULL << 32))
+	                   && (getenv ("GDSP_PERCENTILE_RESIDENT_OFF") == NULL);
 	if (resident)
 		{
 		bool took = false;
@@ -1929,7 +2043,7 @@ static int pc_finish_binarize (PcJob& J, double T, bool* onePass)
 	const bool bracketHolds = J.fusedAny && (T >= J.vLo) && (T <= J.vHi);
 	// positions queued per fused source: one copy per device
 	std::vector<std::vector<unsigned long long> > queued (J.devices.size ());
-	if (bracketHolds && J.fixupsDone) queued[0] = J.queuedHost;    // (the resident route: one device, counts read back already)
+	if (bracketHolds && J.fixupsDone) queued = J.queuedHost;       // (the resident route: counts read back already)
 	else if (bracketHolds)
 		{
 		for (size_t d=0 ; d<J.devices.size () ; d++)

@@ -279,7 +279,14 @@ static int percentile_run (dspop* _op, dspop* binarize)
 		if (fuse.which < 0) { fprintf (stderr, "[%s] internal error: nothing to fuse\n", _op->name);  exit (EXIT_FAILURE); }   /* (percentile_fusable said yes) */
 		double** outs = (double**) calloc (nsrc? nsrc : 1, sizeof(double*));
 		if (outs == NULL) { fprintf (stderr, "[%s] out of memory\n", _op->name);  exit (EXIT_FAILURE); }
-		for (int i=0 ; i<nsrc ; i++) outs[i] = partner_of (parts[i].s);
+		for (int i=0 ; i<nsrc ; i++)
+			{
+			/* the fused kernels index the output like the source: both must start at the vector's first base
+			 * (percentile_fusable asks for whole chromosomes and a window of one base, so nothing is skipped) */
+			if ((src[i].n != 0) && ((src[i].d_v != parts[i].base) || (parts[i].first != 0)))
+				{ fprintf (stderr, "[%s] internal error: a fused binarize over a stretch\n", _op->name);  exit (EXIT_FAILURE); }
+			outs[i] = partner_of (parts[i].s);
+			}
 		fuse.d_out = outs;
 		int onePass = 0;
 		check_gdsp (gdsp_percentiles_binarize (src, nsrc, op->windowSize, op->minAllowed, op->maxAllowed, pts, npct,
@@ -292,6 +299,14 @@ static int percentile_run (dspop* _op, dspop* binarize)
 		                              selectStrategy, 0, reduce, reduceCtx, vals, &numValues), "percentile");
 	if (nsrc > 0) select_device_of (parts[0].s);
 	free (src);
+	if (getenv ("GDSP_PERCENTILE_REPORT") != NULL)               /* how the call was answered (tests; gdsp_percentiles_stats) */
+		{
+		uint64_t st[8];
+		gdsp_percentiles_stats (st);
+		fprintf (stderr, "[%s] route=%s resident=%d readbacks=%s population=%llu sample=%llu candidates=%llu fallbacks=%llu fused=%d\n",
+		         _op->name, (st[0] == GDSP_SELECT_BRACKET)? "bracket" : "radix", (int) st[7], (st[7] != 0)? "1" : "many",
+		         (unsigned long long) st[1], (unsigned long long) st[2], (unsigned long long) st[3], (unsigned long long) st[4], (int) st[6]);
+		}
 	if (numValues == 0)
 		{
 		fprintf (stderr, "[%s] percentile can't be computed;  no input values meet the criteria\n", _op->name);

@@ -47,7 +47,7 @@ def test_running_sums_behind_smooth_stay_within_the_stated_bound(case, tmp_path)
 
 
 @pytest.mark.parametrize("poison", ["1e300", "-1e300"])
-@pytest.mark.parametrize("case", DIGESTS[::2], ids=[c["name"] for c in DIGESTS[::2]])
+@pytest.mark.parametrize("case", DIGESTS[::3], ids=[c["name"] for c in DIGESTS[::3]])
 def test_seam_crossing_pipelines_do_not_read_memory_nobody_wrote(case, poison, tmp_path, monkeypatch):
     """as tests/test_cli_hip.py::test_no_operator_reads_memory_nobody_wrote, at sizes where tiles meet their seams and
     on the whole-vector routes of the long windows"""

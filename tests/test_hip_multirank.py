@@ -63,6 +63,7 @@ def test_device_reduction_hook_through_rccl_at_world_size_one():
     one = _bench(1, "percentile", 0.08)
     assert got["percentile99"] == one["percentile99"] and got["sampled"] == one["sampled"]
     assert got["config"]["collectives"] == "rccl (torch.distributed nccl backend), device words"
+    assert got["percentile_stats"]["resident"] == 1 and got["binarize_in_one_pass"] is True, got["percentile_stats"]
 
 
 def test_percentile_over_two_ranks_equals_one_rank():
@@ -73,6 +74,22 @@ def test_percentile_over_two_ranks_equals_one_rank():
     assert two["sampled"] == one["sampled"] == one["config"]["bases"]
     assert two["percentile99"] == one["percentile99"]
     assert two["percentile_route"] == one["percentile_route"] == "bracket"
+    # both are decided on the device with one read-back: across ranks every digit pass and the counting pass are cut at
+    # their reduction (count, all-reduce of the device words through the hook, pick) -- gdsp_percentile.hip: pc_resident
+    for r in (one, two):
+        assert r["percentile_stats"]["resident"] == 1 and r["percentile_stats"]["fallbacks"] == 0, r["percentile_stats"]
+        assert r["binarize_in_one_pass"] is True
+    assert two["percentile_stats"]["population"] == one["percentile_stats"]["population"]
+    assert two["percentile_stats"]["sample"] == one["percentile_stats"]["sample"]
+
+
+def test_percentile_alone_over_two_ranks_equals_one_rank():
+    """the same without the fused binarize (gdsp_percentiles), two ranks sharing the GPU against one"""
+    one = _bench(1, "percentile", 0.08, ["--nofuse"])
+    two = _bench(2, "percentile", 0.08, ["--nofuse"])
+    assert two["percentile99"] == one["percentile99"] and two["sampled"] == one["sampled"]
+    for r in (one, two):
+        assert r["percentile_stats"]["resident"] == 1 and r["percentile_stats"]["fallbacks"] == 0, r["percentile_stats"]
 
 
 def test_smooth_over_two_ranks_reports_the_whole_job():
