@@ -231,6 +231,7 @@ int gdsp_percentiles_binarize (const source* src, int nsrc, uint32_t window, dou
 	return OK;
 	}
 int gdsp_percentiles_use_comm (void* c) { (void) c;  return OK; }
+void gdsp_percentiles_stats (uint64_t out[8]) { memset (out, 0, 8 * sizeof(uint64_t)); }
 
 /* the interval-file operators that walk sorted intervals: the CSR lists them tile by tile in file order */
 static uint32_t gather (uint32_t n, const uint32_t* start, const uint32_t* end, const double* val, const uint32_t* off, const uint32_t* list,
