@@ -174,6 +174,113 @@ void fir_slide_kernel (FsTable T, FsTaps taps)
 	else          { if (edge) fs_strip<0, true> (in, out, n, s0, S, NB, taps, wLds);  else fs_strip<0, false> (in, out, n, s0, S, NB, taps, wLds); }
 	}
 
+// ---- the same walk with the memory side taken off the lanes' critical path (GDSP_FIR_SLIDE=2).  In the kernel above a
+// lane fetches its own strip 16 bytes at a time, one pair ahead of the arithmetic: every 128-byte line is a miss the
+// wave waits for (90 Gbases/s, and slower the further apart the strips lie).  Here a workgroup is ONE pair of waves --
+// the two parity classes of 64 strips -- and a block of 16 inputs per strip comes in as eight LDS-DMA loads
+// (global_load_lds_dwordx4: per-lane source address, lane-linear destination: image [pair][lane], read back with
+// conflict-free ds_read_b128), four issued by each wave, a whole block ahead of its use: two input buffers, one barrier
+// per block.  The 16 outputs a block finishes per strip (8 from each class) meet in LDS as 8 pairs and leave as 16-byte
+// stores, four pairs per wave.  Strips at a vector's ends fill their LDS slots through guarded register loads instead.
+#define FS2_THREADS 128
+template <int PI>
+__device__ __forceinline__ void fs2_strip (const double* __restrict__ in, double* __restrict__ out, const int64_t n, const int64_t s0,
+                                           const int S, const int NB, const bool edge, const bool idle, const FsTaps& ws,
+                                           const double* __restrict__ wLds, double2 (*inBuf)[FS_B/2][64], double2 (*outBuf)[FS_B/2][64])
+	{
+	const int lane = threadIdx.x & 63;
+	double w[51 - FS_MS];
+#pragma unroll
+	for (int m=FS_MS ; m<51 ; m++) w[m - FS_MS] = wLds[m];
+	double acc[FS_NA];
+#pragma unroll
+	for (int a=0 ; a<FS_NA ; a++) acc[a] = 0.0;
+	const int64_t g0 = s0 - FS_LEAD;
+	const double* __restrict__ inp  = in + g0;                     // input t of the strip
+	double* __restrict__       outp = out + s0;                    // output o of the strip
+
+	// this wave's half of block b's eight pairs, into buffer `buf`
+	auto fetch = [&] (int b, int buf)
+		{
+#pragma unroll
+		for (int kk=0 ; kk<FS_B/4 ; kk++)
+			{
+			const int k = PI * (FS_B/4) + kk, t = b * FS_B + 2*k;
+			if (!edge)
+				__builtin_amdgcn_global_load_lds ((const __attribute__((address_space(1))) void*) (inp + t),
+				                                  (__attribute__((address_space(3))) void*) &inBuf[buf][k][0], 16, 0, 0);
+			else
+				{
+				const int64_t g = g0 + t;
+				double2 r;
+				r.x = ((g     >= 0) && (g     < n))? in[g]     : 0.0;
+				r.y = ((g + 1 >= 0) && (g + 1 < n))? in[g + 1] : 0.0;
+				inBuf[buf][k][lane] = r;
+				}
+			}
+		};
+	fetch (0, 0);
+	__syncthreads ();                                              // (the taps too)
+	if (NB > 1) fetch (1, 1);
+	for (int b=0 ; b<NB ; b++)
+		{
+		const int buf = b & 1, tb = b * FS_B;
+		double2 cur = inBuf[buf][0][lane];
+#pragma unroll
+		for (int dp=0 ; dp<FS_B/2 ; dp++)
+			{
+			const double2 nxt = inBuf[buf][(dp + 1 < FS_B/2)? dp + 1 : dp][lane];
+			fs_pair<PI> (acc, ws, w, cur.x, cur.y, 2*dp);
+			cur = nxt;
+			}
+		// finished: accumulator a <-> o = tb + PI + 2a - 100: element PI of the strip's pair a
+#pragma unroll
+		for (int a=0 ; a<FS_B/2 ; a++) reinterpret_cast<double*> (&outBuf[buf][a][lane])[PI] = acc[a];
+#pragma unroll
+		for (int a=0 ; a<FS_NA - FS_B/2 ; a++) acc[a] = acc[a + FS_B/2];
+#pragma unroll
+		for (int a=FS_NA - FS_B/2 ; a<FS_NA ; a++) acc[a] = 0.0;
+		__syncthreads ();                                          // block b's inputs are consumed and its outputs paired; block b+1's inputs have landed
+		if (b + 2 < NB) fetch (b + 2, buf);
+#pragma unroll
+		for (int kk=0 ; kk<FS_B/4 ; kk++)
+			{
+			const int a = PI * (FS_B/4) + kk, o = tb + 2*a - 50 - FS_LEAD;
+			if ((o < 0) || (o >= S) || idle) continue;
+			const double2 r = outBuf[buf][a][lane];
+			if (!edge) *reinterpret_cast<double2*> (outp + o) = r;
+			else
+				{
+				if ((s0 + o     >= 0) && (s0 + o     < n)) outp[o]     = r.x;
+				if ((s0 + o + 1 >= 0) && (s0 + o + 1 < n)) outp[o + 1] = r.y;
+				}
+			}
+		}
+	}
+
+__global__ __launch_bounds__(FS2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void fir_slide_lds_kernel (FsTable T, FsTaps taps)
+	{
+	__shared__ __attribute__((aligned(16))) double2 inBuf[2][FS_B/2][64];
+	__shared__ __attribute__((aligned(16))) double2 outBuf[2][FS_B/2][64];
+	__shared__ double wLds[51];
+	if (threadIdx.x < 51) wLds[threadIdx.x] = taps.w[threadIdx.x];
+	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	uint32_t   strip = blockIdx.x * 64 + lane;
+	const bool idle  = (strip >= T.strip0[T.nvec]);                // (such a lane walks the table's last strip and stores nothing)
+	if (idle) strip = T.strip0[T.nvec] - 1;
+	uint32_t v = 0;
+	while ((v + 1 < T.nvec) && (T.strip0[v + 1] <= strip)) v++;
+	const double* in  = T.in[v];
+	double*       out = T.out[v];
+	const int64_t n   = (int64_t) T.n[v];
+	const int64_t s0   = (int64_t) (strip - T.strip0[v]) * T.S - FS_SHIFT;
+	const int64_t lo   = s0 - FS_LEAD, hi = lo + (int64_t) T.NB * FS_B;
+	const bool    edge = !((lo >= 0) && (hi <= n));
+	if (wave) fs2_strip<1> (in, out, n, s0, (int) T.S, (int) T.NB, edge, idle, taps, wLds, inBuf, outBuf);
+	else      fs2_strip<0> (in, out, n, s0, (int) T.S, (int) T.NB, edge, idle, taps, wLds, inBuf, outBuf);
+	}
+
 // ------------------------------------------------------------------- host ----
 // GDSP_FIR_SLIDE=1: this kernel for exact W=101 (A/B against the direct kernel; opt-in until measured)
 bool gdsp_fir_slide_wanted (uint64_t bases)
@@ -222,8 +329,11 @@ int gdsp_fir_slide_batch (const gdsp_batch_item* items, int nitems, const double
 		for (int j=k ; j<GDSP_BATCH_MAX ; j++) T.strip0[j+1] = T.strip0[k];
 		T.nvec = (uint32_t) k;
 		if (k == 0) break;
-		const uint32_t blocks = (T.strip0[k] + 127) / 128;
-		hipLaunchKernelGGL (fir_slide_kernel, dim3(blocks), dim3(FS_THREADS), 0, s, T, taps);
+		const char* form = getenv ("GDSP_FIR_SLIDE");
+		if ((form != NULL) && (strcmp (form, "2") == 0))
+			hipLaunchKernelGGL (fir_slide_lds_kernel, dim3((T.strip0[k] + 63) / 64), dim3(FS2_THREADS), 0, s, T, taps);
+		else
+			hipLaunchKernelGGL (fir_slide_kernel, dim3((T.strip0[k] + 127) / 128), dim3(FS_THREADS), 0, s, T, taps);
 		}
 	GDSP_LAUNCH_CHECK ();
 	return GDSP_OK;

@@ -42,9 +42,14 @@ CASES = [(n, kind, 0) for n in SIZES for kind in ("depth", "real", "noise", "odd
       + [(n, kind, strip) for strip in (512, 1024, 4096) for n in (526, 1038, 4110, 65550, 300007) for kind in ("real", "odd")]
 
 
+# GDSP_FIR_SLIDE=1: every lane fetches its own strip; =2: blocks of inputs staged by LDS-DMA a block ahead, outputs paired in LDS
+FORMS = ["1", "2"]
+
+
+@pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("n,kind,strip", CASES)
-def test_sliding_accumulators_give_the_reference_bits(n, kind, strip, gd, monkeypatch):
-    monkeypatch.setenv("GDSP_FIR_SLIDE", "1")
+def test_sliding_accumulators_give_the_reference_bits(n, kind, strip, form, gd, monkeypatch):
+    monkeypatch.setenv("GDSP_FIR_SLIDE", form)
     if strip:
         monkeypatch.setenv("GDSP_FIR_SLIDE_STRIP", str(strip))
     rng = np.random.default_rng(n * 7 + strip)
@@ -54,8 +59,9 @@ def test_sliding_accumulators_give_the_reference_bits(n, kind, strip, gd, monkey
     assert bits_equal(got, want), first_diff(got, want)
 
 
-def test_a_table_of_vectors_in_one_launch(gd, monkeypatch):
-    monkeypatch.setenv("GDSP_FIR_SLIDE", "1")
+@pytest.mark.parametrize("form", FORMS)
+def test_a_table_of_vectors_in_one_launch(form, gd, monkeypatch):
+    monkeypatch.setenv("GDSP_FIR_SLIDE", form)
     monkeypatch.setenv("GDSP_FIR_SLIDE_STRIP", "512")
     rng = np.random.default_rng(3)
     lens = [70001, 1, 0, 513, 40000, 14, 498, 99999, 2, 1024] + [3000 + 17 * i for i in range(30)]      # more than one table of 32
@@ -67,13 +73,14 @@ def test_a_table_of_vectors_in_one_launch(gd, monkeypatch):
         assert bits_equal(o.numpy(), want), (x.size, first_diff(o.numpy(), want))
 
 
-def test_same_bits_as_the_direct_kernel_on_a_whole_chromosome(gd, monkeypatch):
+@pytest.mark.parametrize("form", FORMS)
+def test_same_bits_as_the_direct_kernel_on_a_whole_chromosome(form, gd, monkeypatch):
     """20 Mbp of real-valued coverage: every output equal to the direct kernel's (which the golden vectors and the
     in-run check of bench.py hold to the reference binary)"""
     n = 20_000_003
     v = gd.synth_coverage(SEED, 5, 0, n, 1)
     monkeypatch.setenv("GDSP_FIR_SLIDE", "0")
     direct = gd.smooth(v, 101, mode=gd.FIR_EXACT).numpy()
-    monkeypatch.setenv("GDSP_FIR_SLIDE", "1")
+    monkeypatch.setenv("GDSP_FIR_SLIDE", form)
     slide = gd.smooth(v, 101, mode=gd.FIR_EXACT).numpy()
     assert bits_equal(slide, direct), first_diff(slide, direct)

@@ -8,6 +8,7 @@ import glob
 import json
 import os
 import re
+import subprocess
 import sys
 
 SKIP = ("synth_coverage_kernel", "__amd_rocclr", "fill", "copyBuffer")
@@ -19,9 +20,22 @@ ALGORITHMIC = {"pc_fixup_kernel": None, "pc_hist_chain_kernel": None, "pc_pick_k
                "clump_scan_": None, "clump_bits_": None, "clump_mark_kernel": None, "pc_res_": None, "pc_sample_tab_kernel": 8, "report_scan_kernel": None, "pc_hist_keys_kernel": None,
                "cumsum_offsets_kernel": None, "hf_": None, "window_sum_rows_kernel": None}
 
+
+
+def same_kernels(built):
+    """the build a summary was measured on (`# library:` line, the hash gdsp_version() carries) has the kernels and headers of HEAD"""
+    if not built or built.endswith("-dirty"):
+        return False
+    h = built.split()[-1]
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return subprocess.call(["git", "-C", repo, "diff", "--quiet", h, "HEAD", "--", "genodsp_amd/csrc", "include"],
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) == 0
+
+
 lib = sys.argv[1]
 root = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 kernels = {}
+stale = []
 tag = sys.argv[3] if len(sys.argv) > 3 else "r03"
 for path in sorted(glob.glob(os.path.join(root, tag + "_prof_*.txt"))):
     lines = open(path).read().splitlines()
@@ -29,6 +43,11 @@ for path in sorted(glob.glob(os.path.join(root, tag + "_prof_*.txt"))):
     if not m:
         continue
     bases = int(m.group(2))
+    built = next((l.split(":", 1)[1].strip() for l in lines[:4] if l.startswith("# library:")), None)
+    if not same_kernels(built):
+        # a summary measured on another build than the tree's kernels: refuse (evidence hygiene)
+        stale.append((os.path.basename(path), built))
+        continue
     for line in lines:
         f = line[74:].split()
         if line.startswith("#") or line.startswith("kernel") or len(f) < 6:
@@ -58,6 +77,8 @@ for path in sorted(glob.glob(os.path.join(root, tag + "_prof_*.txt"))):
             entry["algorithmic_bytes"] = per_base * launch_bases
             entry["hbm_bytes_over_algorithmic"] = round((fetch + write) / (per_base * launch_bases), 4)
         kernels[name] = entry
+if stale and not os.environ.get("GDSP_TRAFFIC_ALLOW_STALE"):
+    sys.exit("traffic.json NOT written: these summaries were not measured on library %s: %s" % (lib, stale))
 note = ("HBM bytes per launch over algorithmic bytes, from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (gfx950 "
         "corrections of MI355X_MICROARCH.md applied: FETCH_SIZE doubled, KiB -> bytes); `library` = git hash of the build that was "
         "profiled, so a stale ratio shows in bench.py's roofline.traffic_measured; written by tools/make_traffic.py")

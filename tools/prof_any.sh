@@ -12,10 +12,12 @@ if [ -n "$SQ" ]; then   # SQ=1: two more passes of issue / wait / LDS counters (
 rocprofv3 --kernel-trace --output-format csv -d $out/${op}_sq1 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS -- python3 tools/prof_op.py $op $launches $n > $out/${op}_sq1.log 2>&1 || tail -3 $out/${op}_sq1.log
 rocprofv3 --kernel-trace --output-format csv -d $out/${op}_sq2 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE -- python3 tools/prof_op.py $op $launches $n > $out/${op}_sq2.log 2>&1 || tail -3 $out/${op}_sq2.log
 fi
-python3 - "$out" "$op" "$n" <<'PY' > $out/$op.txt
+lib=$(python3 -c "import genodsp_amd as gd; print(gd.lib().gdsp_version().decode())" 2>/dev/null | tail -1)
+python3 - "$out" "$op" "$n" "$lib" <<'PY' > $out/$op.txt
 import csv, glob, sys, collections
 out, op, n = sys.argv[1], sys.argv[2], int(sys.argv[3])
 print("# %s on %d bases; rocprofv3 --kernel-trace --stats, then --pmc FETCH_SIZE / WRITE_SIZE in separate passes" % (op, n))
+print("# library: %s" % sys.argv[4])
 print("# FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B: MI355X_MICROARCH.md, HBM); units KiB -> bytes")
 stats = {}
 for f in glob.glob(out + "/%s_stats/*/*kernel_stats.csv" % op):

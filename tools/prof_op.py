@@ -70,6 +70,13 @@ RUN = {
     "percentile": lambda: gd.percentile([real], [99000]),
     "report": lambda: gd.report_runs(depth),
 }
+if op in ("percentile_genome", "percentile_binarize_genome"):
+    # the genome-wide call of BASELINE configs[4]: 24 sources, 3.1 Gbp (n is ignored)
+    import bench
+    del depth, real, a, b
+    vecs = [gd.synth_coverage(20240611, c, 0, n_c, 1) for c, (_, n_c) in enumerate(bench.GENOME)]
+    outs = [gd.DeviceVector(v.n) for v in vecs] if op == "percentile_binarize_genome" else None
+    RUN[op] = (lambda: gd.percentile(vecs, [99000])) if outs is None else (lambda: gd.percentile_binarize(vecs, [99000], outs=outs))
 for _ in range(launches):
     RUN[op]()
 gd.sync()
