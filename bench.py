@@ -47,7 +47,7 @@ WORKLOAD_KERNELS = {
     "peaks": {"fused": ["fir_fixed_extrema_kernel<101,9,FMA,true>"],
               "nofuse": ["fir_fixed_kernel<101,9,FMA>", "extrema_blocks_kernel"]},
     "morph": {"fused": ["morph_dilate_erode_kernel"], "nofuse": ["extrema_blocks_kernel", "pointwise_kernel"]},
-    "percentile": {"fused": ["pc_partition_kernel<2, false, true, true>", "pc_res_fixup_tab_kernel"], "nofuse": ["pc_partition_kernel", "pointwise_kernel"]}}
+    "percentile": {"fused": ["pc_partition_tab_kernel<2, false, true, true>", "pc_res_fixup_tab_kernel"], "nofuse": ["pc_partition_tab_kernel", "pointwise_kernel"]}}
 KERNELS = {"hann": "hann_blocks_kernel<101>", "fma": "fir_fixed_kernel<101,9,true>",
            "exact": "fir_fixed_kernel<101,9,false>"}
 

@@ -145,8 +145,6 @@ static void hann_launch (const double* d_in, double* d_out, uint32_t n, const do
 #define HN_RT_SMALL_MAX_W 1701                                  // up to here the 256-thread form is the faster one (measured)
 #define HN_RT_SCAN_MIN_W  1001                                  // from here on it scans its block totals instead of walking them (measured: 801 -4 %, 1001 +4 %, 1501 +20 %)
 #define HN_RT_MAX_NT 512
-#define HN_RT_MID_THREADS 384                                   // the form between: 6144 staged elements, 70 KiB of LDS, two workgroups per CU (twelve waves, like three of 256)
-#define HN_RT_MID_MIN_W   100000                                // (set by measurement)
 #define HN_RT_BIG    768                                        // threads of the long-window form: 12288 staged elements, 122 KiB of LDS
 struct HannRT
 	{
@@ -386,12 +384,12 @@ static int hann_plan_rt (uint32_t W, HannPlanRT** out)
 	memset (pl, 0, sizeof(*pl));
 	pl->device = device;  pl->W = W;
 	const int E = pl->E = hann_direct_taps (W);
-	int THREADS = (W > HN_RT_SMALL_MAX_W)? HN_RT_BIG : (W >= HN_RT_MID_MIN_W)? HN_RT_MID_THREADS : HN_THREADS;   // long windows: bigger tiles (less of each is halo)
-	if (const char* e = getenv ("GDSP_HANN_THREADS"))              // A/B of the forms on one box: 256 | 384 | 768
-		{ const int t = atoi (e);  if ((t == 256) || ((t == HN_RT_MID_THREADS) && (E >= 13)) || (t == HN_RT_BIG)) THREADS = t; }
-	if ((THREADS == HN_THREADS) && (E > 17)) THREADS = HN_RT_MID_THREADS;         // (the 256-thread form is instantiated up to E = 17)
-	if ((THREADS != HN_THREADS) && (E < 13)) THREADS = HN_THREADS;
-	pl->threads = THREADS;
+	// long windows: the big tile, two-level block totals.  Round 4 measured the forms side by side on one box (249 Mbp,
+	// profiles/r04_hann_forms.txt): 256 threads 214 / 186 / 180 Gbases/s at 1001 / 1501 / 1701 taps against 158 / 163 / 167
+	// with 768 (a tile three times as long loses less to its halo, 8 % against 24 % at 1001 taps, but one workgroup of
+	// twelve waves per CU waits at its barriers with nobody to run meanwhile); a 384-thread form (6144 staged elements,
+	// 70 KiB: two workgroups per CU) ran at 123 / 111 / 109.  The threshold stays where it is.
+	const int THREADS = pl->threads = (W > HN_RT_SMALL_MAX_W)? HN_RT_BIG : HN_THREADS;
 	const int H = (int) (W - 1) / 2, DM = (int) W - 2*E - 1, BACK = DM + E;
 	HannRT& K = pl->K;
 	K.DQ = DM / HN_G;  K.DR = DM % HN_G;  K.NT = K.DQ - 1;
@@ -403,7 +401,7 @@ static int hann_plan_rt (uint32_t W, HannPlanRT** out)
 	// needs no spill to keep three waves per SIMD), segmented scans above; the segments need runs of at least 32 blocks,
 	// the long-window form's 64 is what it was tuned with
 	pl->scan = (THREADS > HN_THREADS) || ((W >= HN_RT_SCAN_MIN_W) && (getenv ("GDSP_HANN_WALK") == NULL));   // (GDSP_HANN_WALK: the walk at any window of the 256-thread form, for A/B timing)
-	K.SEG    = (pl->scan && (K.NT >= ((THREADS == HN_RT_BIG)? 64 : 32)))? 32 : 0;
+	K.SEG    = (pl->scan && (K.NT >= ((THREADS > HN_THREADS)? 64 : 32)))? 32 : 0;
 	const double pi = 3.14159265358979323846264;
 	const long   M  = (long) W + 1;
 	auto cs = [&] (long m, double* c, double* sn)
@@ -473,26 +471,25 @@ int gdsp_hann_blocks_apply (const double* d_in, double* d_out, uint32_t n, uint3
 	if (rc != GDSP_OK) return rc;
 	GDSP_REQUIRE ((pl->K.DQ >= 2) && (pl->K.NT + 40 <= HN_RT_MAX_NT) && (pl->K.OUT >= 512) && ((pl->K.LEAD & 1) == 0), "window outside the block-sum kernel's range");
 	const uint32_t ntiles = (uint32_t) (((uint64_t) n + pl->K.OUT - 1) / pl->K.OUT);
-#define HN_RT_GO(EE, TT, SS) hipLaunchKernelGGL ((hann_blocks_rt_kernel<EE, TT, SS>), dim3(ntiles), dim3(TT), 0, s, d_in, d_out, n, ntiles, pl->K, pl->d_rot, d_taps, (int) W)
-#define HN_RT_ANY(EE) do { if (pl->threads == HN_RT_BIG) HN_RT_GO (EE, HN_RT_BIG, true);  else if (pl->threads == HN_RT_MID_THREADS) HN_RT_GO (EE, HN_RT_MID_THREADS, true); \
-                           else if (pl->scan) HN_RT_GO (EE, HN_THREADS, true);  else HN_RT_GO (EE, HN_THREADS, false); } while (0)
-#define HN_RT_LONG(EE) do { if (pl->threads == HN_RT_BIG) HN_RT_GO (EE, HN_RT_BIG, true);  else HN_RT_GO (EE, HN_RT_MID_THREADS, true); } while (0)
+#define HN_RT_SMALL(EE) hipLaunchKernelGGL ((hann_blocks_rt_kernel<EE, HN_THREADS, false>), dim3(ntiles), dim3(HN_THREADS), 0, s, d_in, d_out, n, ntiles, pl->K, pl->d_rot, d_taps, (int) W)
+#define HN_RT_MID(EE)   hipLaunchKernelGGL ((hann_blocks_rt_kernel<EE, HN_THREADS, true>),  dim3(ntiles), dim3(HN_THREADS), 0, s, d_in, d_out, n, ntiles, pl->K, pl->d_rot, d_taps, (int) W)
+#define HN_RT_BIGK(EE)  hipLaunchKernelGGL ((hann_blocks_rt_kernel<EE, HN_RT_BIG, true>),   dim3(ntiles), dim3(HN_RT_BIG),  0, s, d_in, d_out, n, ntiles, pl->K, pl->d_rot, d_taps, (int) W)
 	switch (pl->E)
 		{
-		case 8:  HN_RT_GO (8,  HN_THREADS, false);  break;
-		case 9:  HN_RT_GO (9,  HN_THREADS, false);  break;
-		case 12: HN_RT_GO (12, HN_THREADS, false);  break;
-		case 13: HN_RT_ANY (13);  break;                               // (windows of 1001 taps and more need 13 or more)
-		case 16: HN_RT_ANY (16);  break;
-		case 17: HN_RT_ANY (17);  break;
-		case 20: HN_RT_LONG (20);  break;
-		case 21: HN_RT_LONG (21);  break;
-		case 28: HN_RT_GO (28, HN_RT_BIG, true);  break;
-		default: HN_RT_GO (29, HN_RT_BIG, true);  break;
+		case 8:  HN_RT_SMALL (8);  break;
+		case 9:  HN_RT_SMALL (9);  break;
+		case 12: HN_RT_SMALL (12); break;
+		case 13: if (pl->scan) HN_RT_MID (13); else HN_RT_SMALL (13);  break;      // (windows of 1001 taps and more need 13 or more)
+		case 16: if (pl->scan) HN_RT_MID (16); else HN_RT_SMALL (16);  break;
+		case 17: if (pl->scan) HN_RT_MID (17); else HN_RT_SMALL (17);  break;
+		case 20: HN_RT_BIGK (20);  break;
+		case 21: HN_RT_BIGK (21);  break;
+		case 28: HN_RT_BIGK (28);  break;
+		default: HN_RT_BIGK (29);  break;
 		}
-#undef HN_RT_GO
-#undef HN_RT_ANY
-#undef HN_RT_LONG
+#undef HN_RT_SMALL
+#undef HN_RT_MID
+#undef HN_RT_BIGK
 	GDSP_LAUNCH_CHECK ();
 	return GDSP_OK;
 	}

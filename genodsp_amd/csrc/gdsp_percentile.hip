@@ -126,6 +126,8 @@ void pc_sample_tab_kernel (PcSampleTab T, uint32_t window, double lo, double hi,
 
 // state of the resident route (see pc_res_digit_kernel below)
 #define PC_RES_MAXP   8                                        // percentiles per call
+#define PC_LS_GRID    64                                       // grid keys per percentile (one wave looks them up)
+#define PC_LS_KEYS    8192                                     // keys one workgroup sorts in LDS
 #define PC_RES_BINS   (1 << 13)
 #define PC_RES_SAMPLE 0
 #define PC_RES_CAND   1
@@ -148,6 +150,10 @@ struct PcResident
 	uint64_t scopeLo[PC_RES_MAXP], scopeHi[PC_RES_MAXP], rankIn[PC_RES_MAXP], binCount[PC_RES_MAXP];
 	uint32_t candTop[PC_RES_MAXP];                             // the bits of the scope's keys below their common prefix
 	double   values[PC_RES_MAXP];
+	// the selects in one workgroup's LDS (pc_ls_* below): per percentile a grid of ascending distinct keys across the stretch
+	// its rank lies in, and whether the candidates' answer has been written already
+	uint64_t grid[PC_RES_MAXP][PC_LS_GRID];
+	uint32_t gridN[PC_RES_MAXP], candDone[PC_RES_MAXP];
 #ifdef PC_RES_TIMING
 	unsigned long long dbg[2][5][8];
 #endif
@@ -159,7 +165,8 @@ struct PcResHist                                               // behind the PcR
 	unsigned long long notMin[2], max[2];                      // ~(smallest key counted), largest key counted: zero = nothing counted
 	uint32_t ticket, pad0;
 	unsigned long long localCand;                              // split route: candidates THIS device kept (the counter itself is summed over ranks)
-	uint32_t pad[4];
+	unsigned long long compactCount;                           // pc_ls_cand_pick_kernel: keys kept inside the grid's span
+	uint32_t pad[2];
 	uint32_t slab[1][2][PC_RES_BINS];                          // the shared histogram(s) of the pass in flight: zero between passes
 	};
 struct PcPts { uint32_t v[PC_RES_MAXP];  int n; };
@@ -174,11 +181,13 @@ struct PcPts { uint32_t v[PC_RES_MAXP];  int n; };
 struct PcFuse { double vLo, vHi, one, zero;  double* out;  uint32_t* pos;  unsigned long long* posCount;  uint32_t posCap;
                 int jLo, jHi; };                              // the bracket's ends as pivots of the counting pass (-1: that side is open)
 
+// bid / nblk: this workgroup's number among the workgroups of its source, and how many those are (the whole grid when the
+// launch covers one source; a stretch of it when a table of sources shares one launch, pc_partition_tab_kernel below)
 template <int M, bool BOUNDED, bool DENSE, bool FUSE>
-__global__ __launch_bounds__(PC_THREADS, (M <= 2)? 5 : 1)     // two pivots: five workgroups per CU (the fused form takes 98 registers otherwise: 4 waves per SIMD)
-void pc_partition_kernel (const double* __restrict__ v, uint32_t n, uint32_t window, double lo, double hi, PcPivots P,
-                          unsigned long long* __restrict__ ctr, uint64_t* __restrict__ cand, unsigned long long cap,
-                          uint32_t ntiles, PcFuse F, const PcResident* __restrict__ res)
+__device__ __forceinline__
+void pc_partition_body (const double* __restrict__ v, uint32_t n, uint32_t window, double lo, double hi, PcPivots P,
+                        unsigned long long* __restrict__ ctr, uint64_t* __restrict__ cand, unsigned long long cap,
+                        uint32_t ntiles, PcFuse F, const PcResident* __restrict__ res, const uint32_t bid, const uint32_t nblk)
 	{
 	constexpr int NC = 2*M + 5;                                // counters of this instantiation
 	if (res != NULL)                                           // the resident route: pivots and bracket were decided on the device
@@ -194,10 +203,10 @@ void pc_partition_kernel (const double* __restrict__ v, uint32_t n, uint32_t win
 
 	const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const size_t   npop = DENSE? (size_t) n : ((size_t) n + window - 1) / window;
-	// a workgroup's tiles are blockIdx.x, + gridDim.x, ...: the workgroups in flight read one compact stretch of the vector
+	// a workgroup's tiles are bid, + nblk, ...: the workgroups in flight read one compact stretch of the vector
 	// between them (a workgroup streaming its own contiguous 512 KiB, next tile prefetched, ran at 5.1 TB/s; this way, with the
 	// registers of the prefetch given back for occupancy, 5.5)
-	const uint32_t step = gridDim.x;
+	const uint32_t step = nblk;
 	unsigned long long* candCount = ctr + (size_t) PC_REPL * PC_CTR_WORDS;
 	uint32_t held = 0;                                         // candidates waiting in this wave's buffer (wave uniform)
 	uint32_t cGt[M], cEq[M], cGeLo = 0, cGtHi = 0, cNanPos = 0, cNanNeg = 0, cNegInf = 0;   // per lane
@@ -418,7 +427,7 @@ void pc_partition_kernel (const double* __restrict__ v, uint32_t n, uint32_t win
 				}
 			};
 		const uint32_t whole = (uint32_t) (npop / PC_TILE);
-		uint32_t tile = blockIdx.x;
+		uint32_t tile = bid;
 		double2 A[4], B[4];
 		if (tile < whole) load_half (tile, 0, A);
 		while (tile < whole)
@@ -430,10 +439,10 @@ void pc_partition_kernel (const double* __restrict__ v, uint32_t n, uint32_t win
 			work_half (tile, 1, B);
 			tile = next;
 			}
-		if ((whole < ntiles) && (whole % step == blockIdx.x)) tile_plain (whole);
+		if ((whole < ntiles) && (whole % step == bid)) tile_plain (whole);
 		}
 	else
-		for (uint32_t tile=blockIdx.x ; tile<ntiles ; tile+=step) tile_plain (tile);
+		for (uint32_t tile=bid ; tile<ntiles ; tile+=step) tile_plain (tile);
 	if (held) flush ();
 	if (FUSE && uheld) uflush ();
 
@@ -458,6 +467,34 @@ void pc_partition_kernel (const double* __restrict__ v, uint32_t n, uint32_t win
 		               : (t == 4)? PC_CTR_NEGINF : (t < 5+M)? PC_CTR_GT + (t-5) : PC_CTR_EQ + (t-5-M);
 		if (c) atomicAdd (ctr + (size_t) (blockIdx.x % PC_REPL) * PC_CTR_WORDS + slot, c);
 		}
+	}
+
+// The launch covers up to PC_TAB sources: source i owns workgroups block0[i] .. block0[i+1]-1, which walk its tiles
+// exactly as the launch of its own would.  24 launches of 130 Mbp each ramp up and drain 24 times (4.8 TB/s over the
+// genome where one chromosome-sized launch reaches 5.2 under the profiler); here the next source's first workgroups start
+// while the last ones of the source before are still counting.
+struct PcCountTab
+	{
+	const double*       v[PC_TAB];
+	double*             out[PC_TAB];                               // FUSE: the binarized signal
+	uint32_t*           pos[PC_TAB];                               // ... the strip of undecided positions, its count and its capacity
+	unsigned long long* posCount[PC_TAB];
+	uint32_t            posCap[PC_TAB];
+	uint32_t            n[PC_TAB], ntiles[PC_TAB];
+	uint32_t            block0[PC_TAB + 1];
+	int                 nsrc;
+	};
+template <int M, bool BOUNDED, bool DENSE, bool FUSE>
+__global__ __launch_bounds__(PC_THREADS, (M <= 2)? 5 : 1)     // two pivots: five workgroups per CU (the fused form takes 98 registers otherwise: 4 waves per SIMD)
+void pc_partition_tab_kernel (PcCountTab T, uint32_t window, double lo, double hi, PcPivots P,
+                              unsigned long long* __restrict__ ctr, uint64_t* __restrict__ cand, unsigned long long cap,
+                              PcFuse F, const PcResident* __restrict__ res)
+	{
+	int i = 0;
+	while ((i + 1 < T.nsrc) && (T.block0[i + 1] <= blockIdx.x)) i++;        // (scalar: a few compares per workgroup of up to 16 tiles)
+	if (FUSE) { F.out = T.out[i];  F.pos = T.pos[i];  F.posCount = T.posCount[i];  F.posCap = T.posCap[i]; }
+	pc_partition_body<M, BOUNDED, DENSE, FUSE> (T.v[i], T.n[i], window, lo, hi, P, ctr, cand, cap, T.ntiles[i], F, res,
+	                                            blockIdx.x - T.block0[i], T.block0[i + 1] - T.block0[i]);
 	}
 
 // one digit histogram over a short list of keys, restricted to keyLo <= key <= keyHi
@@ -919,6 +956,358 @@ void pc_res_digit_kernel (const uint64_t* __restrict__ keys, const unsigned long
 #endif
 	}
 
+// ---- the selects of the resident route in a workgroup's LDS (one device, nobody to reduce with).  A radix select over a
+// list costs a launch per digit, each with a histogram to merge and a decision by the last workgroup: ten launches of
+// 21 us in a 249 Mbp call whose counting pass takes 380 (profiles/r04_prof_percentile.txt).  But neither stage needs the
+// digits.  The SUBSAMPLE only has to yield two keys either side of the target rank: one workgroup sorts a strided 8192 of
+// its keys in LDS (pc_ls_sub_kernel) and lays a grid of <= 64 of them across four standard deviations either side of
+// the rank; one pass over all the keys then counts them per grid cell (pc_ls_grid_kernel: a binary search per key, a few
+// counters per workgroup, no histogram), and the last workgroup takes as the bracket the nearest grid keys outside the
+// ranks the digit passes used to chase -- a cell wider at most on either side.  The CANDIDATES' answer is an exact order
+// statistic: the same sort and grid over a strided 8192 of the candidates in scope (a list that short is answered on the
+// spot), then one pass that counts the cells AND keeps what lies within the grid's span; the last workgroup knows the
+// cell that holds the rank (a grid key itself when the rank falls on its ties), gathers that cell's keys from what was
+// kept, sorts them in LDS and reads the answer off.  Four launches instead of ten per percentile -- two plus two per
+// further percentile.  What the grids miss (a rank outside four standard deviations, a cell too big for LDS, a list kept
+// past its capacity) marks the percentile for the plain route (how = 2), like a rank outside its bracket always has.
+__device__ __forceinline__ void pc_ls_sort (uint64_t* a, int n)       // bitonic, ascending; n a power of two <= PC_LS_KEYS; ends with the workgroup in step
+	{
+	for (int k=2 ; k<=n ; k<<=1)
+		for (int j=k>>1 ; j>0 ; j>>=1)
+			{
+			for (int t=threadIdx.x ; t<n/2 ; t+=PC_RES_THREADS)
+				{
+				const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+				const uint64_t x = a[i], y = a[i + j];
+				const bool up = ((i & k) == 0);
+				if ((x > y) == up) { a[i] = y;  a[i + j] = x; }
+				}
+			__syncthreads ();
+			}
+	}
+
+// a strided share of `keys` (those within [keyLo, keyHi], PC_NO_KEY skipped) into LDS, sorted; returns how many, and the
+// stride in *strideOut.  a[] holds PC_LS_KEYS words; sCount is a word of LDS.
+__device__ __forceinline__ int pc_ls_gather_sorted (uint64_t* a, uint32_t* sCount, const uint64_t* __restrict__ keys, unsigned long long count,
+                                                    uint64_t keyLo, uint64_t keyHi, unsigned long long* strideOut)
+	{
+	const unsigned long long stride = (count + PC_LS_KEYS - 1) / PC_LS_KEYS;
+	if (threadIdx.x == 0) *sCount = 0;
+	__syncthreads ();
+	const unsigned long long picks = (stride == 0)? 0 : (count + stride - 1) / stride;
+	for (unsigned long long i=threadIdx.x ; i<picks ; i+=PC_RES_THREADS)
+		{
+		const uint64_t key = keys[i * stride];
+		if ((key != PC_NO_KEY) && (key >= keyLo) && (key <= keyHi)) a[atomicAdd (sCount, 1u)] = key;
+		}
+	__syncthreads ();
+	const int m = (int) *sCount;
+	int n = 2;
+	while (n < m) n <<= 1;
+	for (int i=m+threadIdx.x ; i<n ; i+=PC_RES_THREADS) a[i] = ~0ULL;
+	__syncthreads ();
+	pc_ls_sort (a, n);
+	*strideOut = stride;
+	return m;
+	}
+
+// wave `w` lays percentile w's grid: <= PC_LS_GRID ascending distinct keys of the sorted a[0..m) at even steps of rank
+// from rLo to rHi (lane g: rank rLo + g (rHi - rLo) / 63)
+__device__ __forceinline__ void pc_ls_lay_grid (const uint64_t* a, long long rLo, long long rHi, uint64_t* __restrict__ grid, uint32_t* __restrict__ gridN)
+	{
+	const int lane = threadIdx.x & 63;
+	const long long r = rLo + ((rHi - rLo) * lane) / (PC_LS_GRID - 1);
+	const uint64_t key = a[r];
+	const uint64_t prev = (uint64_t) __shfl_up ((unsigned long long) key, 1, 64);
+	const uint64_t keep = __ballot ((lane == 0) || (key != prev));
+	if ((keep >> lane) & 1) grid[__popcll (keep & ((1ULL << lane) - 1))] = key;
+	if (lane == 0) *gridN = (uint32_t) __popcll (keep);
+	}
+
+// SAMPLE stage, first launch: one workgroup.  Grids for every percentile from a strided 8192 of the subsample.
+__global__ __launch_bounds__(PC_RES_THREADS)
+void pc_ls_sub_kernel (const uint64_t* __restrict__ keys, unsigned long long slots, PcPts pts, PcResident* __restrict__ R)
+	{
+	__shared__ uint64_t a[PC_LS_KEYS];
+	__shared__ uint32_t sCount;
+	if (R->status != PC_RES_OK) return;
+	unsigned long long stride;
+	const int m = pc_ls_gather_sorted (a, &sCount, keys, slots, 0, ~0ULL, &stride);
+	const int wave = threadIdx.x >> 6;
+	if (wave >= pts.n) return;
+	if (m == 0) { if ((threadIdx.x & 63) == 0) R->gridN[wave] = 0;  return; }
+	const double pp = pts.v[wave] / 100000.0;
+	const double ks = floor ((double) m * pp);
+	const double dl = ceil (4.0 * sqrt ((double) m * pp * (1.0 - pp))) + 8.0;
+	long long rLo = (long long) (ks - dl), rHi = (long long) (ks + dl);
+	if (rLo < 0) rLo = 0;
+	if (rHi > m - 1) rHi = m - 1;
+	pc_ls_lay_grid (a, rLo, rHi, R->grid[wave], &R->gridN[wave]);
+	}
+
+// the cell of a key in an ascending grid of gn distinct keys: j = how many grid keys lie below it; *onKey: it IS grid key j
+__device__ __forceinline__ int pc_ls_cell (const uint64_t* grid, int gn, uint64_t key, bool* onKey)
+	{
+	int lo = 0, hi = gn;
+	while (lo < hi) { const int mid = (lo + hi) >> 1;  if (grid[mid] < key) lo = mid + 1;  else hi = mid; }
+	*onKey = (lo < gn) && (grid[lo] == key);
+	return lo;
+	}
+
+// cell counters of percentile i in the shared slab (zero between launches, like the digit passes' histograms):
+// open[j] = keys strictly between grid keys j-1 and j (j = 0..gn), on[j] = keys equal to grid key j
+#define PC_LS_CELLS (PC_LS_GRID + 1)
+__device__ __forceinline__ uint32_t* pc_ls_open (PcResHist* H, int i) { return &H->slab[0][0][(2*i)     * PC_LS_CELLS]; }
+__device__ __forceinline__ uint32_t* pc_ls_on   (PcResHist* H, int i) { return &H->slab[0][0][(2*i + 1) * PC_LS_CELLS]; }
+
+// the last workgroup of a launch (the digit passes' arrival ticket): true in every thread of it, with the other
+// workgroups' adds visible
+__device__ __forceinline__ bool pc_ls_last (PcResHist* H, uint32_t* sLast)
+	{
+	asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads ();
+	if (threadIdx.x == 0)
+		{
+		__threadfence ();
+		const uint32_t t = __hip_atomic_fetch_add (&H->ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+		*sLast = (t == gridDim.x - 1)? 1 : 0;
+		}
+	__syncthreads ();
+	if (!*sLast) return false;
+	__builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "agent");
+	return true;
+	}
+
+// SAMPLE stage, second launch: every key of the subsample into its cell of every percentile's grid; the last workgroup
+// turns the counts into brackets (what digit 0's rank decision and the last digit's pick did: pc_res_digit_kernel).
+__global__ __launch_bounds__(PC_RES_THREADS)
+void pc_ls_grid_kernel (const uint64_t* __restrict__ keys, unsigned long long slots, PcPts pts, PcResident* __restrict__ R, PcResHist* __restrict__ H)
+	{
+	__shared__ uint64_t grid[PC_RES_MAXP][PC_LS_GRID];
+	__shared__ uint32_t gn[PC_RES_MAXP];
+	__shared__ uint32_t cOpen[PC_RES_MAXP][PC_LS_CELLS], cOn[PC_RES_MAXP][PC_LS_CELLS];
+	__shared__ uint32_t sLast;
+	if (R->status != PC_RES_OK) return;
+	const int np = pts.n, p = threadIdx.x, lane = p & 63, wave = p >> 6;
+	for (int q=p ; q<np*PC_LS_GRID ; q+=PC_RES_THREADS) grid[q / PC_LS_GRID][q % PC_LS_GRID] = R->grid[q / PC_LS_GRID][q % PC_LS_GRID];
+	if (p < np) gn[p] = R->gridN[p];
+	for (int q=p ; q<np*PC_LS_CELLS ; q+=PC_RES_THREADS) { cOpen[q / PC_LS_CELLS][q % PC_LS_CELLS] = 0;  cOn[q / PC_LS_CELLS][q % PC_LS_CELLS] = 0; }
+	__syncthreads ();
+	const size_t stride = (size_t) gridDim.x * PC_RES_THREADS;
+	for (size_t i = (size_t) blockIdx.x * PC_RES_THREADS + p ; i < slots ; i += 16*stride)
+		{
+		uint64_t k[16];
+#pragma unroll
+		for (int u=0 ; u<16 ; u++) k[u] = (i + u*stride < slots)? keys[i + u*stride] : PC_NO_KEY;
+#pragma unroll
+		for (int u=0 ; u<16 ; u++)
+			{
+			if (k[u] == PC_NO_KEY) continue;
+			for (int w=0 ; w<np ; w++)
+				{
+				bool onKey;
+				const int j = pc_ls_cell (grid[w], (int) gn[w], k[u], &onKey);
+				atomicAdd (onKey? &cOn[w][j] : &cOpen[w][j], 1u);
+				}
+			}
+		}
+	__syncthreads ();
+	for (int q=p ; q<np*PC_LS_CELLS ; q+=PC_RES_THREADS)
+		{
+		const int w = q / PC_LS_CELLS, j = q % PC_LS_CELLS;
+		if (cOpen[w][j]) atomicAdd (&pc_ls_open (H, w)[j], cOpen[w][j]);
+		if (cOn[w][j])   atomicAdd (&pc_ls_on (H, w)[j],   cOn[w][j]);
+		}
+	if (!pc_ls_last (H, &sLast)) return;
+
+	// ---- the last workgroup: wave w settles percentile w.  Lane j holds cell j (lane 63 cells 63 and 64).
+	if (wave < np)
+		{
+		const int g = (int) gn[wave];
+		const uint32_t* o = pc_ls_open (H, wave);
+		const uint32_t* e = pc_ls_on (H, wave);
+		unsigned long long mine = (unsigned long long) o[lane] + e[lane];              // cell `lane`: its open stretch, then its key's ties
+		const unsigned long long tail = (lane == 63)? o[64] : 0;                       // (above the last grid key)
+		unsigned long long incl = mine;
+		for (int d=1 ; d<64 ; d*=2) { const unsigned long long up = __shfl_up (incl, d, 64);  if (lane >= d) incl += up; }
+		const unsigned long long total = __shfl (incl, 63, 64) + __shfl (tail, 63, 64);
+		const unsigned long long below = incl - mine + o[lane];                         // keys strictly below grid key `lane`
+		const unsigned long long upto  = incl;                                          // keys at or below it
+		const double pp = pts.v[wave] / 100000.0;
+		const double ks = floor ((double) total * pp);
+		const double dl = ceil (4.0 * sqrt ((double) total * pp * (1.0 - pp))) + 16.0;
+		const bool v0 = (total >= 256) && (ks - dl >= 0.0), v1 = (total >= 256) && (ks + dl <= (double) total - 1);
+		const unsigned long long kLo = v0? (unsigned long long) (ks - dl) : 0, kHi = v1? (unsigned long long) (ks + dl) : 0;
+		// low end: the largest grid key with no more than kLo keys below it (the key of rank kLo is then at or above it)
+		const uint64_t okLo = __ballot (v0 && (lane < g) && (below <= kLo));
+		// high end: the smallest grid key with more than kHi keys at or below it
+		const uint64_t okHi = __ballot (v1 && (lane < g) && (upto >= kHi + 1));
+		if (lane == 0)
+			{
+			if (wave == 0) { R->sTotal = total;  if (total < 256) R->status = PC_RES_FEW; }
+			R->openLo[wave] = (okLo != 0)? 0 : 1;  R->openHi[wave] = (okHi != 0)? 0 : 1;
+			if (okLo != 0) R->bLo[wave] = grid[wave][63 - __builtin_clzll (okLo)];
+			if (okHi != 0) R->bHi[wave] = grid[wave][__builtin_ctzll (okHi)];
+			}
+		}
+	__syncthreads ();
+	for (int q=p ; q<np*2*PC_LS_CELLS ; q+=PC_RES_THREADS) H->slab[0][0][q] = 0;
+	if (p == 0) H->ticket = 0;
+	}
+
+// CAND stage, first launch: one workgroup.  A strided 8192 of percentile `which`'s candidates in scope, sorted; a list
+// that short is the whole list and the answer is read off; otherwise a grid around where the rank should fall.
+__global__ __launch_bounds__(PC_RES_THREADS)
+void pc_ls_cand_sub_kernel (const uint64_t* __restrict__ keys, const unsigned long long* __restrict__ countPtr, unsigned long long countCap,
+                            int which, PcResident* __restrict__ R)
+	{
+	__shared__ uint64_t a[PC_LS_KEYS];
+	__shared__ uint32_t sCount;
+	if ((R->status != PC_RES_OK) || (R->how[which] != 1)) return;
+	unsigned long long count = *countPtr;
+	if (count > countCap) count = countCap;
+	const uint64_t keyLo = R->scopeLo[which], keyHi = R->scopeHi[which];
+	const unsigned long long rank = R->rankIn[which], inBin = R->binCount[which];
+	unsigned long long stride;
+	const int m = pc_ls_gather_sorted (a, &sCount, keys, count, keyLo, keyHi, &stride);
+	if (stride <= 1)                                               // every candidate was looked at
+		{
+		if (threadIdx.x == 0)
+			{
+			if (((unsigned long long) m != inBin) || (rank >= inBin)) R->status = PC_RES_DISAGREE;
+			else { R->values[which] = gdsp_value_of (a[rank]);  R->candDone[which] = 1; }
+			}
+		return;
+		}
+	if (threadIdx.x >= 64) return;
+	if (m < 2) { if (threadIdx.x == 0) R->how[which] = 2;  return; }   // (nothing to lay a grid on: the plain route)
+	const double q  = (double) rank / (double) inBin;
+	const double ks = floor ((double) m * q);
+	const double dl = ceil (4.0 * sqrt ((double) m * q * (1.0 - q))) + 8.0;
+	long long rLo = (long long) (ks - dl), rHi = (long long) (ks + dl);
+	if (rLo < 0) rLo = 0;
+	if (rHi > m - 1) rHi = m - 1;
+	pc_ls_lay_grid (a, rLo, rHi, R->grid[which], &R->gridN[which]);
+	}
+
+// CAND stage, second launch: the candidates in scope counted per cell, those within the grid's span kept (`kept`, up to
+// keptCap keys); the last workgroup finds the cell of the rank and sorts its keys.
+__global__ __launch_bounds__(PC_RES_THREADS)
+void pc_ls_cand_pick_kernel (const uint64_t* __restrict__ keys, const unsigned long long* __restrict__ countPtr, unsigned long long countCap,
+                             int which, PcResident* __restrict__ R, PcResHist* __restrict__ H, uint64_t* __restrict__ kept, unsigned long long keptCap)
+	{
+	__shared__ uint64_t a[PC_LS_KEYS];
+	__shared__ uint64_t grid[PC_LS_GRID];
+	__shared__ uint32_t cOpen[PC_LS_CELLS], cOn[PC_LS_CELLS];
+	__shared__ uint32_t sLast, sCount;
+	__shared__ long long sCell;
+	__shared__ unsigned long long sBefore;
+	if ((R->status != PC_RES_OK) || (R->how[which] != 1) || R->candDone[which]) return;
+	const int p = threadIdx.x, lane = p & 63;
+	const int g = (int) R->gridN[which];
+	if (p < PC_LS_GRID) grid[p] = (p < g)? R->grid[which][p] : ~0ULL;
+	if (p < PC_LS_CELLS) { cOpen[p] = 0;  cOn[p] = 0; }
+	__syncthreads ();
+	unsigned long long count = *countPtr;
+	if (count > countCap) count = countCap;
+	const uint64_t keyLo = R->scopeLo[which], keyHi = R->scopeHi[which];
+	const uint64_t spanLo = grid[0], spanHi = grid[g - 1];
+	const size_t stride = (size_t) gridDim.x * PC_RES_THREADS;
+	for (size_t i = (size_t) blockIdx.x * PC_RES_THREADS + p ; i < count ; i += 8*stride)
+		{
+		uint64_t k[8];
+#pragma unroll
+		for (int u=0 ; u<8 ; u++) k[u] = (i + u*stride < count)? keys[i + u*stride] : PC_NO_KEY;
+#pragma unroll
+		for (int u=0 ; u<8 ; u++)
+			{
+			const bool in = (k[u] != PC_NO_KEY) && (k[u] >= keyLo) && (k[u] <= keyHi);
+			bool onKey = false;
+			if (in)
+				{
+				const int j = pc_ls_cell (grid, g, k[u], &onKey);
+				atomicAdd (onKey? &cOn[j] : &cOpen[j], 1u);
+				}
+			const bool keep = in && !onKey && (k[u] > spanLo) && (k[u] < spanHi);
+			const uint64_t mask = __ballot (keep);
+			if (mask != 0)
+				{
+				unsigned long long base = 0;
+				if (lane == 0) base = atomicAdd (&H->compactCount, (unsigned long long) __popcll (mask));
+				base = __shfl (base, 0, 64);
+				const unsigned long long at = base + __popcll (mask & ((1ULL << lane) - 1));
+				if (keep && (at < keptCap)) kept[at] = k[u];
+				}
+			}
+		}
+	__syncthreads ();
+	if (p < PC_LS_CELLS)
+		{
+		if (cOpen[p]) atomicAdd (&pc_ls_open (H, 0)[p], cOpen[p]);
+		if (cOn[p])   atomicAdd (&pc_ls_on (H, 0)[p],   cOn[p]);
+		}
+	if (!pc_ls_last (H, &sLast)) return;
+
+	// ---- the last workgroup: the cell of the rank (wave 0), then its keys
+	const unsigned long long rank = R->rankIn[which], inBin = R->binCount[which];
+	if (p < 64)
+		{
+		const uint32_t* o = pc_ls_open (H, 0);
+		const uint32_t* e = pc_ls_on (H, 0);
+		const unsigned long long mine = (unsigned long long) o[lane] + e[lane], tail = (lane == 63)? o[64] : 0;
+		unsigned long long incl = mine;
+		for (int d=1 ; d<64 ; d*=2) { const unsigned long long up = __shfl_up (incl, d, 64);  if (lane >= d) incl += up; }
+		const unsigned long long total = __shfl (incl, 63, 64) + __shfl (tail, 63, 64);
+		const unsigned long long before = incl - mine;                                  // keys below cell `lane`'s open stretch
+		const bool inOpen = (rank >= before) && (rank < before + o[lane]);
+		const bool onKey  = (lane < g) && (rank >= before + o[lane]) && (rank < incl);
+		const uint64_t mOpen = __ballot (inOpen), mOn = __ballot (onKey);
+		if (lane == 0)
+			{
+			sCell = -1;  sBefore = 0;
+			if (total != inBin) R->status = PC_RES_DISAGREE;
+			else if (mOn != 0) { R->values[which] = gdsp_value_of (grid[__builtin_ctzll (mOn)]);  R->candDone[which] = 1; }
+			else if ((mOpen != 0) && (__builtin_ctzll (mOpen) >= 1) && (__builtin_ctzll (mOpen) < g)
+			         && (H->compactCount <= keptCap)) sCell = (long long) __builtin_ctzll (mOpen);
+			else R->how[which] = 2;                                // beyond the grid's span, or more kept than there was room for
+			}
+		if (inOpen && (mOn == 0)) sBefore = before;
+		}
+	__syncthreads ();
+	const long long cell = sCell;
+	if (cell >= 1)                                                 // (uniform)
+		{
+		const uint64_t lo = grid[cell - 1], hi = grid[cell];       // the cell's keys lie strictly between
+		const unsigned long long nkept = H->compactCount, want = pc_ls_open (H, 0)[cell];
+		if (want > PC_LS_KEYS) { if (p == 0) R->how[which] = 2; }
+		else
+			{
+			if (p == 0) sCount = 0;
+			__syncthreads ();
+			for (unsigned long long i=p ; i<nkept ; i+=PC_RES_THREADS)
+				{
+				const uint64_t key = kept[i];
+				if ((key > lo) && (key < hi)) { const uint32_t at = atomicAdd (&sCount, 1u);  if (at < PC_LS_KEYS) a[at] = key; }
+				}
+			__syncthreads ();
+			const int m = (int) sCount;
+			if ((unsigned long long) m != want) { if (p == 0) R->status = PC_RES_DISAGREE; }
+			else
+				{
+				int n = 2;
+				while (n < m) n <<= 1;
+				for (int i=m+p ; i<n ; i+=PC_RES_THREADS) a[i] = ~0ULL;
+				__syncthreads ();
+				pc_ls_sort (a, n);
+				if (p == 0) { R->values[which] = gdsp_value_of (a[rank - sBefore]);  R->candDone[which] = 1; }
+				}
+			}
+		}
+	__syncthreads ();
+	if (p < 2*PC_LS_CELLS) H->slab[0][0][p] = 0;
+	if (p == 0) { H->ticket = 0;  H->compactCount = 0; }
+	}
+
 // the pivots of the counting pass out of every percentile's bracket (host: pc_run, the end of step 2)
 __global__ void pc_res_pivots_kernel (PcResident* __restrict__ R, int np, int fuseWhich)
 	{
@@ -1119,6 +1508,9 @@ static PcDevice   pcDev[64];
 static int        pcDevLen = 0;
 static std::mutex pcLock;
 
+#define PC_RES_CTR_AT       ((PC_RES_STATE_BYTES + sizeof(PcResHist) + 255) / 256 * 256)
+#define PC_RES_POSCOUNT_AT  ((PC_RES_CTR_AT + PC_CTR_SPLIT * sizeof(uint64_t) + 255) / 256 * 256)
+#define PC_RES_BLOCK_BYTES  (PC_RES_POSCOUNT_AT + PC_MAX_FUSED_SOURCES * sizeof(unsigned long long))
 static int pc_device (int device, size_t sampleCap, size_t candCap, PcDevice** out)
 	{
 	PcDevice* d = NULL;
@@ -1130,11 +1522,15 @@ static int pc_device (int device, size_t sampleCap, size_t candCap, PcDevice** o
 		memset (d, 0, sizeof(*d));
 		d->device = device;
 		GDSP_HIP_TRY (hipMalloc ((void**) &d->hist, PC_HIST_WORDS * sizeof(uint64_t)));
-		GDSP_HIP_TRY (hipMalloc ((void**) &d->ctr,  PC_CTR_SPLIT * sizeof(uint64_t)));
 		GDSP_HIP_TRY (hipMalloc ((void**) &d->tmp,  PC_TMP_WORDS * sizeof(uint64_t)));
-		GDSP_HIP_TRY (hipMalloc ((void**) &d->posCount, PC_MAX_FUSED_SOURCES * sizeof(unsigned long long)));
 		GDSP_HIP_TRY (hipMalloc ((void**) &d->chain, sizeof(PcChain)));
-		GDSP_HIP_TRY (hipMalloc ((void**) &d->res, PC_RES_STATE_BYTES + sizeof(PcResHist)));
+		// the resident route's state, the digit passes' histograms, the counting pass's counters and the strips' counts in
+		// ONE block: the route clears them with one fill (three fills of 4.5 us each were a twentieth of a 249 Mbp call)
+		char* block = NULL;
+		GDSP_HIP_TRY (hipMalloc ((void**) &block, PC_RES_BLOCK_BYTES));
+		d->res      = reinterpret_cast<PcResident*> (block);
+		d->ctr      = reinterpret_cast<uint64_t*> (block + PC_RES_CTR_AT);
+		d->posCount = reinterpret_cast<unsigned long long*> (block + PC_RES_POSCOUNT_AT);
 		}
 	if (d->sampleCap < sampleCap)
 		{
@@ -1461,50 +1857,75 @@ static int pc_count_launch (PcJob& J, const PcPivots& P, int mUse, bool bounded,
 	for (size_t d=0 ; d<J.devices.size () ; d++)
 		{
 		GDSP_HIP_TRY (hipSetDevice (J.devices[d]));
-		GDSP_HIP_TRY (hipMemsetAsync (J.scratch[d]->ctr, 0, PC_CTR_SPLIT * sizeof(uint64_t), gdsp_stream (J.stream[d])));
-		GDSP_HIP_TRY (hipMemsetAsync (J.scratch[d]->posCount, 0, PC_MAX_FUSED_SOURCES * sizeof(unsigned long long), gdsp_stream (J.stream[d])));
+		if (!resident)                                              // (the resident route cleared them with its state)
+			{
+			GDSP_HIP_TRY (hipMemsetAsync (J.scratch[d]->ctr, 0, PC_CTR_SPLIT * sizeof(uint64_t), gdsp_stream (J.stream[d])));
+			GDSP_HIP_TRY (hipMemsetAsync (J.scratch[d]->posCount, 0, PC_MAX_FUSED_SOURCES * sizeof(unsigned long long), gdsp_stream (J.stream[d])));
+			}
 		unsigned long long* ctr = (unsigned long long*) J.scratch[d]->ctr;
 		const PcResident* RES = resident? J.scratch[d]->res : NULL;
-		for (int i=0 ; i<J.nsrc ; i++)
+		hipStream_t st = gdsp_stream (J.stream[d]);
+		// GDSP_PERCENTILE_COUNT_PER_SOURCE=1: a launch per source (what rounds 2 and 3 measured), for the A/B on one box
+		const char* perSourceEnv = getenv ("GDSP_PERCENTILE_COUNT_PER_SOURCE");
+		const bool  perSource = (perSourceEnv != NULL) && (strcmp (perSourceEnv, "0") != 0);
+		// sources of one flavour (fused / dense / strided) share a launch, up to PC_TAB at a time
+		for (int flavour=0 ; flavour<3 ; flavour++)
 			{
-			if ((J.src[i].device != J.devices[d]) || (J.src[i].n == 0)) continue;
-			hipStream_t st = gdsp_stream (J.stream[d]);
-			const size_t   p      = ((size_t) J.src[i].n + J.window - 1) / J.window;
-			const uint32_t ntiles = (uint32_t) ((p + PC_TILE - 1) / PC_TILE);
-			const uint32_t perWG  = std::max<uint32_t> (1, std::min<uint32_t> (PC_TILES_PER_WG, ntiles / PC_MIN_WGS));
-			const uint32_t blocks = (ntiles + perWG - 1) / perWG;
-			const bool     dense  = (J.window == 1) && gdsp_aligned16 (J.src[i].d_v);
-			const bool     fused  = (J.fusedSource[i] >= 0) && fuseUsable;
+			PcCountTab T;
+			memset (&T, 0, sizeof(T));
 			PcFuse F;
 			memset (&F, 0, sizeof(F));
-			if (fused)
+			auto go = [&] ()
 				{
-				F.vLo = J.vLo;  F.vHi = J.vHi;  F.one = J.fuse->one;  F.zero = J.fuse->zero;  F.out = J.fuse->d_out[i];
-				F.pos = J.scratch[d]->pos + J.posOffset[i];  F.posCount = J.scratch[d]->posCount + J.fusedSource[i];
-				F.posCap = (uint32_t) J.posCap[i];
-				F.jLo = fuseJLo;  F.jHi = fuseJHi;
-				J.fusedAny = true;
-				}
-			else J.fusedSource[i] = -1;
+				if (T.nsrc == 0) return;
+				const uint32_t blocks = T.block0[T.nsrc];
+				const bool fused = (flavour == 0), dense = (flavour == 1);
 #define PC_LAUNCH_B(MM, BB)                                                                                                    \
-			do { if (fused) hipLaunchKernelGGL ((pc_partition_kernel<MM, BB, true, true>),  dim3(blocks), dim3(PC_THREADS), 0,    \
-			                                     st, J.src[i].d_v, J.src[i].n, J.window, J.lo, J.hi, P, ctr, \
-			                                     J.scratch[d]->cand, (unsigned long long) J.scratch[d]->candCap, ntiles, F, RES);  \
-			     else if (dense) hipLaunchKernelGGL ((pc_partition_kernel<MM, BB, true, false>),  dim3(blocks), dim3(PC_THREADS), 0, \
-			                                     st, J.src[i].d_v, J.src[i].n, J.window, J.lo, J.hi, P, ctr, \
-			                                     J.scratch[d]->cand, (unsigned long long) J.scratch[d]->candCap, ntiles, F, RES);  \
-			     else       hipLaunchKernelGGL ((pc_partition_kernel<MM, BB, false, false>), dim3(blocks), dim3(PC_THREADS), 0,   \
-			                                     st, J.src[i].d_v, J.src[i].n, J.window, J.lo, J.hi, P, ctr, \
-			                                     J.scratch[d]->cand, (unsigned long long) J.scratch[d]->candCap, ntiles, F, RES); } while (0)
+				do { if (fused) hipLaunchKernelGGL ((pc_partition_tab_kernel<MM, BB, true, true>),  dim3(blocks), dim3(PC_THREADS), 0, \
+				                                     st, T, J.window, J.lo, J.hi, P, ctr,                                            \
+				                                     J.scratch[d]->cand, (unsigned long long) J.scratch[d]->candCap, F, RES);        \
+				     else if (dense) hipLaunchKernelGGL ((pc_partition_tab_kernel<MM, BB, true, false>),  dim3(blocks), dim3(PC_THREADS), 0, \
+				                                     st, T, J.window, J.lo, J.hi, P, ctr,                                            \
+				                                     J.scratch[d]->cand, (unsigned long long) J.scratch[d]->candCap, F, RES);        \
+				     else       hipLaunchKernelGGL ((pc_partition_tab_kernel<MM, BB, false, false>), dim3(blocks), dim3(PC_THREADS), 0, \
+				                                     st, T, J.window, J.lo, J.hi, P, ctr,                                            \
+				                                     J.scratch[d]->cand, (unsigned long long) J.scratch[d]->candCap, F, RES); } while (0)
 #define PC_LAUNCH(MM) do { if (bounded) PC_LAUNCH_B (MM, true);  else PC_LAUNCH_B (MM, false); } while (0)
-			*padded += (uint64_t) ntiles * PC_TILE;
-			if      (mUse <= 2)  PC_LAUNCH (2);
-			else if (mUse <= 4)  PC_LAUNCH (4);
-			else if (mUse <= 8)  PC_LAUNCH (8);
-			else if (mUse <= 16) PC_LAUNCH (16);
-			else                PC_LAUNCH (32);
+				if      (mUse <= 2)  PC_LAUNCH (2);
+				else if (mUse <= 4)  PC_LAUNCH (4);
+				else if (mUse <= 8)  PC_LAUNCH (8);
+				else if (mUse <= 16) PC_LAUNCH (16);
+				else                PC_LAUNCH (32);
 #undef PC_LAUNCH_B
 #undef PC_LAUNCH
+				T.nsrc = 0;
+				};
+			for (int i=0 ; i<J.nsrc ; i++)
+				{
+				if ((J.src[i].device != J.devices[d]) || (J.src[i].n == 0)) continue;
+				const size_t   p      = ((size_t) J.src[i].n + J.window - 1) / J.window;
+				const uint32_t ntiles = (uint32_t) ((p + PC_TILE - 1) / PC_TILE);
+				const uint32_t perWG  = std::max<uint32_t> (1, std::min<uint32_t> (PC_TILES_PER_WG, ntiles / PC_MIN_WGS));
+				const uint32_t blocks = (ntiles + perWG - 1) / perWG;
+				const bool     dense  = (J.window == 1) && gdsp_aligned16 (J.src[i].d_v);
+				const bool     fused  = (J.fusedSource[i] >= 0) && fuseUsable;
+				if ((fused? 0 : dense? 1 : 2) != flavour) continue;
+				const int k = T.nsrc;
+				T.v[k] = J.src[i].d_v;  T.n[k] = J.src[i].n;  T.ntiles[k] = ntiles;  T.block0[k + 1] = T.block0[k] + blocks;
+				if (fused)
+					{
+					F.vLo = J.vLo;  F.vHi = J.vHi;  F.one = J.fuse->one;  F.zero = J.fuse->zero;  F.jLo = fuseJLo;  F.jHi = fuseJHi;
+					T.out[k] = J.fuse->d_out[i];
+					T.pos[k] = J.scratch[d]->pos + J.posOffset[i];  T.posCount[k] = J.scratch[d]->posCount + J.fusedSource[i];
+					T.posCap[k] = (uint32_t) J.posCap[i];
+					J.fusedAny = true;
+					}
+				else J.fusedSource[i] = -1;
+				*padded += (uint64_t) ntiles * PC_TILE;
+				T.nsrc++;
+				if ((T.nsrc == PC_TAB) || perSource) { go ();  GDSP_LAUNCH_CHECK (); }
+				}
+			go ();
 			GDSP_LAUNCH_CHECK ();
 			}
 		}
@@ -1533,7 +1954,7 @@ static int pc_resident (PcJob& J, const uint32_t* pThousandths, int np, uint32_t
 		st[d] = gdsp_stream (J.stream[d]);
 		R[d]  = J.scratch[d]->res;
 		H[d]  = reinterpret_cast<PcResHist*> (reinterpret_cast<char*> (J.scratch[d]->res) + PC_RES_STATE_BYTES);
-		GDSP_HIP_TRY (hipMemsetAsync (R[d], 0, PC_RES_STATE_BYTES + sizeof(PcResHist), st[d]));
+		GDSP_HIP_TRY (hipMemsetAsync (R[d], 0, PC_RES_BLOCK_BYTES, st[d]));         // state, histograms, counters, strip counts
 		}
 	PcPts pts;
 	memset (&pts, 0, sizeof(pts));
@@ -1580,10 +2001,23 @@ static int pc_resident (PcJob& J, const uint32_t* pThousandths, int np, uint32_t
 		return GDSP_OK;
 		};
 
+	// one device, nobody to reduce with: the selects run in a workgroup's LDS (pc_ls_*), two launches per stage instead of a
+	// launch per digit.  GDSP_PERCENTILE_LDS_SELECT=0 keeps the digit passes (A/B; the split route always takes them)
+	const char* lsEnv = getenv ("GDSP_PERCENTILE_LDS_SELECT");
+	const bool  lds = !split && (ND == 1) && !((lsEnv != NULL) && (strcmp (lsEnv, "0") == 0));
 	// subsample, then the ranks either side of every percentile's target: five digits each, no answer awaited
 	PC_TRY (pc_sample_launch (J, sstride));
-	for (int i=0 ; i<np ; i++)
-		for (int digit=0 ; digit<PC_DIGITS ; digit++) PC_TRY (digit_pass (PC_RES_SAMPLE, digit, i));
+	if (lds)
+		{
+		const unsigned long long slots = J.sampleCount[0];
+		const uint32_t blocks = (uint32_t) std::min<unsigned long long> (PC_RES_MAXB, std::max<unsigned long long> (1, (slots + 16383) / 16384));
+		hipLaunchKernelGGL (pc_ls_sub_kernel, dim3(1), dim3(PC_RES_THREADS), 0, st[0], (const uint64_t*) J.scratch[0]->sample, slots, pts, R[0]);
+		hipLaunchKernelGGL (pc_ls_grid_kernel, dim3(blocks), dim3(PC_RES_THREADS), 0, st[0], (const uint64_t*) J.scratch[0]->sample, slots, pts, R[0], H[0]);
+		GDSP_LAUNCH_CHECK ();
+		}
+	else
+		for (int i=0 ; i<np ; i++)
+			for (int digit=0 ; digit<PC_DIGITS ; digit++) PC_TRY (digit_pass (PC_RES_SAMPLE, digit, i));
 	const int fuseWhich = (J.fuse != NULL)? J.fuse->which : -1;
 	for (size_t d=0 ; d<ND ; d++)
 		{
@@ -1627,8 +2061,24 @@ static int pc_resident (PcJob& J, const uint32_t* pThousandths, int np, uint32_t
 		}
 
 	// an order statistic of the candidates for every percentile that landed inside a bracket
-	for (int i=0 ; i<np ; i++)
-		for (int digit=0 ; digit<PC_DIGITS ; digit++) PC_TRY (digit_pass (PC_RES_CAND, digit, i));
+	if (lds)
+		{
+		PcDevice* sc = J.scratch[0];
+		const unsigned long long* countPtr = (const unsigned long long*) sc->ctr + (size_t) PC_REPL * PC_CTR_WORDS;
+		const uint32_t blocks = (uint32_t) std::min<size_t> (4 * PC_RES_MAXB, std::max<size_t> (4, sc->candCap / 65536));
+		for (int i=0 ; i<np ; i++)
+			{
+			hipLaunchKernelGGL (pc_ls_cand_sub_kernel, dim3(1), dim3(PC_RES_THREADS), 0, st[0], (const uint64_t*) sc->cand, countPtr,
+			                    (unsigned long long) sc->candCap, i, R[0]);
+			// (the subsample has served: its buffer keeps what the pass finds within the grid's span)
+			hipLaunchKernelGGL (pc_ls_cand_pick_kernel, dim3(blocks), dim3(PC_RES_THREADS), 0, st[0], (const uint64_t*) sc->cand, countPtr,
+			                    (unsigned long long) sc->candCap, i, R[0], H[0], sc->sample, (unsigned long long) sc->sampleCap);
+			}
+		GDSP_LAUNCH_CHECK ();
+		}
+	else
+		for (int i=0 ; i<np ; i++)
+			for (int digit=0 ; digit<PC_DIGITS ; digit++) PC_TRY (digit_pass (PC_RES_CAND, digit, i));
 	// the fused binarize's open positions
 	if (J.fusedAny)
 		{

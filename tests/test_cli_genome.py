@@ -39,17 +39,26 @@ def genome():
 SHARDINGS = {"chromosomes": [], "bases_3_shards": ["--gpus=3", "--sharding=bases"]}
 
 
+# configs[4] once more without `--preserve`: the reference needs it (its percentile sorts the signal in place,
+# percentile.c:34-36, and the command line restores it from the text it wrote); here the signal is never touched, the same
+# bytes come out, and `percentile = binarize` runs fused in one read of the signal instead of around 1.6 s of text
+EXTRA = {"config4_percentile_without_preserve": "config4_percentile"}
+
+
 @pytest.mark.parametrize("sharding", list(SHARDINGS))
-@pytest.mark.parametrize("name", list(gc.PIPELINES))
+@pytest.mark.parametrize("name", list(gc.PIPELINES) + list(EXTRA))
 def test_genome_scale_pipeline_prints_what_the_reference_prints(name, sharding, genome):
     gold, chroms, reads = genome
-    if name not in gold["runs"]:
-        pytest.skip("no recorded reference run for " + name)
-    want = gold["runs"][name]
+    recorded = EXTRA.get(name, name)
+    if recorded not in gold["runs"]:
+        pytest.skip("no recorded reference run for " + recorded)
+    want = gold["runs"][recorded]
     assert want["returncode"] == 0
     preserve = os.path.join(gc.workdir(), "preserve.hip.dat")
     env = dict(os.environ, GDSP_OVERSUBSCRIBE_GPUS="1")
-    args = gc.args_for(name, chroms, preserve)
+    args = gc.args_for(recorded, chroms, preserve)
+    if name in EXTRA:
+        args = [a for a in args if not a.startswith("--preserve=")]
     cmd = [BIN, args[0], "--report=gpu"] + SHARDINGS[sharding] + args[1:]
     got = gc.digest_run(cmd, reads, env=env)
     if os.path.exists(preserve):

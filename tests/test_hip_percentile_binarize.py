@@ -61,12 +61,14 @@ def test_fused_leaves_sources_intact_and_reports_nothing_when_nothing_qualifies(
     assert cnt == 0 and vals == [] and not one_pass
 
 
-ROUTES = {"resident": {}, "chained": {"GDSP_PERCENTILE_RESIDENT_OFF": "1"},
+# resident: decided on the device, its selects in one workgroup's LDS (pc_ls_*); resident_digits: the same with a launch
+# per radix digit (what a call across ranks takes); chained / host: the digits with five read-backs / one per digit
+ROUTES = {"resident": {}, "resident_digits": {"GDSP_PERCENTILE_LDS_SELECT": "0"}, "chained": {"GDSP_PERCENTILE_RESIDENT_OFF": "1"},
           "host": {"GDSP_PERCENTILE_RESIDENT_OFF": "1", "GDSP_PERCENTILE_CHAIN_OFF": "1"}}
 
 
 @pytest.mark.parametrize("n", [70_000, 2_100_001, 9_000_003])
-def test_the_three_routes_of_a_one_device_call_agree(n, gd, monkeypatch):
+def test_the_routes_of_a_one_device_call_agree(n, gd, monkeypatch):
     """A call on one device with nothing to reduce is decided on the device (pc_resident: one read-back); the same call
     with the digits chained (five read-backs) and with a read-back per digit must give the same population, the same
     values bit for bit and the same binarized outputs -- on coverage, read depth (ties on the pivots), NaN / infinities /
@@ -80,20 +82,20 @@ def test_the_three_routes_of_a_one_device_call_agree(n, gd, monkeypatch):
         for pts, kw in (([99000], {}), ([500, 50000, 99990], {}), ([75000], {"lo": 1.0, "hi": 60.0}), ([90000], {"window": 3})):
             seen = {}
             for route, env in ROUTES.items():
-                for k in ("GDSP_PERCENTILE_RESIDENT_OFF", "GDSP_PERCENTILE_CHAIN_OFF"):
+                for k in ("GDSP_PERCENTILE_RESIDENT_OFF", "GDSP_PERCENTILE_CHAIN_OFF", "GDSP_PERCENTILE_LDS_SELECT"):
                     monkeypatch.delenv(k, raising=False)
                 for k, v in env.items():
                     monkeypatch.setenv(k, v)
                 cnt, vals = gd.percentile(vecs, pts, **kw)
                 st = gd.percentile_stats()
-                if route == "resident" and st["route"] == gd.SELECT_BRACKET and len(pts) <= 8:
+                if route.startswith("resident") and st["route"] == gd.SELECT_BRACKET and len(pts) <= 8:
                     assert st["resident"] == 1 or st["sample"] < 256, (name, pts, kw, st)
-                if route != "resident":
+                if not route.startswith("resident"):
                     assert st["resident"] == 0
                 fused = gd.percentile_binarize(vecs, pts, which=len(pts) - 1, **kw)
                 seen[route] = (cnt, np.array(vals), fused[0], np.array(fused[1]), [o.numpy() for o in fused[2]])
             ref = seen["host"]
-            for route in ("resident", "chained"):
+            for route in ("resident", "resident_digits", "chained"):
                 got = seen[route]
                 assert got[0] == ref[0] and got[2] == ref[2] and bits_equal(got[1], ref[1]) and bits_equal(got[3], ref[3]), (name, pts, kw, route)
                 for a, b in zip(got[4], ref[4]):

@@ -14,7 +14,7 @@ import sys
 SKIP = ("synth_coverage_kernel", "__amd_rocclr", "fill", "copyBuffer")
 # bytes the operator has to move per base: in + out, or in only for the passes that only read
 ALGORITHMIC = {"pc_fixup_kernel": None, "pc_hist_chain_kernel": None, "pc_pick_kernel": None, "peaks_probe_kernel": None, "peaks_exact_kernel": None, "peaks_init_kernel": None, "fir_fixed_extrema_gated_kernel": None,
-               "pc_sample_kernel": 8, "pc_partition_kernel": 8, "cumsum_totals_kernel": 8, "report_count_kernel": 8,
+               "pc_sample_kernel": 8, "pc_partition_tab_kernel": 8, "cumsum_totals_kernel": 8, "report_count_kernel": 8,
                "report_write_kernel": 8, "clump_write_kernel": 8,        # (clump_chunk_stats_kernel reads the signal and writes R': the default 16)
                # launches over a few words per chunk, or whose traffic is not a per-base figure: bytes only
                "clump_scan_": None, "clump_bits_": None, "clump_mark_kernel": None, "pc_res_": None, "pc_sample_tab_kernel": 8, "report_scan_kernel": None, "pc_hist_keys_kernel": None,
@@ -63,7 +63,7 @@ for path in sorted(glob.glob(os.path.join(root, tag + "_prof_*.txt"))):
         for key, val in ALGORITHMIC.items():
             if name.startswith(key):
                 per_base = val
-        if name.startswith("pc_partition_kernel") and name.endswith("true, true>"):
+        if name.startswith("pc_partition_tab_kernel") and name.endswith("true, true>"):
             per_base = 16                 # the fused form writes the binarized signal too
         launch_bases = bases
         if m.group(1).endswith("_batch") or m.group(1) == "percentile_binarize":
