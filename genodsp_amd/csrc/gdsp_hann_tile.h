@@ -51,10 +51,13 @@ __attribute__((unused)) static __device__ __noinline__ void hann_direct_tile (do
 	__syncthreads ();
 	}
 
-template <int W> struct HannGeom
+// E direct taps at either end (HN_E for the smoothed track itself: the cancellation in S - C where the taps are small must
+// stay inside W 2^-52 sum|w x| per window; 0 for the peaks filter, gdsp_peaks.hip, which only needs every value to a few
+// parts in 2^40 of the tile's largest input and saves the 256 multiply-adds per thread the direct taps cost)
+template <int W, int EE = HN_E> struct HannGeom
 	{
 	static constexpr int H      = (W - 1) / 2;
-	static constexpr int E      = HN_E;
+	static constexpr int E      = EE;
 	static constexpr int DM     = W - 2*E - 1;           // a' = b' - DM: ends of the middle stretch
 	static constexpr int DQ     = DM / HN_G, DR = DM % HN_G;
 	static constexpr int BACK   = DM + E;                // first element of the window = b' - BACK
@@ -71,12 +74,12 @@ template <int W> struct HannGeom
 	static_assert (LO + NEDGE <= 2 * HN_G, "left edge spans more than two blocks");
 	};
 
-template <int W> struct HannConsts
+template <int W, int EE = HN_E> struct HannConsts
 	{
-	double edge[HN_E];                                             // 1 - cos(w k),        k = 1..E
+	double edge[(EE > 0)? EE : 1];                                 // 1 - cos(w k),        k = 1..E
 	double ownC[HN_G], ownS[HN_G];                                 // exp(+j w u),         u = 0..15
-	double leftC[HannGeom<W>::NLEFT], leftS[HannGeom<W>::NLEFT];   // exp(+j w (u - DM)),  u = 0..NLEFT-1
-	double rotC[HannGeom<W>::NT], rotS[HannGeom<W>::NT];           // exp(-j w 16 d),      d = 1..NT
+	double leftC[HannGeom<W, EE>::NLEFT], leftS[HannGeom<W, EE>::NLEFT];   // exp(+j w (u - DM)),  u = 0..NLEFT-1
+	double rotC[HannGeom<W, EE>::NT], rotS[HannGeom<W, EE>::NT];   // exp(-j w 16 d),      d = 1..NT
 	double demC[HN_G], demS[HN_G];                                 // exp(+j w (W-E - s)), s = 0..15
 	double scale;                                                  // c = 1 / (2 * sum of raw taps)
 	};
@@ -86,12 +89,12 @@ template <int W> struct HannConsts
 // over the workgroup), and the staged inputs are still in the LDS image (no barrier after the last read).
 // With STATS, stats[wave] = { largest magnitude's high word, bit 0: a sign bit is set, bit 1: 0 < |x| < 2^-500 } of the wave's
 // 64 blocks (visible on return).
-template <int W, bool STATS = false>
+template <int W, bool STATS = false, int EE = HN_E>
 __device__ __forceinline__ bool hann_tile_sums (double* lds, double (*tot)[HN_THREADS], uint32_t* huge,
                                                 const double* __restrict__ in, uint32_t n, int64_t e0,
-                                                const HannConsts<W>& K, double (&acc)[HN_G], uint32_t (*stats)[2] = NULL)
+                                                const HannConsts<W, EE>& K, double (&acc)[HN_G], uint32_t (*stats)[2] = NULL)
 	{
-	typedef HannGeom<W> G;
+	typedef HannGeom<W, EE> G;
 	const int  p    = threadIdx.x;
 	const bool live = (p >= G::HALO_L) && (p < HN_THREADS - G::HALO_R);
 
@@ -123,7 +126,7 @@ __device__ __forceinline__ bool hann_tile_sums (double* lds, double (*tot)[HN_TH
 	// ---- phase 0: the E taps at either end of each of the 16 windows, directly
 #pragma unroll
 	for (int s=0 ; s<HN_G ; s++) acc[s] = 0.0;
-	if (live)
+	if ((G::E > 0) && live)
 		{
 		const double* xl = lds + (p - G::HALO_L) * HN_PITCH;        // element b'-BACK of s=0 is xl[LO]
 #pragma unroll
@@ -234,10 +237,10 @@ __device__ __forceinline__ bool hann_tile_sums (double* lds, double (*tot)[HN_TH
 	return direct;
 	}
 
-template <int W>
-static void hann_consts (HannConsts<W>& K)
+template <int W, int EE = HN_E>
+static void hann_consts (HannConsts<W, EE>& K)
 	{
-	typedef HannGeom<W> G;
+	typedef HannGeom<W, EE> G;
 	const double pi = 3.14159265358979323846264;
 	const int    M  = W + 1;                                       // the window's period
 	auto cs = [&] (long m, double* c, double* sn)                   // exp(j*2*pi*m/M), argument reduced first

@@ -31,6 +31,14 @@
 #include <vector>
 #include "gdsp_hann_tile.h"
 
+// The filter's block sums take ALL the window's taps (no direct taps at the ends, HannGeom's E = 0): what it decides on is
+// either two values' high words two units apart -- more than a part in 2^21 -- or intervals of KAPPA times the tile's
+// largest magnitude, and the cancellation the direct taps are there to avoid in `smooth --smooth=hann` costs a part in
+// 2^36 of a value at the worst (all of a window's weight under its smallest tap: (1 - cos w) = 1.9e-3 of the unweighted
+// sum, against ~140 roundings of 2^-53 of it).  256 multiply-adds and 46 LDS reads per thread and tile less.
+#ifndef PK_E
+#define PK_E 0
+#endif
 #define PK_HMAX        7                                  // neighbourhoods up to 15 bases: one lane of a 16-lane group per neighbour
 #define PK_PROBE_TILES 64
 #define PK_TILE_CAP    192                                // undecided bases a tile can queue (4.8 % of its 3974: nine times the average on real-valued coverage)
@@ -74,11 +82,11 @@ __global__ void peaks_init_kernel (GdspPeaksCtl* ctl, GdspBatch B, uint32_t stri
 #define PK_NEED_INPLACE 12
 template <int W, bool FMA, bool MAX, int HH, bool PROBE>
 __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t tile,
-                                                   const HannConsts<W>& K, const double* __restrict__ d_taps, double fill, GdspPeaksCtl* ctl,
+                                                   const HannConsts<W, PK_E>& K, const double* __restrict__ d_taps, double fill, GdspPeaksCtl* ctl,
                                                    uint16_t* __restrict__ strip, uint32_t* __restrict__ tileCount, uint32_t cap,
                                                    uint32_t* __restrict__ tileList, uint32_t gt)
 	{
-	typedef HannGeom<W> G;
+	typedef HannGeom<W, PK_E> G;
 	constexpr double KAPPA = 16.0 * W * 2.220446049250313e-16;
 	constexpr int    h = HH, sh = HH & 1;                          // sh keeps the first staged index even
 	constexpr int    stride = G::OUT - 2*h - 2*sh;                 // outputs kept per tile (even)
@@ -110,7 +118,7 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 	if (p == 0) { nsure = 0;  queued = 0; }                        // (the barriers of the block sums come before their first use)
 	if (!PROBE && (p < W)) tapsLds[p] = d_taps[p];
 	double acc[HN_G];
-	bool direct = hann_tile_sums<W, false> (lds, tot, huge, in, n, e0, K, acc);
+	bool direct = hann_tile_sums<W, false, PK_E> (lds, tot, huge, in, n, e0, K, acc);
 
 	// ---- what the tile's inputs are like, from the own block in the LDS image (after the block sums: inside them, where
 	// the registers are fullest, the same few integer operations per element cost a fifth of the kernel): is a sign bit
@@ -451,7 +459,7 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 
 template <int W, bool MAX, int HH>
 __global__ __launch_bounds__(HN_THREADS)
-void peaks_probe_kernel (GdspBatch B, HannConsts<W> K, GdspPeaksCtl* ctl)
+void peaks_probe_kernel (GdspBatch B, HannConsts<W, PK_E> K, GdspPeaksCtl* ctl)
 	{
 	const uint32_t v = blockIdx.x / PK_PROBE_TILES, j = blockIdx.x % PK_PROBE_TILES;
 	const uint32_t tiles = B.tile0[v+1] - B.tile0[v];
@@ -463,7 +471,7 @@ void peaks_probe_kernel (GdspBatch B, HannConsts<W> K, GdspPeaksCtl* ctl)
 
 template <int W, bool FMA, bool MAX, int HH>
 __global__ __launch_bounds__(HN_THREADS) __attribute__((amdgpu_waves_per_eu(3)))     // three workgroups per CU, like hann_blocks_kernel
-void peaks_filter_kernel (GdspBatch B, HannConsts<W> K, const double* __restrict__ d_taps, double fill, GdspPeaksCtl* ctl, uint16_t* strips,
+void peaks_filter_kernel (GdspBatch B, HannConsts<W, PK_E> K, const double* __restrict__ d_taps, double fill, GdspPeaksCtl* ctl, uint16_t* strips,
                           uint32_t* counts, uint32_t cap, uint32_t* tileList)
 	{
 	const double* in;  double* out;  uint32_t n, v;
@@ -485,7 +493,7 @@ void peaks_exact_kernel (GdspBatch B, PeaksTaps<W> taps, int h, double fill, con
                          const uint16_t* __restrict__ strips, const uint32_t* __restrict__ counts, uint32_t cap,
                          const uint32_t* __restrict__ tileList)
 	{
-	typedef HannGeom<W> G;
+	typedef HannGeom<W, PK_E> G;
 	constexpr int H = (W - 1) / 2;
 	constexpr int GROUPS = HN_THREADS / PK_GROUP;
 	__shared__ double xs[GROUPS][PK_XS];
@@ -605,10 +613,10 @@ bool gdsp_peaks_filter_available (uint32_t W, uint32_t N)
 	}
 
 template <bool MAX, int HH>
-static int peaks_launch (const gdsp_batch_item* items, int count, const HannConsts<101>& K, const PeaksTaps<101>& taps, int fma,
+static int peaks_launch (const gdsp_batch_item* items, int count, const HannConsts<101, PK_E>& K, const PeaksTaps<101>& taps, int fma,
                          double fill, const double* h_taps, void* stream)
 	{
-	typedef HannGeom<101> G;
+	typedef HannGeom<101, PK_E> G;
 	constexpr int stride = G::OUT - 2*HH - 2*(HH & 1);
 	hipStream_t s = gdsp_stream (stream);
 	GdspBatch B;
@@ -650,8 +658,8 @@ int gdsp_peaks_filter_batch (const gdsp_batch_item* items, int nitems, const dou
 	{
 	const int h = (int) ((N - 1) / 2);
 	GDSP_REQUIRE ((h >= 1) && (h <= PK_HMAX), "neighbourhood outside the filter's range");
-	HannConsts<101> K;
-	hann_consts<101> (K);
+	HannConsts<101, PK_E> K;
+	hann_consts<101, PK_E> (K);
 	PeaksTaps<101> taps;
 	memcpy (taps.w, h_taps, sizeof(taps.w));
 	std::vector<gdsp_batch_item> live;

@@ -118,8 +118,15 @@ void pc_sample_tab_kernel (PcSampleTab T, uint32_t window, double lo, double hi,
 // is 15 % slower, a 2048-workgroup grid-stride loop the same as this.)  Counters go to one of PC_REPL replicas (workgroup id mod PC_REPL) so that the
 // end-of-workgroup atomics do not queue on a handful of addresses; the host adds the replicas.
 #define PC_TILE         (PC_THREADS * 16)
+#ifndef PC_TILES_PER_WG
 #define PC_TILES_PER_WG 16                              // at most
+#endif
+#ifndef PC_MIN_WGS
 #define PC_MIN_WGS      1024
+#endif
+#ifndef PC_WGS_PER_CU
+#define PC_WGS_PER_CU   5                               // of the two-pivot forms (tools/exp_kernel.sh: -DPC_WGS_PER_CU=3 ...)
+#endif
 #define PC_REPL         64
 #define PC_CTR_ALL      (PC_REPL * PC_CTR_WORDS + 1)      // replicas, then the candidate count
 #define PC_CTR_SPLIT    (PC_CTR_ALL + 2)                  // split resident route, summed over ranks with the rest: padded elements, lists that overflowed
@@ -127,7 +134,8 @@ void pc_sample_tab_kernel (PcSampleTab T, uint32_t window, double lo, double hi,
 // state of the resident route (see pc_res_digit_kernel below)
 #define PC_RES_MAXP   8                                        // percentiles per call
 #define PC_LS_GRID    64                                       // grid keys per percentile (one wave looks them up)
-#define PC_LS_KEYS    8192                                     // keys one workgroup sorts in LDS
+#define PC_LS_KEYS    8192                                     // keys one workgroup can sort in LDS (the cell that holds a candidates' rank)
+#define PC_LS_SUB     2048                                     // the strided share of a list a grid is laid on
 #define PC_RES_BINS   (1 << 13)
 #define PC_RES_SAMPLE 0
 #define PC_RES_CAND   1
@@ -485,7 +493,7 @@ struct PcCountTab
 	int                 nsrc;
 	};
 template <int M, bool BOUNDED, bool DENSE, bool FUSE>
-__global__ __launch_bounds__(PC_THREADS, (M <= 2)? 5 : 1)     // two pivots: five workgroups per CU (the fused form takes 98 registers otherwise: 4 waves per SIMD)
+__global__ __launch_bounds__(PC_THREADS, (M <= 2)? PC_WGS_PER_CU : 1)     // two pivots: five workgroups per CU (the fused form takes 98 registers otherwise: 4 waves per SIMD)
 void pc_partition_tab_kernel (PcCountTab T, uint32_t window, double lo, double hi, PcPivots P,
                               unsigned long long* __restrict__ ctr, uint64_t* __restrict__ cand, unsigned long long cap,
                               PcFuse F, const PcResident* __restrict__ res)
@@ -970,35 +978,79 @@ void pc_res_digit_kernel (const uint64_t* __restrict__ keys, const unsigned long
 // kept, sorts them in LDS and reads the answer off.  Four launches instead of ten per percentile -- two plus two per
 // further percentile.  What the grids miss (a rank outside four standard deviations, a cell too big for LDS, a list kept
 // past its capacity) marks the percentile for the plain route (how = 2), like a rank outside its bracket always has.
-__device__ __forceinline__ void pc_ls_sort (uint64_t* a, int n)       // bitonic, ascending; n a power of two <= PC_LS_KEYS; ends with the workgroup in step
+// Bitonic, ascending; n a power of two <= PC_LS_KEYS; ends with the workgroup in step.  A workgroup barrier per stage made
+// a sort of 8192 keys 91 barriers long -- ~55 us on a chip that a single workgroup does not bring up to speed
+// (profiles/r04_percentile_lds_steps.txt).  So wave w owns the pairs of keys n/16 w .. n/16 (w+1) - 1: every stage whose
+// partners lie n/32 or less apart stays inside one wave's stretch and needs no more than the wave's own LDS accesses in
+// order; only the ten stages that reach across stretches (of 91, at 8192 keys) meet at a barrier.  Up to 1024 keys one
+// wave sorts alone.
+__device__ __forceinline__ void pc_ls_sort (uint64_t* a, int n)
 	{
-	for (int k=2 ; k<=n ; k<<=1)
-		for (int j=k>>1 ; j>0 ; j>>=1)
-			{
-			for (int t=threadIdx.x ; t<n/2 ; t+=PC_RES_THREADS)
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int waves = (n <= 1024)? 1 : PC_RES_THREADS / 64;
+	const int per   = (n / 2) / waves;                              // pairs per wave and stage (>= 1: n >= 2)
+	if (wave < waves)
+		for (int k=2 ; k<=n ; k<<=1)
+			for (int j=k>>1 ; j>0 ; j>>=1)
 				{
-				const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-				const uint64_t x = a[i], y = a[i + j];
-				const bool up = ((i & k) == 0);
-				if ((x > y) == up) { a[i] = y;  a[i + j] = x; }
+				const bool across = (waves > 1) && (j > per);               // partners in different waves' stretches
+				if (across) __syncthreads ();
+				else { __builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");  __builtin_amdgcn_wave_barrier (); }
+				// four pairs per lane at a time, every load before the first store: written pair by pair the compiler keeps
+				// each pair's stores ahead of the next pair's loads (it cannot know they do not meet) and a stage costs
+				// four LDS round trips instead of one
+				for (int r0=0 ; r0<per ; r0+=256)
+					{
+					uint64_t x[4], y[4];
+					int      at[4];
+#pragma unroll
+					for (int q=0 ; q<4 ; q++)
+						{
+						const int r = r0 + q*64 + lane;
+						const int t = wave * per + ((r < per)? r : 0);
+						at[q] = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+						x[q] = a[at[q]];  y[q] = a[at[q] + j];
+						}
+#pragma unroll
+					for (int q=0 ; q<4 ; q++)
+						{
+						const bool up = ((at[q] & k) == 0);
+						if ((r0 + q*64 + lane < per) && ((x[q] > y[q]) == up)) { a[at[q]] = y[q];  a[at[q] + j] = x[q]; }
+						}
+					}
+				if (across) __syncthreads ();
 				}
-			__syncthreads ();
-			}
+	__syncthreads ();
 	}
 
-// a strided share of `keys` (those within [keyLo, keyHi], PC_NO_KEY skipped) into LDS, sorted; returns how many, and the
-// stride in *strideOut.  a[] holds PC_LS_KEYS words; sCount is a word of LDS.
+// a strided share of `keys` -- about `sub` of them, sub <= PC_LS_KEYS -- (those within [keyLo, keyHi], PC_NO_KEY skipped) into
+// LDS, sorted; returns how many, and the stride in *strideOut.  a[] holds PC_LS_KEYS words; sCount is a word of LDS.
 __device__ __forceinline__ int pc_ls_gather_sorted (uint64_t* a, uint32_t* sCount, const uint64_t* __restrict__ keys, unsigned long long count,
-                                                    uint64_t keyLo, uint64_t keyHi, unsigned long long* strideOut)
+                                                    uint64_t keyLo, uint64_t keyHi, unsigned long long sub, unsigned long long* strideOut)
 	{
-	const unsigned long long stride = (count + PC_LS_KEYS - 1) / PC_LS_KEYS;
+	const unsigned long long stride = (count + sub - 1) / sub;
 	if (threadIdx.x == 0) *sCount = 0;
 	__syncthreads ();
-	const unsigned long long picks = (stride == 0)? 0 : (count + stride - 1) / stride;
-	for (unsigned long long i=threadIdx.x ; i<picks ; i+=PC_RES_THREADS)
+	const unsigned long long picks = (stride == 0)? 0 : (count + stride - 1) / stride;     // <= sub <= PC_LS_KEYS: eight per thread at most
+	const int lane = threadIdx.x & 63;
+	uint64_t k[PC_LS_KEYS / PC_RES_THREADS];
+#pragma unroll
+	for (int u=0 ; u<PC_LS_KEYS/PC_RES_THREADS ; u++)
 		{
-		const uint64_t key = keys[i * stride];
-		if ((key != PC_NO_KEY) && (key >= keyLo) && (key <= keyHi)) a[atomicAdd (sCount, 1u)] = key;
+		const unsigned long long i = (unsigned long long) u * PC_RES_THREADS + threadIdx.x;
+		k[u] = (i < picks)? keys[i * stride] : PC_NO_KEY;
+		}
+#pragma unroll
+	for (int u=0 ; u<PC_LS_KEYS/PC_RES_THREADS ; u++)
+		{
+		if ((unsigned long long) u * PC_RES_THREADS >= picks) break;   // (uniform)
+		const bool     in   = (k[u] != PC_NO_KEY) && (k[u] >= keyLo) && (k[u] <= keyHi);
+		const uint64_t mask = __ballot (in);                           // (one LDS atomic per wave and round, not one per key on one address)
+		if (mask == 0) continue;
+		uint32_t base = 0;
+		if (lane == 0) base = atomicAdd (sCount, (uint32_t) __popcll (mask));
+		base = (uint32_t) __shfl ((int) base, 0, 64);
+		if (in) a[base + __popcll (mask & ((1ULL << lane) - 1))] = k[u];
 		}
 	__syncthreads ();
 	const int m = (int) *sCount;
@@ -1032,7 +1084,7 @@ void pc_ls_sub_kernel (const uint64_t* __restrict__ keys, unsigned long long slo
 	__shared__ uint32_t sCount;
 	if (R->status != PC_RES_OK) return;
 	unsigned long long stride;
-	const int m = pc_ls_gather_sorted (a, &sCount, keys, slots, 0, ~0ULL, &stride);
+	const int m = pc_ls_gather_sorted (a, &sCount, keys, slots, 0, ~0ULL, PC_LS_SUB, &stride);
 	const int wave = threadIdx.x >> 6;
 	if (wave >= pts.n) return;
 	if (m == 0) { if ((threadIdx.x & 63) == 0) R->gridN[wave] = 0;  return; }
@@ -1045,12 +1097,16 @@ void pc_ls_sub_kernel (const uint64_t* __restrict__ keys, unsigned long long slo
 	pc_ls_lay_grid (a, rLo, rHi, R->grid[wave], &R->gridN[wave]);
 	}
 
-// the cell of a key in an ascending grid of gn distinct keys: j = how many grid keys lie below it; *onKey: it IS grid key j
-__device__ __forceinline__ int pc_ls_cell (const uint64_t* grid, int gn, uint64_t key, bool* onKey)
+// the cell of a key in an ascending grid of distinct keys padded to PC_LS_GRID entries with ~0: j = how many grid keys lie
+// below it; *onKey: it IS grid key j.  Six probes whatever the key: the searches of a thread's keys run side by side.
+__device__ __forceinline__ int pc_ls_cell (const uint64_t* grid, uint64_t key, bool* onKey)
 	{
-	int lo = 0, hi = gn;
-	while (lo < hi) { const int mid = (lo + hi) >> 1;  if (grid[mid] < key) lo = mid + 1;  else hi = mid; }
-	*onKey = (lo < gn) && (grid[lo] == key);
+	int lo = 0;
+#pragma unroll
+	for (int step=PC_LS_GRID/2 ; step>=1 ; step>>=1) { if (grid[lo + step - 1] < key) lo += step; }
+	const uint64_t at = grid[lo];
+	if (at < key) { lo++;  *onKey = false; }                       // (above every grid key: only where all 64 are real)
+	else *onKey = (at == key);
 	return lo;
 	}
 
@@ -1089,10 +1145,17 @@ void pc_ls_grid_kernel (const uint64_t* __restrict__ keys, unsigned long long sl
 	__shared__ uint32_t sLast;
 	if (R->status != PC_RES_OK) return;
 	const int np = pts.n, p = threadIdx.x, lane = p & 63, wave = p >> 6;
-	for (int q=p ; q<np*PC_LS_GRID ; q+=PC_RES_THREADS) grid[q / PC_LS_GRID][q % PC_LS_GRID] = R->grid[q / PC_LS_GRID][q % PC_LS_GRID];
 	if (p < np) gn[p] = R->gridN[p];
+	__syncthreads ();
+	for (int q=p ; q<np*PC_LS_GRID ; q+=PC_RES_THREADS)
+		grid[q / PC_LS_GRID][q % PC_LS_GRID] = ((uint32_t) (q % PC_LS_GRID) < gn[q / PC_LS_GRID])? R->grid[q / PC_LS_GRID][q % PC_LS_GRID] : ~0ULL;
 	for (int q=p ; q<np*PC_LS_CELLS ; q+=PC_RES_THREADS) { cOpen[q / PC_LS_CELLS][q % PC_LS_CELLS] = 0;  cOn[q / PC_LS_CELLS][q % PC_LS_CELLS] = 0; }
 	__syncthreads ();
+	// nearly every key lies below or above a grid (which spans a few hundred of the subsample's ranks): those are counted
+	// in registers, a ballot each; only the keys inside a grid's span are looked up and go through LDS atomics
+	uint32_t under[PC_RES_MAXP], over[PC_RES_MAXP];
+#pragma unroll
+	for (int w=0 ; w<PC_RES_MAXP ; w++) { under[w] = 0;  over[w] = 0; }
 	const size_t stride = (size_t) gridDim.x * PC_RES_THREADS;
 	for (size_t i = (size_t) blockIdx.x * PC_RES_THREADS + p ; i < slots ; i += 16*stride)
 		{
@@ -1100,16 +1163,35 @@ void pc_ls_grid_kernel (const uint64_t* __restrict__ keys, unsigned long long sl
 #pragma unroll
 		for (int u=0 ; u<16 ; u++) k[u] = (i + u*stride < slots)? keys[i + u*stride] : PC_NO_KEY;
 #pragma unroll
-		for (int u=0 ; u<16 ; u++)
+		for (int w=0 ; w<PC_RES_MAXP ; w++)
 			{
-			if (k[u] == PC_NO_KEY) continue;
-			for (int w=0 ; w<np ; w++)
+			if (w >= np) break;
+			const int      g  = (int) gn[w];
+			const uint64_t g0 = grid[w][0], g1 = (g > 0)? grid[w][g - 1] : 0;
+#pragma unroll
+			for (int u=0 ; u<16 ; u++)
 				{
-				bool onKey;
-				const int j = pc_ls_cell (grid[w], (int) gn[w], k[u], &onKey);
-				atomicAdd (onKey? &cOn[w][j] : &cOpen[w][j], 1u);
+				const bool valid = (k[u] != PC_NO_KEY);
+				const bool lowK  = valid && ((g == 0) || (k[u] < g0)), highK = valid && (g > 0) && (k[u] > g1);
+				under[w] += lowK? 1u : 0u;  over[w] += highK? 1u : 0u;
+				const bool inside = valid && !lowK && !highK;
+				if (__ballot (inside) == 0) continue;
+				if (inside)
+					{
+					bool onKey;
+					const int j = pc_ls_cell (grid[w], k[u], &onKey);
+					atomicAdd (onKey? &cOn[w][j] : &cOpen[w][j], 1u);
+					}
 				}
 			}
+		}
+#pragma unroll
+	for (int w=0 ; w<PC_RES_MAXP ; w++)
+		{
+		if (w >= np) break;
+		uint32_t a = under[w], b = over[w];
+		for (int off=32 ; off>0 ; off>>=1) { a += __shfl_down (a, off, 64);  b += __shfl_down (b, off, 64); }
+		if (lane == 0) { if (a) atomicAdd (&cOpen[w][0], a);  if (b) atomicAdd (&cOpen[w][gn[w]], b); }
 		}
 	__syncthreads ();
 	for (int q=p ; q<np*PC_LS_CELLS ; q+=PC_RES_THREADS)
@@ -1169,7 +1251,9 @@ void pc_ls_cand_sub_kernel (const uint64_t* __restrict__ keys, const unsigned lo
 	const uint64_t keyLo = R->scopeLo[which], keyHi = R->scopeHi[which];
 	const unsigned long long rank = R->rankIn[which], inBin = R->binCount[which];
 	unsigned long long stride;
-	const int m = pc_ls_gather_sorted (a, &sCount, keys, count, keyLo, keyHi, &stride);
+	// the cell that will hold the rank has about N / (16 sqrt m) keys (N in scope, m of them gathered) and must fit the last
+	// workgroup's LDS: long lists are sampled four times as densely
+	const int m = pc_ls_gather_sorted (a, &sCount, keys, count, keyLo, keyHi, (count > (1ULL << 20))? PC_LS_KEYS : PC_LS_SUB, &stride);
 	if (stride <= 1)                                               // every candidate was looked at
 		{
 		if (threadIdx.x == 0)
@@ -1207,11 +1291,13 @@ void pc_ls_cand_pick_kernel (const uint64_t* __restrict__ keys, const unsigned l
 	const int g = (int) R->gridN[which];
 	if (p < PC_LS_GRID) grid[p] = (p < g)? R->grid[which][p] : ~0ULL;
 	if (p < PC_LS_CELLS) { cOpen[p] = 0;  cOn[p] = 0; }
+	if (p == 0) sCount = 0;
 	__syncthreads ();
 	unsigned long long count = *countPtr;
 	if (count > countCap) count = countCap;
 	const uint64_t keyLo = R->scopeLo[which], keyHi = R->scopeHi[which];
 	const uint64_t spanLo = grid[0], spanHi = grid[g - 1];
+	uint32_t under = 0, over = 0;                                  // in scope, below / above the grid's span: counted in registers
 	const size_t stride = (size_t) gridDim.x * PC_RES_THREADS;
 	for (size_t i = (size_t) blockIdx.x * PC_RES_THREADS + p ; i < count ; i += 8*stride)
 		{
@@ -1222,24 +1308,41 @@ void pc_ls_cand_pick_kernel (const uint64_t* __restrict__ keys, const unsigned l
 		for (int u=0 ; u<8 ; u++)
 			{
 			const bool in = (k[u] != PC_NO_KEY) && (k[u] >= keyLo) && (k[u] <= keyHi);
+			const bool lowK = in && (k[u] < spanLo), highK = in && (k[u] > spanHi);
+			under += lowK? 1u : 0u;  over += highK? 1u : 0u;
+			const bool inside = in && !lowK && !highK;
+			if (__ballot (inside) == 0) continue;
 			bool onKey = false;
-			if (in)
+			if (inside)
 				{
-				const int j = pc_ls_cell (grid, g, k[u], &onKey);
+				const int j = pc_ls_cell (grid, k[u], &onKey);
 				atomicAdd (onKey? &cOn[j] : &cOpen[j], 1u);
 				}
-			const bool keep = in && !onKey && (k[u] > spanLo) && (k[u] < spanHi);
+			const bool keep = inside && !onKey;                        // strictly between two grid keys
 			const uint64_t mask = __ballot (keep);
-			if (mask != 0)
+			if (mask != 0)                                             // into the workgroup's own buffer: an LDS atomic per wave and round
 				{
-				unsigned long long base = 0;
-				if (lane == 0) base = atomicAdd (&H->compactCount, (unsigned long long) __popcll (mask));
-				base = __shfl (base, 0, 64);
-				const unsigned long long at = base + __popcll (mask & ((1ULL << lane) - 1));
-				if (keep && (at < keptCap)) kept[at] = k[u];
+				uint32_t base = 0;
+				if (lane == 0) base = atomicAdd (&sCount, (uint32_t) __popcll (mask));
+				base = (uint32_t) __shfl ((int) base, 0, 64);
+				const uint32_t at = base + (uint32_t) __popcll (mask & ((1ULL << lane) - 1));
+				if (keep && (at < PC_LS_KEYS)) a[at] = k[u];
 				}
 			}
 		}
+	__syncthreads ();
+	// what the workgroup kept goes out in one piece (one global atomic per workgroup: one per wave and round put nine
+	// thousand of them on one address, 12 ns each); more than its buffer holds counts as more than the list holds
+		{
+		const uint32_t mine = sCount;
+		if (p == 0) sBefore = atomicAdd (&H->compactCount, (mine <= PC_LS_KEYS)? (unsigned long long) mine : keptCap + 1);
+		__syncthreads ();
+		const unsigned long long base = sBefore;
+		if (mine <= PC_LS_KEYS)
+			for (uint32_t i=p ; i<mine ; i+=PC_RES_THREADS) { if (base + i < keptCap) kept[base + i] = a[i]; }
+		}
+	for (int off=32 ; off>0 ; off>>=1) { under += __shfl_down (under, off, 64);  over += __shfl_down (over, off, 64); }
+	if (lane == 0) { if (under) atomicAdd (&cOpen[0], under);  if (over) atomicAdd (&cOpen[g], over); }
 	__syncthreads ();
 	if (p < PC_LS_CELLS)
 		{
@@ -1284,10 +1387,25 @@ void pc_ls_cand_pick_kernel (const uint64_t* __restrict__ keys, const unsigned l
 			{
 			if (p == 0) sCount = 0;
 			__syncthreads ();
-			for (unsigned long long i=p ; i<nkept ; i+=PC_RES_THREADS)
+			// (eight loads in flight per thread: one workgroup reading some fifty thousand keys one round trip at a time
+			// was most of this launch)
+			for (unsigned long long i0=0 ; i0<nkept ; i0+=8*PC_RES_THREADS)
 				{
-				const uint64_t key = kept[i];
-				if ((key > lo) && (key < hi)) { const uint32_t at = atomicAdd (&sCount, 1u);  if (at < PC_LS_KEYS) a[at] = key; }
+				uint64_t key[8];
+#pragma unroll
+				for (int u=0 ; u<8 ; u++) { const unsigned long long i = i0 + (unsigned long long) u * PC_RES_THREADS + p;  key[u] = (i < nkept)? kept[i] : 0; }
+#pragma unroll
+				for (int u=0 ; u<8 ; u++)
+					{
+					const bool     mine = (key[u] > lo) && (key[u] < hi);   // (a slot past the list reads as 0: below every cell, lo >= the first grid key)
+					const uint64_t mask = __ballot (mine);
+					if (mask == 0) continue;
+					uint32_t base = 0;
+					if (lane == 0) base = atomicAdd (&sCount, (uint32_t) __popcll (mask));
+					base = (uint32_t) __shfl ((int) base, 0, 64);
+					const uint32_t at = base + (uint32_t) __popcll (mask & ((1ULL << lane) - 1));
+					if (mine && (at < PC_LS_KEYS)) a[at] = key[u];
+					}
 				}
 			__syncthreads ();
 			const int m = (int) sCount;

@@ -1711,7 +1711,7 @@ static void parse_options (int _argc, char** _argv)            /* genodsp.c:284-
 			}
 		if ((strcmp (arg, "--progress=operations") == 0) || (strcmp (arg, "--progress:operations") == 0)
 		 || (strcmp (arg, "--debug=operations") == 0))
-			{ trackOperations = true;  continue; }
+			{ trackOperations = true;  batchLaunches = false;  continue; }   /* the progress lines come in the reference's order (genodsp.c:909-921): chromosome by chromosome */
 		if (strcmp (arg, "--version") == 0)
 			{ fprintf (stderr, "%s (version %s; %s)\n", programName, programVersion, gdsp_version ());  exit (EXIT_SUCCESS); }
 		if (strcmp (arg, "--debug=input") == 0)   { dbgInput   = true;  continue; }
