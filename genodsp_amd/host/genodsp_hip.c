@@ -130,7 +130,7 @@ static int numDevices     = 1;
 int        firMode        = GDSP_FIR_EXACT;      /* --smooth=exact|fma|hann (see ops_sum.c) */
 int        selectStrategy = GDSP_SELECT_AUTO;    /* --percentile=auto|radix|bracket (see ops_percentile.c) */
 static int fuseChains     = true;                /* --nofuse: one kernel per operator          */
-static int batchLaunches  = true;                /* --nobatch: one launch per operator and chromosome, chromosome by chromosome */
+static int batchLaunches  = -1;                  /* --nobatch: one launch per operator and chromosome, chromosome by chromosome; --batch: one per operator and device (the default, except under --progress=operations) */
 enum { reduce_auto, reduce_rccl, reduce_host };
 static int reduceHow      = reduce_auto;         /* --reduce=rccl|host: how whole-genome operators combine the devices */
 static gdsp_comm* deviceComm = NULL;             /* RCCL communicator over the devices in use (NULL: host sums)        */
@@ -217,6 +217,8 @@ static void usage (void)
 	"  --reduce=rccl|host        how percentile / invert combine the GPUs' counts: an RCCL all-reduce in\n"
 	"                            HBM (default with --gpus > 1) or sums on the host\n"
 	"  --nobatch                 apply operators chromosome by chromosome, one launch each, in the reference's order\n"
+	"                            (implied by --progress=operations, whose lines then come in the reference's order;\n"
+	"                            --batch keeps one launch per operator and device there too)\n"
 	"                            (default: an operator covers all the chromosomes of a device in one launch)\n"
 	"  --nofuse                  run every operator as its own kernel (default: the chains\n"
 	"                            smooth=localmax|localmin and dilate=erode[=binarize] are fused)\n"
@@ -1669,6 +1671,7 @@ static void parse_options (int _argc, char** _argv)            /* genodsp.c:284-
 			}
 		if (strcmp (arg, "--nofuse") == 0) { fuseChains = false;  continue; }
 		if (strcmp (arg, "--nobatch") == 0) { batchLaunches = false;  continue; }
+		if (strcmp (arg, "--batch") == 0)   { batchLaunches = true;   continue; }
 		if (strcmp (arg, "--shards=show") == 0)          { showShards = true;   continue; }
 		if (strcmp (arg, "--sharding=bases") == 0)       { shardBases = true;   continue; }
 		if (strcmp (arg, "--sharding=chromosomes") == 0) { shardBases = false;  continue; }
@@ -1711,7 +1714,7 @@ static void parse_options (int _argc, char** _argv)            /* genodsp.c:284-
 			}
 		if ((strcmp (arg, "--progress=operations") == 0) || (strcmp (arg, "--progress:operations") == 0)
 		 || (strcmp (arg, "--debug=operations") == 0))
-			{ trackOperations = true;  batchLaunches = false;  continue; }   /* the progress lines come in the reference's order (genodsp.c:909-921): chromosome by chromosome */
+			{ trackOperations = true;  continue; }
 		if (strcmp (arg, "--version") == 0)
 			{ fprintf (stderr, "%s (version %s; %s)\n", programName, programVersion, gdsp_version ());  exit (EXIT_SUCCESS); }
 		if (strcmp (arg, "--debug=input") == 0)   { dbgInput   = true;  continue; }
@@ -1765,6 +1768,9 @@ int main (int argc, char** argv)
 	set_named_global ("showUncovered", (valtype) showUncovered);
 	set_named_global ("originOne",     (valtype) originOne);
 	parse_options (argc, argv);
+	/* --progress=operations prints a line per operator and chromosome in the order they are applied; the reference applies
+	 * them chromosome by chromosome (genodsp.c:909-921), so that order is kept there unless --batch asks otherwise */
+	if (batchLaunches < 0) batchLaunches = !trackOperations;
 
 	if (showShards)
 		{

@@ -199,7 +199,7 @@ def test_base_sharding_prints_what_the_reference_printed(case, tmp_path, monkeyp
     test box.  Same bytes as the reference binary."""
     import hashlib
     monkeypatch.setenv("GDSP_OVERSUBSCRIBE_GPUS", "1")
-    rc, out, err = run(["--gpus=3", "--sharding=bases", "--progress=operations"] + case["args"], case["stdin"],
+    rc, out, err = run(["--gpus=3", "--sharding=bases", "--progress=operations", "--batch"] + case["args"], case["stdin"],
                        case["chroms_text"], tmp_path, case.get("files"))
     assert rc == 0, err
     assert hashlib.sha256(out.encode()).hexdigest() == case["sha256"], (case["args"], out[:300])
@@ -231,7 +231,7 @@ def test_base_sharding_cuts_chromosomes_and_matches_whole_chromosomes(tmp_path, 
     for pl in pipelines:
         got = {}
         for how in ("chromosomes", "bases"):
-            rc, out, err = run(["--precision=10", "--gpus=4", "--sharding=" + how, "--progress=operations"] + pl, iv, chroms, tmp_path)
+            rc, out, err = run(["--precision=10", "--gpus=4", "--sharding=" + how, "--progress=operations", "--batch"] + pl, iv, chroms, tmp_path)
             assert rc == 0, err
             got[how] = out
             if how == "bases" and pl[1] != "percentile":
@@ -242,6 +242,24 @@ def test_base_sharding_cuts_chromosomes_and_matches_whole_chromosomes(tmp_path, 
                     assert ("%s(chrL:0-" % first) in err and ("%s(chrS:0-7000)" % first) in err, err[-1500:]
         assert got["bases"] == got["chromosomes"], pl
         assert len(got["bases"].splitlines()) >= 2
+
+
+def test_progress_lines_come_in_the_reference_order(tmp_path):
+    """--progress=operations: the reference applies a run of operators chromosome by chromosome, longest first
+    (genodsp.c:909-921), and prints `operator(chromosome)` as it goes; the driver keeps that order when the lines are
+    asked for (one launch per operator and device otherwise, or with --batch), and prints the same signal either way."""
+    chroms = "chrA 5000\nchrB 9000\n"
+    iv = "chrA 10 400 2\nchrB 100 900 3\nchrB 500 2500 1\n"
+    pl = ["=", "addconst", "1", "=", "clip", "--max=3", "=", "abs"]
+    rc, out, err = run(["--progress=operations"] + pl, iv, chroms, tmp_path)
+    assert rc == 0, err
+    ops = [l for l in err.splitlines() if l.split("(")[0] in ("addconst", "clip", "abs")]
+    assert ops == ["addconst(chrB)", "clip(chrB)", "abs(chrB)", "addconst(chrA)", "clip(chrA)", "abs(chrA)"], err
+    rc, out2, err2 = run(["--progress=operations", "--batch"] + pl, iv, chroms, tmp_path)
+    assert rc == 0, err2
+    ops2 = [l for l in err2.splitlines() if l.split("(")[0] in ("addconst", "clip", "abs")]
+    assert ops2 == ["addconst(chrB)", "addconst(chrA)", "clip(chrB)", "clip(chrA)", "abs(chrB)", "abs(chrA)"], err2
+    assert out == out2
 
 
 def test_rccl_communicator_reduces_percentile_and_invert(tmp_path, monkeypatch):
@@ -264,7 +282,7 @@ def test_rccl_communicator_reduces_percentile_and_invert(tmp_path, monkeypatch):
     got = {}
     for how in ("host", "rccl"):
         for route in ("radix", "bracket"):
-            rc, out, err = run(["--precision=12", "--reduce=" + how, "--percentile=" + route, "--progress=operations",
+            rc, out, err = run(["--precision=12", "--reduce=" + how, "--percentile=" + route, "--progress=operations", "--batch",
                                 "=", "percentile", "5..95by15", "--min=-1", "=", "clip", "--max=percentile80", "=", "invert",
                                 "=", "percentile", "0,100", "=", "variables"], iv, chroms, tmp_path)
             assert rc == 0, err
