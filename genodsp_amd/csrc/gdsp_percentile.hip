@@ -154,7 +154,7 @@ struct PcResident
 	int      jLo, jHi;
 	uint64_t N, candCount, overflow;                           // after the counting pass: population, candidates kept, list overflowed
 	uint64_t bins[2*PC_MAX_PIVOTS + 1];
-	uint32_t how[PC_RES_MAXP];                                 // 0: answered (a pivot's ties, or nothing to answer)  1: an order statistic of the candidates  2: needs the plain route
+	uint32_t how[PC_RES_MAXP];                                 // 0: answered (a pivot's ties, or nothing to answer)  1: an order statistic of the candidates  2: needs the plain route  3: the selects in LDS gave up: the candidates' digits, from the host
 	uint64_t scopeLo[PC_RES_MAXP], scopeHi[PC_RES_MAXP], rankIn[PC_RES_MAXP], binCount[PC_RES_MAXP];
 	uint32_t candTop[PC_RES_MAXP];                             // the bits of the scope's keys below their common prefix
 	double   values[PC_RES_MAXP];
@@ -1264,7 +1264,7 @@ void pc_ls_cand_sub_kernel (const uint64_t* __restrict__ keys, const unsigned lo
 		return;
 		}
 	if (threadIdx.x >= 64) return;
-	if (m < 2) { if (threadIdx.x == 0) R->how[which] = 2;  return; }   // (nothing to lay a grid on: the plain route)
+	if (m < 2) { if (threadIdx.x == 0) R->how[which] = 3;  return; }   // (nothing to lay a grid on: the plain route)
 	const double q  = (double) rank / (double) inBin;
 	const double ks = floor ((double) m * q);
 	const double dl = ceil (4.0 * sqrt ((double) m * q * (1.0 - q))) + 8.0;
@@ -1278,7 +1278,8 @@ void pc_ls_cand_sub_kernel (const uint64_t* __restrict__ keys, const unsigned lo
 // keptCap keys); the last workgroup finds the cell of the rank and sorts its keys.
 __global__ __launch_bounds__(PC_RES_THREADS)
 void pc_ls_cand_pick_kernel (const uint64_t* __restrict__ keys, const unsigned long long* __restrict__ countPtr, unsigned long long countCap,
-                             int which, PcResident* __restrict__ R, PcResHist* __restrict__ H, uint64_t* __restrict__ kept, unsigned long long keptCap)
+                             int which, PcResident* __restrict__ R, PcResHist* __restrict__ H, uint64_t* __restrict__ kept, unsigned long long keptCap,
+                             int giveUp)                       // (tests: behave as if the cell had outgrown LDS)
 	{
 	__shared__ uint64_t a[PC_LS_KEYS];
 	__shared__ uint64_t grid[PC_LS_GRID];
@@ -1369,10 +1370,11 @@ void pc_ls_cand_pick_kernel (const uint64_t* __restrict__ keys, const unsigned l
 			{
 			sCell = -1;  sBefore = 0;
 			if (total != inBin) R->status = PC_RES_DISAGREE;
+			else if (giveUp) R->how[which] = 3;
 			else if (mOn != 0) { R->values[which] = gdsp_value_of (grid[__builtin_ctzll (mOn)]);  R->candDone[which] = 1; }
 			else if ((mOpen != 0) && (__builtin_ctzll (mOpen) >= 1) && (__builtin_ctzll (mOpen) < g)
 			         && (H->compactCount <= keptCap)) sCell = (long long) __builtin_ctzll (mOpen);
-			else R->how[which] = 2;                                // beyond the grid's span, or more kept than there was room for
+			else R->how[which] = 3;                                // beyond the grid's span, or more kept than there was room for
 			}
 		if (inOpen && (mOn == 0)) sBefore = before;
 		}
@@ -1382,7 +1384,7 @@ void pc_ls_cand_pick_kernel (const uint64_t* __restrict__ keys, const unsigned l
 		{
 		const uint64_t lo = grid[cell - 1], hi = grid[cell];       // the cell's keys lie strictly between
 		const unsigned long long nkept = H->compactCount, want = pc_ls_open (H, 0)[cell];
-		if (want > PC_LS_KEYS) { if (p == 0) R->how[which] = 2; }
+		if (want > PC_LS_KEYS) { if (p == 0) R->how[which] = 3; }
 		else
 			{
 			if (p == 0) sCount = 0;
@@ -1561,7 +1563,7 @@ void pc_res_fixup_kernel (const double* __restrict__ v, double* __restrict__ out
                           const unsigned long long* __restrict__ posCount, uint32_t cap, const PcResident* __restrict__ R, int which,
                           int tiesAbove, double one, double zero)
 	{
-	if ((R->status != PC_RES_OK) || (R->N == 0) || (R->how[which] == 2)) return;
+	if ((R->status != PC_RES_OK) || (R->N == 0) || (R->how[which] >= 2)) return;
 	const double T = R->values[which];
 	if (!((T >= R->vLo) && (T <= R->vHi))) return;
 	const unsigned long long count = *posCount;
@@ -1580,7 +1582,7 @@ struct PcFixTab { const double* v[PC_TAB];  double* out[PC_TAB];  const uint32_t
 __global__ __launch_bounds__(PC_THREADS)
 void pc_res_fixup_tab_kernel (PcFixTab T, const PcResident* __restrict__ R, int which, int tiesAbove, double one, double zero)
 	{
-	if ((R->status != PC_RES_OK) || (R->N == 0) || (R->how[which] == 2)) return;
+	if ((R->status != PC_RES_OK) || (R->N == 0) || (R->how[which] >= 2)) return;
 	const double thr = R->values[which];
 	if (!((thr >= R->vLo) && (thr <= R->vHi))) return;
 	const double* __restrict__ v = T.v[blockIdx.y];
@@ -2190,7 +2192,8 @@ static int pc_resident (PcJob& J, const uint32_t* pThousandths, int np, uint32_t
 			                    (unsigned long long) sc->candCap, i, R[0]);
 			// (the subsample has served: its buffer keeps what the pass finds within the grid's span)
 			hipLaunchKernelGGL (pc_ls_cand_pick_kernel, dim3(blocks), dim3(PC_RES_THREADS), 0, st[0], (const uint64_t*) sc->cand, countPtr,
-			                    (unsigned long long) sc->candCap, i, R[0], H[0], sc->sample, (unsigned long long) sc->sampleCap);
+			                    (unsigned long long) sc->candCap, i, R[0], H[0], sc->sample, (unsigned long long) sc->sampleCap,
+			                    (getenv ("GDSP_PERCENTILE_LDS_GIVEUP") != NULL)? 1 : 0);
 			}
 		GDSP_LAUNCH_CHECK ();
 		}
@@ -2266,12 +2269,28 @@ static int pc_resident (PcJob& J, const uint32_t* pThousandths, int np, uint32_t
 	pcStats[1] = got.N;  pcStats[3] = got.candCount;  pcStats[5]++;  pcStats[7] = 1;
 	if (got.N == 0) return GDSP_OK;
 	std::vector<int> fallback;
-	for (int i=0 ; i<np ; i++) { if (got.how[i] == 2) fallback.push_back (i);  else values[i] = got.values[i]; }
-	J.fixupsDone = J.fusedAny && (got.how[fuseWhich < 0? 0 : fuseWhich] != 2);
+	for (int i=0 ; i<np ; i++)
+		{
+		if (got.how[i] == 2) fallback.push_back (i);
+		else if (got.how[i] == 3)
+			{
+			// the grid missed the rank, or its cell outgrew a workgroup's LDS (pc_ls_cand_*): the candidates are all there and
+			// so are the rank among them and their scope -- the digit passes over that short list, not over the population
+			PcScope inBin = { PC_OVER_CANDIDATES, 1, got.scopeLo[i], got.scopeHi[i] };
+			std::vector<uint64_t> cFirst (PC_HIST_WORDS), keys;
+			PC_TRY (pc_pass (J, inBin, 0, 0, cFirst.data ()));
+			if (pc_total (cFirst) != got.binCount[i]) { gdsp_set_error ("gdsp_percentiles: candidate list and counts disagree");  return GDSP_EHIP; }
+			PC_TRY (pc_select (J, inBin, cFirst, std::vector<uint64_t> (1, got.rankIn[i]), keys));
+			values[i] = gdsp_value_of (keys[0]);
+			pcStats[4]++;                                              // (counted with the fallbacks: more than the one read-back)
+			}
+		else values[i] = got.values[i];
+		}
+	J.fixupsDone = J.fusedAny && (got.how[fuseWhich < 0? 0 : fuseWhich] < 2);
 	if (!fallback.empty ())
 		{
 		uint64_t again = 0;
-		pcStats[4] = fallback.size ();
+		pcStats[4] += fallback.size ();
 		PC_TRY (pc_radix (J, pThousandths, fallback, values, &again));
 		}
 	return GDSP_OK;

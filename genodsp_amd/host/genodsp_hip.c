@@ -1781,6 +1781,7 @@ int main (int argc, char** argv)
 		return EXIT_SUCCESS;
 		}
 
+	const double tStart = now_ms ();
 	int available = 0;
 	check_gdsp (gdsp_device_count (&available), "count GPUs");
 	if (available < 1) { fprintf (stderr, "[%s] no GPU visible\n", programName);  return EXIT_FAILURE; }
@@ -1798,8 +1799,17 @@ int main (int argc, char** argv)
 	sort_chromosomes_by_length ();
 	deal_chromosomes ();
 	if (shardBases) plan_pieces ();                            /* (before allocation: stretches count towards scratch sizes) */
+	const double tAlloc = now_ms ();
 	allocate_vectors ();
 	if (shardBases) allocate_pieces ();
+	if (reportGpu)                                             /* what a run spends before its first interval: the rest of its wall time is the teardown at exit */
+		{
+		u64 bases = 0;
+		for (int i=0 ; chromsSorted[i]!=NULL ; i++) bases += chromsSorted[i]->length;
+		sync_all_devices ();
+		wall_phase (NULL, "start-up (HIP runtime, devices)", tAlloc - tStart, (u64) numDevices, "devices", 0);
+		wall_phase (NULL, "allocate (vectors and partners)", now_ms () - tAlloc, bases, "values", 0);
+		}
 
 	/* stdin is the signal unless the first operator is `input` (genodsp.c:891-893) */
 	if ((pipeline == NULL) || (strcmp (pipeline->name, "input") != 0))

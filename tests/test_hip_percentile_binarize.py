@@ -63,7 +63,10 @@ def test_fused_leaves_sources_intact_and_reports_nothing_when_nothing_qualifies(
 
 # resident: decided on the device, its selects in one workgroup's LDS (pc_ls_*); resident_digits: the same with a launch
 # per radix digit (what a call across ranks takes); chained / host: the digits with five read-backs / one per digit
-ROUTES = {"resident": {}, "resident_digits": {"GDSP_PERCENTILE_LDS_SELECT": "0"}, "chained": {"GDSP_PERCENTILE_RESIDENT_OFF": "1"},
+# resident_gives_up: the LDS select of the candidates declares its cell too big (a hook): the answer then comes from digit
+# passes over the candidate list, asked for by the host after the read-back
+ROUTES = {"resident": {}, "resident_digits": {"GDSP_PERCENTILE_LDS_SELECT": "0"}, "resident_gives_up": {"GDSP_PERCENTILE_LDS_GIVEUP": "1"},
+          "chained": {"GDSP_PERCENTILE_RESIDENT_OFF": "1"},
           "host": {"GDSP_PERCENTILE_RESIDENT_OFF": "1", "GDSP_PERCENTILE_CHAIN_OFF": "1"}}
 
 
@@ -82,7 +85,7 @@ def test_the_routes_of_a_one_device_call_agree(n, gd, monkeypatch):
         for pts, kw in (([99000], {}), ([500, 50000, 99990], {}), ([75000], {"lo": 1.0, "hi": 60.0}), ([90000], {"window": 3})):
             seen = {}
             for route, env in ROUTES.items():
-                for k in ("GDSP_PERCENTILE_RESIDENT_OFF", "GDSP_PERCENTILE_CHAIN_OFF", "GDSP_PERCENTILE_LDS_SELECT"):
+                for k in ("GDSP_PERCENTILE_RESIDENT_OFF", "GDSP_PERCENTILE_CHAIN_OFF", "GDSP_PERCENTILE_LDS_SELECT", "GDSP_PERCENTILE_LDS_GIVEUP"):
                     monkeypatch.delenv(k, raising=False)
                 for k, v in env.items():
                     monkeypatch.setenv(k, v)
@@ -95,7 +98,7 @@ def test_the_routes_of_a_one_device_call_agree(n, gd, monkeypatch):
                 fused = gd.percentile_binarize(vecs, pts, which=len(pts) - 1, **kw)
                 seen[route] = (cnt, np.array(vals), fused[0], np.array(fused[1]), [o.numpy() for o in fused[2]])
             ref = seen["host"]
-            for route in ("resident", "resident_digits", "chained"):
+            for route in ("resident", "resident_digits", "resident_gives_up", "chained"):
                 got = seen[route]
                 assert got[0] == ref[0] and got[2] == ref[2] and bits_equal(got[1], ref[1]) and bits_equal(got[3], ref[3]), (name, pts, kw, route)
                 for a, b in zip(got[4], ref[4]):
