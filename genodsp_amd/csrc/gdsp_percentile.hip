@@ -191,19 +191,11 @@ struct PcFuse { double vLo, vHi, one, zero;  double* out;  uint32_t* pos;  unsig
 
 // bid / nblk: this workgroup's number among the workgroups of its source, and how many those are (the whole grid when the
 // launch covers one source; a stretch of it when a table of sources shares one launch, pc_partition_tab_kernel below)
-// TW (one tile per workgroup, pc_partition_tiles_kernel): bid is the workgroup's one tile; what it keeps -- candidates, and the
-// fused binarize's undecided positions as 16-bit offsets into the tile -- goes to the tile's OWN slots (tw.*), counts beside
-// them, so that no two workgroups ever add to one address.
-struct PcTileSlots { uint64_t* cand;  uint32_t* candCount;  uint16_t* pos;  uint32_t* posCount;  uint32_t tile; };   // `tile`: the tile's number in the device's slot arrays
-#define PC_TS_CAND  64                                         // candidates a tile can keep (0.13 % of real-valued coverage is 5)
-#define PC_TS_POS   256                                        // undecided positions (pivot ties included: a few per cent of read depth)
-#define PC_TS_OVER  0xFFFFFFFFu                                // a tile's count when it had more
-template <int M, bool BOUNDED, bool DENSE, bool FUSE, bool TW = false>
+template <int M, bool BOUNDED, bool DENSE, bool FUSE>
 __device__ __forceinline__
 void pc_partition_body (const double* __restrict__ v, uint32_t n, uint32_t window, double lo, double hi, PcPivots P,
                         unsigned long long* __restrict__ ctr, uint64_t* __restrict__ cand, unsigned long long cap,
-                        uint32_t ntiles, PcFuse F, const PcResident* __restrict__ res, const uint32_t bid, const uint32_t nblk,
-                        const PcTileSlots tw = PcTileSlots ())
+                        uint32_t ntiles, PcFuse F, const PcResident* __restrict__ res, const uint32_t bid, const uint32_t nblk)
 	{
 	constexpr int NC = 2*M + 5;                                // counters of this instantiation
 	if (res != NULL)                                           // the resident route: pivots and bracket were decided on the device
@@ -233,10 +225,8 @@ void pc_partition_body (const double* __restrict__ v, uint32_t n, uint32_t windo
 	for (int j=0 ; j<=M ; j++) take[j] = ((P.collect >> j) & 1)? ~0ULL : 0ULL;
 	const uint64_t takeTop = ((P.collect >> P.m) & 1)? ~0ULL : 0ULL;    // bin m (pivots beyond m are NaN pads)
 
-	bool twOver = false, twUOver = false;                        // TW: a wave's buffer filled up inside the tile (wave uniform)
 	auto flush = [&] ()
 		{
-		if (TW) { twOver = true;  held = 0;  return; }
 		unsigned long long base = 0;
 		if (lane == 0) base = atomicAdd (candCount, (unsigned long long) held);
 		base = __shfl (base, 0, 64);
@@ -345,7 +335,6 @@ void pc_partition_body (const double* __restrict__ v, uint32_t n, uint32_t windo
 
 	auto uflush = [&] ()
 		{
-		if (TW) { twUOver = true;  uheld = 0;  return; }
 		unsigned long long base = 0;
 		if (lane == 0) base = atomicAdd (F.posCount, (unsigned long long) uheld);
 		base = __shfl (base, 0, 64);
@@ -448,13 +437,6 @@ void pc_partition_body (const double* __restrict__ v, uint32_t n, uint32_t windo
 		const uint32_t whole = (uint32_t) (npop / PC_TILE);
 		uint32_t tile = bid;
 		double2 A[4], B[4];
-		if (TW)                                                    // the one tile: all eight loads on their way, then the two halves
-			{
-			if (tile < whole) { load_half (tile, 0, A);  load_half (tile, 1, B);  work_half (tile, 0, A);  work_half (tile, 1, B); }
-			else tile_plain (tile);
-			}
-		else
-		{
 		if (tile < whole) load_half (tile, 0, A);
 		while (tile < whole)
 			{
@@ -467,44 +449,10 @@ void pc_partition_body (const double* __restrict__ v, uint32_t n, uint32_t windo
 			}
 		if ((whole < ntiles) && (whole % step == bid)) tile_plain (whole);
 		}
-		}
 	else
 		for (uint32_t tile=bid ; tile<ntiles ; tile+=step) tile_plain (tile);
-	if (TW)
-		{
-		// the four waves' buffers one behind the other in the tile's slots
-		__shared__ uint32_t twHeld[PC_THREADS/64][2];
-		if (lane == 0) { twHeld[wave][0] = twOver? PC_TS_OVER : held;  twHeld[wave][1] = twUOver? PC_TS_OVER : uheld; }
-		__syncthreads ();
-		uint32_t before[2] = { 0, 0 }, all[2] = { 0, 0 };
-		bool over[2] = { false, false };
-#pragma unroll
-		for (int w=0 ; w<PC_THREADS/64 ; w++)
-			for (int k=0 ; k<2 ; k++)
-				{
-				const uint32_t c = twHeld[w][k];
-				if (c == PC_TS_OVER) over[k] = true;
-				else { if (w < wave) before[k] += c;  all[k] += c; }
-				}
-		if (all[0] > PC_TS_CAND) over[0] = true;
-		if (all[1] > PC_TS_POS)  over[1] = true;
-		if (threadIdx.x == 0)
-			{
-			tw.candCount[tw.tile] = over[0]? PC_TS_OVER : all[0];
-			if (FUSE) tw.posCount[tw.tile] = over[1]? PC_TS_OVER : all[1];
-			}
-		if (!over[0]) { for (uint32_t i=lane ; i<held ; i+=64) tw.cand[(size_t) tw.tile * PC_TS_CAND + before[0] + i] = wbuf[wave][i]; }
-		if (FUSE && !over[1])
-			{
-			const size_t tileStart = (size_t) bid * PC_TILE;
-			for (uint32_t i=lane ; i<uheld ; i+=64) tw.pos[(size_t) tw.tile * PC_TS_POS + before[1] + i] = (uint16_t) (ubuf[wave][i] - tileStart);
-			}
-		}
-	else
-		{
-		if (held) flush ();
-		if (FUSE && uheld) uflush ();
-		}
+	if (held) flush ();
+	if (FUSE && uheld) uflush ();
 
 	auto wave_sum = [&] (uint32_t c)
 		{
@@ -555,97 +503,6 @@ void pc_partition_tab_kernel (PcCountTab T, uint32_t window, double lo, double h
 	if (FUSE) { F.out = T.out[i];  F.pos = T.pos[i];  F.posCount = T.posCount[i];  F.posCap = T.posCap[i]; }
 	pc_partition_body<M, BOUNDED, DENSE, FUSE> (T.v[i], T.n[i], window, lo, hi, P, ctr, cand, cap, T.ntiles[i], F, res,
 	                                            blockIdx.x - T.block0[i], T.block0[i + 1] - T.block0[i]);
-	}
-
-// One tile per workgroup.  On this part a 1:1 read / write stream runs 8-12 % faster when every 32 KiB tile is a short
-// workgroup of its own, dealt out by the hardware in order, three to a CU, than when persistent workgroups walk the tiles
-// -- strided, in contiguous stretches, or taking them from a counter (tools/stream_shapes.hip,
-// profiles/r04_stream_shapes.txt: 6.2 against 5.5-5.8 TB/s out of place) -- PROVIDED the workgroups do not meet at one
-// address when they end: one returning atomic per workgroup on one address costs 17 %, on one of eight nothing, a few
-// plain stores nothing.  So here a workgroup's candidates and undecided positions go to its tile's own slots and its
-// counters to one of 64 replicas; pc_tiles_gather_kernel then lines the candidates up for the selects.  T.block0 counts
-// TILES here; tileBase is the first tile of this launch in the device's slot arrays.
-template <int M, bool BOUNDED, bool FUSE>
-__global__ __launch_bounds__(PC_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
-void pc_partition_tiles_kernel (PcCountTab T, uint32_t window, double lo, double hi, PcPivots P,
-                                unsigned long long* __restrict__ ctr, PcFuse F, const PcResident* __restrict__ res,
-                                PcTileSlots S, uint32_t tileBase)
-	{
-	const uint32_t g = gdsp_xcd_tile (blockIdx.x, T.block0[T.nsrc]);
-	int i = 0;
-	while ((i + 1 < T.nsrc) && (T.block0[i + 1] <= g)) i++;
-	if (FUSE) F.out = T.out[i];
-	S.tile = tileBase + g;
-	pc_partition_body<M, BOUNDED, true, FUSE, true> (T.v[i], T.n[i], window, lo, hi, P, ctr, NULL, 0, T.ntiles[i], F, res,
-	                                                 g - T.block0[i], 1, S);
-	}
-
-// the tiles' candidates, one stretch of the list per workgroup of 256 tiles (one atomic per workgroup reserves it); a tile
-// that kept more than its slots hold makes the list overflow (count > cap: what the selects and the host look at)
-__global__ __launch_bounds__(PC_THREADS)
-void pc_tiles_gather_kernel (const uint64_t* __restrict__ slots, const uint32_t* __restrict__ slotCount, uint32_t ntiles,
-                             uint64_t* __restrict__ cand, unsigned long long* __restrict__ candCount, unsigned long long cap,
-                             const PcResident* __restrict__ res)
-	{
-	__shared__ uint32_t waveTot[PC_THREADS/64];
-	__shared__ unsigned long long sBase;
-	if ((res != NULL) && (res->status != PC_RES_OK)) return;
-	const uint32_t t = blockIdx.x * PC_THREADS + threadIdx.x;
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	uint32_t c = (t < ntiles)? slotCount[t] : 0;
-	const bool over = (c == PC_TS_OVER);
-	if (over) c = 0;
-	uint32_t incl = c;
-	for (int d=1 ; d<64 ; d*=2) { const uint32_t up = __shfl_up (incl, d, 64);  if (lane >= d) incl += up; }
-	if (lane == 63) waveTot[wave] = incl;
-	const bool anyOver = (__ballot (over) != 0);
-	__syncthreads ();
-	uint32_t before = incl - c, total = 0;
-	for (int w=0 ; w<PC_THREADS/64 ; w++) { if (w < wave) before += waveTot[w];  total += waveTot[w]; }
-	if (anyOver && (lane == 0)) atomicAdd (candCount, cap + 1);
-	if (threadIdx.x == 0) sBase = (total != 0)? atomicAdd (candCount, (unsigned long long) total) : 0;
-	__syncthreads ();
-	const unsigned long long at = sBase + before;
-	for (uint32_t k=0 ; k<c ; k++) { if (at + k < cap) cand[at + k] = slots[(size_t) t * PC_TS_CAND + k]; }
-	}
-
-// the fused binarize's undecided positions out of the tiles' slots, once the threshold is known (on the device: R; or
-// from the host: R == NULL and T given): a wave takes 16 tiles; every source's count is added up for the host, more than
-// its capacity when one of its tiles kept more positions than its slots hold (the host binarizes such a source whole)
-__global__ __launch_bounds__(PC_THREADS)
-void pc_fixup_tiles_kernel (PcCountTab T, const uint16_t* __restrict__ posSlots, const uint32_t* __restrict__ posSlotCount, uint32_t tileBase,
-                            const PcResident* __restrict__ R, int which, double Thost, int tiesAbove, double one, double zero)
-	{
-	double thr = Thost;
-	if (R != NULL)
-		{
-		if ((R->status != PC_RES_OK) || (R->N == 0) || (R->how[which] >= 2)) return;
-		thr = R->values[which];
-		if (!((thr >= R->vLo) && (thr <= R->vHi))) return;
-		}
-	const int lane = threadIdx.x & 63;
-	const uint32_t ntiles = T.block0[T.nsrc];
-	const uint32_t g0 = (blockIdx.x * (PC_THREADS / 64) + (threadIdx.x >> 6)) * 16;
-	int i = 0;
-	unsigned long long sum = 0;
-	auto flush = [&] () { if ((lane == 0) && (sum != 0)) atomicAdd (T.posCount[i], sum);  sum = 0; };
-	for (uint32_t g=g0 ; (g<g0+16) && (g<ntiles) ; g++)
-		{
-		if (T.block0[i + 1] <= g) { flush ();  while ((i + 1 < T.nsrc) && (T.block0[i + 1] <= g)) i++; }
-		const uint32_t c = posSlotCount[tileBase + g];
-		if (c == PC_TS_OVER) { sum += (unsigned long long) T.posCap[i] + 1;  continue; }
-		sum += c;
-		const double* __restrict__ v = T.v[i];
-		double* __restrict__ out = T.out[i];
-		const size_t start = (size_t) (g - T.block0[i]) * PC_TILE;
-		for (uint32_t k=lane ; k<c ; k+=64)
-			{
-			const size_t e = start + posSlots[(size_t) (tileBase + g) * PC_TS_POS + k];
-			const double x = v[e];
-			out[e] = (tiesAbove? (x >= thr) : (x > thr))? one : zero;
-			}
-		}
-	flush ();
 	}
 
 // one digit histogram over a short list of keys, restricted to keyLo <= key <= keyHi
@@ -1760,8 +1617,6 @@ struct PcDevice                                               // scratch of one 
 	unsigned long long* posCount;         // one counter per source (PC_MAX_FUSED_SOURCES)
 	PcChain*  chain;                      // ranks being looked up by the chained passes
 	PcResident* res;                      // the resident route's state, a PcResHist behind it (one allocation)
-	// the counting pass with one tile per workgroup (pc_partition_tiles_kernel): every tile's own slots
-	uint64_t* tsCand;  uint32_t* tsCandCount;  uint16_t* tsPos;  uint32_t* tsPosCount;  size_t tsTiles;
 	};
 #define PC_MAX_FUSED_SOURCES 256
 #define PC_TMP_WORDS 64
@@ -1832,9 +1687,6 @@ struct PcJob                                                  // one call of gds
 	std::vector<size_t>    posOffset, posCap;                 // per source
 	double                 vLo, vHi;                          // the bracket the fused stores relied on
 	bool                   fusedAny;
-	struct TileLaunch { size_t d;  PcCountTab T;  uint32_t tileBase; };
-	std::vector<TileLaunch> tileLaunches;                     // fused sources counted one tile per workgroup: their positions lie in the tiles' slots
-	std::vector<char>      tileMode;                          // per source
 	bool                   fixupsDone;                        // the resident route has patched the open positions already ...
 	std::vector<std::vector<unsigned long long> > queuedHost; // ... and these are the strips' counts it read back, per device
 	};
@@ -2136,36 +1988,6 @@ static int pc_count_launch (PcJob& J, const PcPivots& P, int mUse, bool bounded,
 		// GDSP_PERCENTILE_COUNT_PER_SOURCE=1: a launch per source (what rounds 2 and 3 measured), for the A/B on one box
 		const char* perSourceEnv = getenv ("GDSP_PERCENTILE_COUNT_PER_SOURCE");
 		const bool  perSource = (perSourceEnv != NULL) && (strcmp (perSourceEnv, "0") != 0);
-		// GDSP_PERCENTILE_TILES=0: persistent workgroups walking 16 tiles each (rounds 2-3) instead of one tile per workgroup
-		const char* tilesEnv = getenv ("GDSP_PERCENTILE_TILES");
-		const bool  tiles = !perSource && (mUse <= 2) && !((tilesEnv != NULL) && (strcmp (tilesEnv, "0") == 0));
-		PcDevice* sc = J.scratch[d];
-		uint32_t  tileBase = 0;
-		if (tiles)                                                 // every dense source's tiles get slots
-			{
-			size_t need = 0;
-			for (int i=0 ; i<J.nsrc ; i++)
-				{
-				if ((J.src[i].device != J.devices[d]) || (J.src[i].n == 0) || !((J.window == 1) && gdsp_aligned16 (J.src[i].d_v))) continue;
-				need += ((size_t) J.src[i].n + PC_TILE - 1) / PC_TILE;
-				}
-			if (sc->tsTiles < need)
-				{
-				if (sc->tsCand != NULL)
-					{
-					GDSP_HIP_TRY (hipStreamSynchronize (st));
-					GDSP_HIP_TRY (hipFree (sc->tsCand));  GDSP_HIP_TRY (hipFree (sc->tsCandCount));
-					GDSP_HIP_TRY (hipFree (sc->tsPos));   GDSP_HIP_TRY (hipFree (sc->tsPosCount));
-					sc->tsCand = NULL;  sc->tsTiles = 0;
-					}
-				const size_t want = need + need / 8 + 64;
-				GDSP_HIP_TRY (hipMalloc ((void**) &sc->tsCand,      want * PC_TS_CAND * sizeof(uint64_t)));
-				GDSP_HIP_TRY (hipMalloc ((void**) &sc->tsCandCount, want * sizeof(uint32_t)));
-				GDSP_HIP_TRY (hipMalloc ((void**) &sc->tsPos,       want * PC_TS_POS * sizeof(uint16_t)));
-				GDSP_HIP_TRY (hipMalloc ((void**) &sc->tsPosCount,  want * sizeof(uint32_t)));
-				sc->tsTiles = want;
-				}
-			}
 		// sources of one flavour (fused / dense / strided) share a launch, up to PC_TAB at a time
 		for (int flavour=0 ; flavour<3 ; flavour++)
 			{
@@ -2173,31 +1995,11 @@ static int pc_count_launch (PcJob& J, const PcPivots& P, int mUse, bool bounded,
 			memset (&T, 0, sizeof(T));
 			PcFuse F;
 			memset (&F, 0, sizeof(F));
-			const bool tw = tiles && (flavour < 2);
 			auto go = [&] ()
 				{
 				if (T.nsrc == 0) return;
 				const uint32_t blocks = T.block0[T.nsrc];
 				const bool fused = (flavour == 0), dense = (flavour == 1);
-				if (tw)
-					{
-					PcTileSlots S = { sc->tsCand, sc->tsCandCount, sc->tsPos, sc->tsPosCount, 0 };
-					if (fused)
-						{
-						if (bounded) hipLaunchKernelGGL ((pc_partition_tiles_kernel<2, true, true>),  dim3(blocks), dim3(PC_THREADS), 0, st, T, J.window, J.lo, J.hi, P, ctr, F, RES, S, tileBase);
-						else         hipLaunchKernelGGL ((pc_partition_tiles_kernel<2, false, true>), dim3(blocks), dim3(PC_THREADS), 0, st, T, J.window, J.lo, J.hi, P, ctr, F, RES, S, tileBase);
-						PcJob::TileLaunch L = { d, T, tileBase };
-						J.tileLaunches.push_back (L);
-						}
-					else
-						{
-						if (bounded) hipLaunchKernelGGL ((pc_partition_tiles_kernel<2, true, false>),  dim3(blocks), dim3(PC_THREADS), 0, st, T, J.window, J.lo, J.hi, P, ctr, F, RES, S, tileBase);
-						else         hipLaunchKernelGGL ((pc_partition_tiles_kernel<2, false, false>), dim3(blocks), dim3(PC_THREADS), 0, st, T, J.window, J.lo, J.hi, P, ctr, F, RES, S, tileBase);
-						}
-					tileBase += blocks;
-					T.nsrc = 0;
-					return;
-					}
 #define PC_LAUNCH_B(MM, BB)                                                                                                    \
 				do { if (fused) hipLaunchKernelGGL ((pc_partition_tab_kernel<MM, BB, true, true>),  dim3(blocks), dim3(PC_THREADS), 0, \
 				                                     st, T, J.window, J.lo, J.hi, P, ctr,                                            \
@@ -2223,12 +2025,11 @@ static int pc_count_launch (PcJob& J, const PcPivots& P, int mUse, bool bounded,
 				if ((J.src[i].device != J.devices[d]) || (J.src[i].n == 0)) continue;
 				const size_t   p      = ((size_t) J.src[i].n + J.window - 1) / J.window;
 				const uint32_t ntiles = (uint32_t) ((p + PC_TILE - 1) / PC_TILE);
-				const uint32_t perWG  = tw? 1 : std::max<uint32_t> (1, std::min<uint32_t> (PC_TILES_PER_WG, ntiles / PC_MIN_WGS));
+				const uint32_t perWG  = std::max<uint32_t> (1, std::min<uint32_t> (PC_TILES_PER_WG, ntiles / PC_MIN_WGS));
 				const uint32_t blocks = (ntiles + perWG - 1) / perWG;
 				const bool     dense  = (J.window == 1) && gdsp_aligned16 (J.src[i].d_v);
 				const bool     fused  = (J.fusedSource[i] >= 0) && fuseUsable;
 				if ((fused? 0 : dense? 1 : 2) != flavour) continue;
-				J.tileMode[i] = tw? 1 : 0;
 				const int k = T.nsrc;
 				T.v[k] = J.src[i].d_v;  T.n[k] = J.src[i].n;  T.ntiles[k] = ntiles;  T.block0[k + 1] = T.block0[k] + blocks;
 				if (fused)
@@ -2245,13 +2046,6 @@ static int pc_count_launch (PcJob& J, const PcPivots& P, int mUse, bool bounded,
 				if ((T.nsrc == PC_TAB) || perSource) { go ();  GDSP_LAUNCH_CHECK (); }
 				}
 			go ();
-			GDSP_LAUNCH_CHECK ();
-			}
-		if (tileBase != 0)                                         // the tiles' candidates into the list the selects read
-			{
-			hipLaunchKernelGGL (pc_tiles_gather_kernel, dim3((tileBase + PC_THREADS - 1) / PC_THREADS), dim3(PC_THREADS), 0, st,
-			                    (const uint64_t*) sc->tsCand, (const uint32_t*) sc->tsCandCount, tileBase, sc->cand,
-			                    ctr + (size_t) PC_REPL * PC_CTR_WORDS, (unsigned long long) sc->candCap, RES);
 			GDSP_LAUNCH_CHECK ();
 			}
 		}
@@ -2407,15 +2201,6 @@ static int pc_resident (PcJob& J, const uint32_t* pThousandths, int np, uint32_t
 		for (int i=0 ; i<np ; i++)
 			for (int digit=0 ; digit<PC_DIGITS ; digit++) PC_TRY (digit_pass (PC_RES_CAND, digit, i));
 	// the fused binarize's open positions
-	for (const PcJob::TileLaunch& L : J.tileLaunches)              // (sources counted one tile per workgroup: out of the tiles' slots)
-		{
-		GDSP_HIP_TRY (hipSetDevice (J.devices[L.d]));
-		const uint32_t ntiles = L.T.block0[L.T.nsrc];
-		hipLaunchKernelGGL (pc_fixup_tiles_kernel, dim3((ntiles + 63) / 64), dim3(PC_THREADS), 0, st[L.d], L.T, (const uint16_t*) J.scratch[L.d]->tsPos,
-		                    (const uint32_t*) J.scratch[L.d]->tsPosCount, L.tileBase, (const PcResident*) R[L.d], fuseWhich, 0.0,
-		                    J.fuse->tiesAbove, J.fuse->one, J.fuse->zero);
-		GDSP_LAUNCH_CHECK ();
-		}
 	if (J.fusedAny)
 		{
 		for (size_t d=0 ; d<ND ; d++)
@@ -2437,7 +2222,7 @@ static int pc_resident (PcJob& J, const uint32_t* pThousandths, int np, uint32_t
 				};
 			for (int i=0 ; i<J.nsrc ; i++)
 				{
-				if ((J.fusedSource[i] < 0) || (J.src[i].device != J.devices[d]) || J.tileMode[i]) continue;
+				if ((J.fusedSource[i] < 0) || (J.src[i].device != J.devices[d])) continue;
 				T.v[k] = J.src[i].d_v;  T.out[k] = J.fuse->d_out[i];  T.pos[k] = sc->pos + J.posOffset[i];
 				T.posCount[k] = sc->posCount + J.fusedSource[i];  T.cap[k] = (uint32_t) J.posCap[i];
 				most = std::max<size_t> (most, J.src[i].n);
@@ -2600,7 +2385,6 @@ static int pc_run (const gdsp_select_source* sources, int nsources, uint32_t win
 	// fused binarize: a strip of positions per dense source (a sixteenth of its bases; more undecided than that and the
 	// source is binarized by a pass of its own)
 	J.fusedSource.assign (nsources, -1);  J.posOffset.assign (nsources, 0);  J.posCap.assign (nsources, 0);  J.fusedAny = false;
-	J.tileMode.assign (nsources, 0);  J.tileLaunches.clear ();
 	if ((J.fuse != NULL) && bracket && (window == 1))
 		{
 		for (size_t d=0 ; d<J.devices.size () ; d++)
@@ -2849,15 +2633,6 @@ static int pc_finish_binarize (PcJob& J, double T, bool* onePass)
 	if (bracketHolds && J.fixupsDone) queued = J.queuedHost;       // (the resident route: counts read back already)
 	else if (bracketHolds)
 		{
-		for (const PcJob::TileLaunch& L : J.tileLaunches)          // positions in the tiles' slots: patched now, counted per source for the check below
-			{
-			GDSP_HIP_TRY (hipSetDevice (J.devices[L.d]));
-			const uint32_t ntiles = L.T.block0[L.T.nsrc];
-			hipLaunchKernelGGL (pc_fixup_tiles_kernel, dim3((ntiles + 63) / 64), dim3(PC_THREADS), 0, gdsp_stream (J.stream[L.d]), L.T,
-			                    (const uint16_t*) J.scratch[L.d]->tsPos, (const uint32_t*) J.scratch[L.d]->tsPosCount, L.tileBase,
-			                    (const PcResident*) NULL, 0, T, f->tiesAbove, f->one, f->zero);
-			GDSP_LAUNCH_CHECK ();
-			}
 		for (size_t d=0 ; d<J.devices.size () ; d++)
 			{
 			queued[d].assign (PC_MAX_FUSED_SOURCES, 0);
@@ -2880,7 +2655,7 @@ static int pc_finish_binarize (PcJob& J, double T, bool* onePass)
 		if ((slot >= 0) && (queued[d][slot] <= J.posCap[i]))
 			{
 			const unsigned long long count = queued[d][slot];
-			if ((count == 0) || J.fixupsDone || J.tileMode[i]) continue;
+			if ((count == 0) || J.fixupsDone) continue;
 			const uint32_t blocks = (uint32_t) std::min<unsigned long long> (2048, (count + PC_THREADS - 1) / PC_THREADS);
 			hipLaunchKernelGGL (pc_fixup_kernel, dim3(blocks), dim3(PC_THREADS), 0, st, J.src[i].d_v, f->d_out[i],
 			                    J.scratch[d]->pos + J.posOffset[i], J.scratch[d]->posCount + slot, (uint32_t) J.posCap[i],
