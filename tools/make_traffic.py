@@ -72,7 +72,7 @@ for path in sorted(glob.glob(os.path.join(root, tag + "_prof_*.txt"))):
             if "tab_kernel" not in name and "batch" not in name and name.startswith("pc_"):
                 launch_bases = bases // 3
         entry = {"source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; tools/prof_any.sh)" % os.path.basename(path),
-                 "library": lib, "bases_per_launch": launch_bases, "fetch_bytes": fetch, "write_bytes": write}
+                 "library": (built.split()[-1] if built else lib), "bases_per_launch": launch_bases, "fetch_bytes": fetch, "write_bytes": write}
         if per_base is not None:
             entry["algorithmic_bytes"] = per_base * launch_bases
             entry["hbm_bytes_over_algorithmic"] = round((fetch + write) / (per_base * launch_bases), 4)
