@@ -127,3 +127,23 @@ def test_resident_route_gives_way_when_it_cannot_settle_a_call(gd):
     got = gd.percentile([v], nine)
     assert gd.percentile_stats()["resident"] == 0
     assert got[0] == want[0] and bits_equal(np.array(got[1]), np.array(want[1]))
+
+
+def test_eight_percentiles_in_one_resident_call_equal_the_oracle(gd, monkeypatch):
+    """The most percentiles the resident route's state holds, in one call: one workgroup lays eight grids (a wave each)
+    over its sorted share of the subsample, one pass counts the subsample into all eight, and the candidates of every
+    percentile that landed in a bracket go through their own two launches (pc_ls_*).  Values are the oracle's exact order
+    statistics (percentile.c:587-589 for the rank), with and without bounds, on coverage, read depth and noise with NaNs."""
+    for k in ("GDSP_PERCENTILE_RESIDENT_OFF", "GDSP_PERCENTILE_CHAIN_OFF", "GDSP_PERCENTILE_LDS_SELECT", "GDSP_PERCENTILE_LDS_GIVEUP"):
+        monkeypatch.delenv(k, raising=False)
+    n = 2_600_003
+    pts = [100, 2500, 25000, 50000, 75000, 97500, 99900, 99999]
+    for name, x in signals(n, 11).items():
+        vecs = [gd.DeviceVector.from_numpy(x[: n // 2]), gd.DeviceVector.from_numpy(x[n // 2:])]
+        for kw in ({}, {"lo": 0.5, "hi": 55.0}):
+            cnt, vals = gd.percentile(vecs, pts, **kw)
+            st = gd.percentile_stats()
+            wcnt, wvals = cpu.percentile([x[: n // 2], x[n // 2:]], pts, **kw)
+            assert cnt == wcnt and bits_equal(np.array(vals), np.array(wvals)), (name, kw, vals, wvals)
+            if not name.startswith("noise"):                      # (a NaN among the pivots sends the call the old way)
+                assert st["resident"] == 1, (name, kw, st)
