@@ -133,7 +133,8 @@ def test_eight_percentiles_in_one_resident_call_equal_the_oracle(gd, monkeypatch
     """The most percentiles the resident route's state holds, in one call: one workgroup lays eight grids (a wave each)
     over its sorted share of the subsample, one pass counts the subsample into all eight, and the candidates of every
     percentile that landed in a bracket go through their own two launches (pc_ls_*).  Values are the oracle's exact order
-    statistics (percentile.c:587-589 for the rank), with and without bounds, on coverage, read depth and noise with NaNs."""
+    statistics (percentile.c:587-589 for the rank), with and without bounds, on coverage and read depth; on noise with NaNs
+    and infinities the plain radix route's."""
     for k in ("GDSP_PERCENTILE_RESIDENT_OFF", "GDSP_PERCENTILE_CHAIN_OFF", "GDSP_PERCENTILE_LDS_SELECT", "GDSP_PERCENTILE_LDS_GIVEUP"):
         monkeypatch.delenv(k, raising=False)
     n = 2_600_003
@@ -143,7 +144,12 @@ def test_eight_percentiles_in_one_resident_call_equal_the_oracle(gd, monkeypatch
         for kw in ({}, {"lo": 0.5, "hi": 55.0}):
             cnt, vals = gd.percentile(vecs, pts, **kw)
             st = gd.percentile_stats()
-            wcnt, wvals = cpu.percentile([x[: n // 2], x[n // 2:]], pts, **kw)
-            assert cnt == wcnt and bits_equal(np.array(vals), np.array(wvals)), (name, kw, vals, wvals)
-            if not name.startswith("noise"):                      # (a NaN among the pivots sends the call the old way)
+            if name.startswith("noise"):
+                # NaNs in the population: the reference's qsort comparator (genodsp.c:2262-2270) is not an order on them and
+                # the oracle's values are whatever its sort leaves; the plain radix route on the keys' order is the yardstick
+                # (and a NaN among the pivots sends the call the old way: no claim on the route)
+                wcnt, wvals = gd.percentile(vecs, pts, strategy=gd.SELECT_RADIX, **kw)
+            else:
+                wcnt, wvals = cpu.percentile([x[: n // 2], x[n // 2:]], pts, **kw)
                 assert st["resident"] == 1, (name, kw, st)
+            assert cnt == wcnt and bits_equal(np.array(vals), np.array(wvals)), (name, kw, vals, wvals)
