@@ -452,9 +452,11 @@ def other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_base
     kernels = WORKLOAD_KERNELS[args.workload]["nofuse" if args.nofuse else "fused"]
     if args.workload == "peaks":
         kernels = [k.replace("FMA", "false" if args.mode == "exact" else "true") for k in kernels]
-        if not args.nofuse and args.mode == "exact" and os.environ.get("GDSP_PEAKS_FILTER") != "0":
+        filtered = os.environ.get("GDSP_PEAKS_FILTER") not in (("0",) if args.mode == "exact" else ("0", "exact"))
+        if not args.nofuse and filtered:
             # the filtered route (gdsp_peaks.hip): block sums + interval test, then exact taps for what stays undecided
-            kernels = ["peaks_filter_kernel<101, false, true, 5>", "peaks_exact_kernel<101, false, true>",
+            fma = "false" if args.mode == "exact" else "true"
+            kernels = ["peaks_filter_kernel<101, %s, true, 5>" % fma, "peaks_exact_kernel<101, %s, true>" % fma,
                        "peaks_probe_kernel<101, true, 5>", "fir_fixed_extrema_gated_kernel (leaves at once)"]
     if batch:
         kernels = [k if k.startswith(("pc_", "peaks_", "fir_fixed_extrema_gated")) else batch_name(k) for k in kernels]

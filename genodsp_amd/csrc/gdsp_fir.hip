@@ -659,8 +659,8 @@ extern "C" int gdsp_smooth_local_extrema_batch (const gdsp_batch_item* items, in
 	hipStream_t s = gdsp_stream (stream);
 	// the filtered route (gdsp_peaks.hip): block sums rule out ~99.5 % of the bases, the rest are evaluated tap by tap in
 	// the reference's arithmetic -- the same bits, off the FP64 pipe; tie-heavy vectors fall to the direct kernel on the
-	// device.  For EXACT (185 against 140 Gbases/s over the genome); one fused multiply-add per tap is fast enough for
-	// the direct kernel to win (215), so FMA takes the filter only when asked to (GDSP_PEAKS_FILTER=fma: tests)
+	// device.  EXACT: 278 against 133 Gbases/s over the genome; FMA (one fused multiply-add per tap in the exact chains and
+	// in the direct kernel) takes it as well since round 4 (gdsp_peaks_filter_wanted_for_fma)
 	if (gdsp_peaks_filter_available (W, N) && ((mode == GDSP_FIR_EXACT) || gdsp_peaks_filter_wanted_for_fma ()))
 		return gdsp_peaks_filter_batch (items, nitems, plan->h_taps, mode == GDSP_FIR_FMA, N, wantMax, fill, stream);
 	if (mode == GDSP_FIR_FMA)

@@ -680,9 +680,9 @@ def test_filtered_smooth_extrema_is_bit_identical(n, N, gd):
 
 
 def test_filtered_smooth_extrema_in_fma_arithmetic(gd):
-    """--smooth=fma through the same filter (GDSP_PEAKS_FILTER=fma; by default fma takes the direct kernel, which is the
-    faster one at one instruction per tap): the exact evaluations then fuse each tap, and the output is that of the fma
-    FIR followed by the neighbourhood test (the block sums are as close to fma's values as to the reference's)."""
+    """--smooth=fma through the same filter (the default since round 4; GDSP_PEAKS_FILTER=exact keeps fma on the direct
+    kernel): the exact evaluations then fuse each tap, and the output is that of the fma FIR followed by the neighbourhood
+    test (the block sums are as close to fma's values as to the reference's)."""
     rng = np.random.default_rng(77)
     for n in (3973, 20011):
         for name, x in _filter_cases(n, rng).items():
@@ -690,7 +690,7 @@ def test_filtered_smooth_extrema_in_fma_arithmetic(gd):
             sm = gd.smooth(d, 101, mode=gd.FIR_FMA)
             for want_max, fill in ((True, 0.0), (False, cpu.DBL_MAX)):
                 want = gd.local_extrema(sm, 11, want_max, fill).numpy()
-                for env in ({"GDSP_PEAKS_ROUTE": "filter", "GDSP_PEAKS_FILTER": "fma"}, {"GDSP_PEAKS_FILTER": "fma"}, {}):
+                for env in ({"GDSP_PEAKS_ROUTE": "filter"}, {}, {"GDSP_PEAKS_FILTER": "exact"}, {"GDSP_PEAKS_FILTER": "0"}):
                     os.environ.update(env)
                     try:
                         got = gd.smooth_local_extrema(d, 101, 11, want_max, fill, mode=gd.FIR_FMA).numpy()

@@ -14,6 +14,8 @@ done
 python bench.py --workload peaks --mode exact --steps 10 --warmup 2 --no-cpu-baseline >> $W.jsonl 2>> $W.err
 GDSP_PEAKS_FILTER=0 python bench.py --workload peaks --mode exact --steps 10 --warmup 2 --no-cpu-baseline >> $W.jsonl 2>> $W.err
 python bench.py --workload peaks --mode exact --nofuse --steps 10 --warmup 2 --no-cpu-baseline >> $W.jsonl 2>> $W.err
+# --smooth=fma in front of localmax: the filtered route (default since round 4) against the direct kernel
+GDSP_PEAKS_FILTER=exact python bench.py --workload peaks --steps 10 --warmup 2 --no-cpu-baseline >> $W.jsonl 2>> $W.err
 # one launch per chromosome instead of one per operator (what round 2 measured), for the A/B on one box
 python bench.py --launch chromosome --steps 10 --warmup 2 --no-cpu-baseline >> $W.jsonl 2>> $W.err
 for w in morph percentile; do python bench.py --launch chromosome --workload $w --steps 10 --warmup 2 --no-cpu-baseline >> $W.jsonl 2>> $W.err; done
