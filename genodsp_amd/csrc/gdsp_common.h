@@ -169,9 +169,10 @@ static inline void gdsp_batch_make (GdspBatch& B, const gdsp_batch_item* items, 
 // tiles counted, and how many bases the probe looked at.  A vector whose probe found more than PK_DIRECT_NUM/256 of its
 // bases undecided (piecewise-constant depth: every base of a flat run ties) is evaluated base by base by the direct
 // kernel instead -- decided on the device, the same way by every block of every launch.
-struct GdspPeaksCtl { uint32_t count, overflow, probe, sampled; };
+struct GdspPeaksCtl { uint32_t count, overflow, probe, sampled, flat; };   // flat: bases of the probed tiles that would be written their run's value (gdsp_peaks.hip, CWM)
 #define GDSP_PEAKS_DIRECT_NUM 3u
 __device__ __forceinline__ bool gdsp_peaks_takes_direct (const GdspPeaksCtl& c) { return (uint64_t) c.probe * 256u > (uint64_t) c.sampled * GDSP_PEAKS_DIRECT_NUM; }
+__device__ __forceinline__ bool gdsp_peaks_is_flat (const GdspPeaksCtl& c) { return (uint64_t) c.flat * 32u > (uint64_t) c.sampled; }   // more than an eighth of the probed bases (sampled counts quarter bases)
 
 // gdsp_fir.hip: the direct fused kernel over a table of vectors, gated: a block works only when its vector takes the direct
 // route (probe) or its queue overflowed

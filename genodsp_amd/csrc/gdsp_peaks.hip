@@ -11,10 +11,13 @@
 //   * a base of an all-zero window is exactly zero, and so are neighbours that do not beat it -> 0, no arithmetic;
 //   * the rest -- the local extrema of a smoothed signal and what ties with them, ~0.5 % of the bases of real-valued
 //     coverage -- are QUEUED (their positions, in HBM).
-// Four launches per table of vectors, no host round trip:
-//   P  probe: the filter on 64 tiles spread over each vector, counting only.  A vector on which more than 3/256 of the
-//      bases stay undecided (piecewise-constant read depth smooths into runs of exactly equal values: every base a
-//      tie) takes the direct kernel instead; every block of the later launches reads the same counters and decides alike.
+// Per table of vectors, one read-back of a few words:
+//   P  probe: the filter on 64 tiles spread over each vector, counting only: the bases that would stay undecided, and
+//      the bases of flat stretches (piecewise-constant read depth smooths into runs of exactly equal values: every base
+//      a tie, kept, and written its run's value by the CWM form of the filter, below).  The host reads the counts and
+//      launches the filter once per form over the vectors that take it; a vector on which more than 3/256 of the bases
+//      would stay undecided even so takes the direct kernel instead (every block of the later launches reads the same
+//      counters and decides alike).  GDSP_PEAKS_FLAT=0: no CWM form, no read-back (rounds 3-4a).
 //   A  filter: block sums -> interval test -> `fill` / 0 written with 16-byte stores, undecided bases queued in the tile's
 //      own strip in HBM (16-bit tile-local indices; an LDS atomic per wave).  LDS and registers of hann_blocks_kernel:
 //      3 workgroups per CU.
@@ -58,7 +61,7 @@ __global__ void peaks_init_kernel (GdspPeaksCtl* ctl, GdspBatch B, uint32_t stri
 	if (v >= GDSP_BATCH_MAX) return;
 	const uint32_t tiles = B.tile0[v+1] - B.tile0[v];
 	GdspPeaksCtl c;
-	c.count = 0;  c.overflow = 0;  c.probe = 0;
+	c.count = 0;  c.overflow = 0;  c.probe = 0;  c.flat = 0;
 	c.sampled = 4 * ((tiles < PK_PROBE_TILES)? tiles : PK_PROBE_TILES) * stride;     // quarter bases, like the probe's count
 	if (route == 1) c.sampled = 0x40000000u;                       // (a probe counts at most 4 x 64 x 3984 quarter bases: gdsp_peaks_takes_direct never says yes)
 	if (route == 2) { c.sampled = 0;  c.probe = 0x00800000u; }
@@ -73,14 +76,24 @@ __global__ void peaks_init_kernel (GdspPeaksCtl* ctl, GdspBatch B, uint32_t stri
 // real-valued coverage) gets its exact value right here, one lane per base, tap by tap from that image, in the
 // reference's order.  Only bases that tie or nearly tie with a neighbour -- the comparison itself needs exact values --
 // go to the tile's strip in HBM for the exact kernel.
-#define PK_SURE_CAP 256                                       // certain peaks a tile evaluates in place (one lane each); more go to the strip
+#define PK_SURE_CAP 256                                       // certain peaks a tile evaluates in place (one lane each); more go to the strip (CWM: less PK_LEAD_CAP)
+#define PK_LEAD_CAP 64                                        // runs of equal inputs whose shared value a tile evaluates (below); with PK_SURE_CAP a workgroup's worth of lanes
 // A tile with no more than PK_NEED_INPLACE undecided bases (the usual case on real-valued coverage: a flat top here and
 // there) settles them itself as well: one lane per neighbour evaluates its exact value in the same pass as the certain
 // peaks (the chain of 101 multiply-adds costs a wave the same whether 40 or 250 of its lanes run it), the comparison of
 // minmax.c:1195-1216 follows on those values.  Such a tile is not listed for the exact kernel, which round 3 measured at
 // 54 us per 145 Mbp for visiting nearly every tile of a chromosome for one or two bases each.
 #define PK_NEED_INPLACE 12
-template <int W, bool FMA, bool MAX, int HH, bool PROBE>
+// CWM (a vector of piecewise-constant input: read depth): every base of a flat stretch of such a signal ties with its
+// neighbours and is KEPT, so it needs its exact value, and the filter as it stands can only queue it -- the probe then
+// sends the vector to the direct kernel, 202 operations a base.  But a base whose whole WINDOW is one run of equal inputs
+// c has the value T(c) = ((0 + w_0 c) + w_1 c) + ..., a function of c alone: the same bits for every such base, one
+// chain of taps per run.  So: a change bit per staged element (it differs from the one before); a base is `cw` when no
+// change falls inside its window; neighbours within HH of a cw base that are cw themselves lie in the same run (their
+// windows overlap in >= 94 elements) and tie exactly -- only the others are compared, on the high words as always; a cw
+// base they do not beat, with margin, is written T of its run, which the run's first cw base of the tile (its leader)
+// gets from the same chain of taps as the certain peaks; without margin it is queued like any undecided base.
+template <int W, bool FMA, bool MAX, int HH, bool PROBE, bool CWM>
 __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t tile,
                                                    const HannConsts<W, PK_E>& K, const double* __restrict__ d_taps, double fill, GdspPeaksCtl* ctl,
                                                    uint16_t* __restrict__ strip, uint32_t* __restrict__ tileCount, uint32_t cap,
@@ -97,11 +110,17 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 	__shared__ uint32_t stats[NW][2];
 	__shared__ double   edgeLo[NW][HH], edgeHi[NW][HH];            // a wave's first block's first HH values, its last block's last HH
 	__shared__ uint32_t zeroBits[HN_THREADS/2], sureBits[HN_THREADS/2];   // per block of 16 outputs (16 bits each): exact zeros; peaks evaluated in place
+	constexpr int SURE_CAP = CWM? PK_SURE_CAP - PK_LEAD_CAP : PK_SURE_CAP;
 	__shared__ uint16_t sureList[PK_SURE_CAP];
 	__shared__ uint16_t needList[PK_NEED_INPLACE];                 // the first undecided bases: settled in place when there are no more than these
 	__shared__ double   exactVal[PK_NEED_INPLACE * (2*HH + 1)];    // ... from the exact values of their neighbourhoods
 	__shared__ double   tapsLds[W];                                // the window, for the exact values (as scalar operands its 202 words crowd out the block sums' constants)
 	__shared__ uint32_t nsure, queued;
+	__shared__ uint16_t chgBits[CWM? HN_THREADS : 1];              // per staged block: element u differs from the element before it
+	__shared__ uint16_t leadList[CWM? PK_LEAD_CAP : 1];
+	__shared__ double   blockT[CWM? HN_THREADS : 1];               // per block of outputs that holds a leader: its run's value
+	__shared__ int      waveLead[CWM? NW : 1];
+	__shared__ uint32_t nlead, nflat;
 
 	const int      p         = threadIdx.x, lane = p & 63, wave = p >> 6;
 	const int64_t  keepStart = (int64_t) tile * stride;            // first output this tile stores
@@ -115,7 +134,7 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 	const int      keepLo    = h + sh;                             // smoothed values [keepLo, keepHi) are this tile's outputs
 	const int      keepHi    = (keepLo + stride < validHi)? keepLo + stride : validHi;
 
-	if (p == 0) { nsure = 0;  queued = 0; }                        // (the barriers of the block sums come before their first use)
+	if (p == 0) { nsure = 0;  queued = 0;  nlead = 0;  nflat = 0; }   // (the barriers of the block sums come before their first use)
 	if (!PROBE && (p < W)) tapsLds[p] = d_taps[p];
 	double acc[HN_G];
 	bool direct = hann_tile_sums<W, false, PK_E> (lds, tot, huge, in, n, e0, K, acc);
@@ -125,7 +144,8 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 	// set, is there a nonzero magnitude below 2^-500.  stats[wave][1] = { bit 0, bit 1 }; read after the next barrier.
 		{
 		const double* xb = lds + p * HN_PITCH;
-		uint32_t signs = 0, smallest = 0xFFFFFFFFu;
+		uint32_t signs = 0, smallest = 0xFFFFFFFFu, chg = 0;
+		long long before = (CWM && (p > 0))? __double_as_longlong (lds[(p - 1) * HN_PITCH + HN_G - 1]) : 0;
 #pragma unroll
 		for (int u=0 ; u<HN_G ; u++)
 			{
@@ -133,7 +153,9 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 			signs |= hi;
 			const uint32_t key = (hi & 0x7FFFFFFFu) | min (lo, 1u);    // 0 only for a zero; a denormal's is 1
 			smallest = min (smallest, key - 1u);                      // (a zero wraps to the top: ignored)
+			if (CWM) { const long long here = __double_as_longlong (xb[u]);  chg |= ((here != before) || ((p == 0) && (u == 0)))? (1u << u) : 0u;  before = here; }
 			}
+		if (CWM) chgBits[p] = (uint16_t) chg;
 		const uint32_t flags = ((__builtin_amdgcn_ballot_w64 ((signs >> 31) != 0) != 0)? 1u : 0u)
 		                     | ((__builtin_amdgcn_ballot_w64 (smallest < 0x20B00000u - 1u) != 0)? 2u : 0u);
 		if (lane == 0) stats[wave][1] = flags;
@@ -173,7 +195,7 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 	if (flagsAll & 2u) direct = true;
 	const bool nonneg = ((flagsAll & 1u) == 0);
 
-	uint32_t isNeed = 0, isZero = 0, isSure = 0;
+	uint32_t isNeed = 0, isZero = 0, isSure = 0, cwLead = 0, cwFlat = 0;      // (cw*: CWM, a block's leaders and the bases written their run's value)
 	if (nonneg && !direct)
 		{
 		// ---- no negative input: every smoothed value is >= 0, and doubles >= 0 order like their bit patterns.  The test
@@ -188,45 +210,99 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 			{
 			// the extreme of the HH words before a base and of the HH after it, for all 16 bases at once: runs of 2 and 4 by doubling
 			constexpr int NV = HN_G + 2*HH;
-			uint32_t m2[NV], m4[NV], run[HN_G + HH + 1];
-#pragma unroll
-			for (int i=0 ; i+1<NV ; i++) m2[i] = MAX? max (k[i], k[i+1]) : min (k[i], k[i+1]);
-#pragma unroll
-			for (int i=0 ; i+3<NV ; i++) m4[i] = MAX? max (m2[i], m2[i+2]) : min (m2[i], m2[i+2]);
-#pragma unroll
-			for (int i=0 ; i<HN_G+HH+1 ; i++)
+			auto runs_of = [&] (const uint32_t (&kk)[NV], uint32_t (&run)[HN_G + HH + 1])
 				{
-				uint32_t r;
-				if      (HH == 1) r = k[i];
-				else if (HH == 2) r = m2[i];
-				else if (HH == 3) r = MAX? max (m2[i], k[i+2])  : min (m2[i], k[i+2]);
-				else if (HH == 4) r = m4[i];
-				else if (HH == 5) r = MAX? max (m4[i], k[i+4])  : min (m4[i], k[i+4]);
-				else if (HH == 6) r = MAX? max (m4[i], m2[i+4]) : min (m4[i], m2[i+4]);
-				else              r = MAX? max (m4[i], m4[i+3]) : min (m4[i], m4[i+3]);
-				run[i] = r;
+				uint32_t m2[NV], m4[NV];
+#pragma unroll
+				for (int i=0 ; i+1<NV ; i++) m2[i] = MAX? max (kk[i], kk[i+1]) : min (kk[i], kk[i+1]);
+#pragma unroll
+				for (int i=0 ; i+3<NV ; i++) m4[i] = MAX? max (m2[i], m2[i+2]) : min (m2[i], m2[i+2]);
+#pragma unroll
+				for (int i=0 ; i<HN_G+HH+1 ; i++)
+					{
+					uint32_t r;
+					if      (HH == 1) r = kk[i];
+					else if (HH == 2) r = m2[i];
+					else if (HH == 3) r = MAX? max (m2[i], kk[i+2]) : min (m2[i], kk[i+2]);
+					else if (HH == 4) r = m4[i];
+					else if (HH == 5) r = MAX? max (m4[i], kk[i+4]) : min (m4[i], kk[i+4]);
+					else if (HH == 6) r = MAX? max (m4[i], m2[i+4]) : min (m4[i], m2[i+4]);
+					else              r = MAX? max (m4[i], m4[i+3]) : min (m4[i], m4[i+3]);
+					run[i] = r;
+					}
+				};
+			uint32_t run[HN_G + HH + 1];
+			runs_of (k, run);
+
+			// CWM: which of the block's bases and of the HH either side have a window without a change (bit i <-> base u = i - HH).
+			// The window of base u of block p is the staged elements 16p+u-100 .. 16p+u: a change at element q rules out
+			// u = q-16p .. q-16p+99.  The change bits of blocks p-7 .. p+1 as one string of 144 bits from element 16(p-7).
+			uint32_t cwAll = 0, run2[HN_G + HH + 1];
+			if (CWM)
+				{
+				unsigned long long w0 = 0, w1 = 0;
+#pragma unroll
+				for (int j=0 ; j<4 ; j++) { w0 |= (unsigned long long) chgBits[p - 7 + j] << (16*j);  w1 |= (unsigned long long) chgBits[p - 3 + j] << (16*j); }
+				unsigned long long w2 = (p + 1 < HN_THREADS)? chgBits[p + 1] : 0xFFFFull;
+				// (the probe only counts: where changes are dense it does not look further.  The filter must: a base's leader is
+				//  found through what its neighbours' threads conclude from the same bits, so every thread concludes exactly)
+				if (!PROBE || (__popcll (w0) + __popcll (w1) + __popcll (w2) <= 8))
+					{
+					cwAll = (1u << NV) - 1u;
+					auto rule_out = [&] (unsigned long long w, int base)
+						{
+						while (w != 0)
+							{
+							const int t = base + __builtin_ctzll (w);           // the change's offset in the string; it rules out u = t-112 .. t-13
+							w &= w - 1;
+							const int lo = max (t - 112 + HH, 0), hi = min (t - 13 + HH, NV - 1);
+							if (lo <= hi) cwAll &= ~((((hi - lo + 1) >= 32)? 0xFFFFFFFFu : ((1u << (hi - lo + 1)) - 1u)) << lo);
+							}
+						};
+					rule_out (w0, 0);  rule_out (w1, 64);  rule_out (w2, 128);
+					// (bases outside the vector are nobody's business)
+					const int first = blk * HN_G - HH;                          // base of bit 0
+					const int lo = max (validLo - first, 0), hi = min (validHi - first, NV);
+					cwAll &= (lo < hi)? ((((hi - lo) >= 32)? 0xFFFFFFFFu : ((1u << (hi - lo)) - 1u)) << lo) : 0u;
+					}
+				uint32_t k2[NV];
+#pragma unroll
+				for (int i=0 ; i<NV ; i++) k2[i] = ((cwAll >> i) & 1u)? away : k[i];
+				runs_of (k2, run2);
 				}
+			uint32_t isFlat = 0;
 #pragma unroll
 			for (int u=0 ; u<HN_G ; u++)
 				{
 				const int      c   = blk * HN_G + u;
-				const uint32_t ext = MAX? max (run[u], run[u + HH + 1]) : min (run[u], run[u + HH + 1]);
+				const bool     cw  = CWM && (((cwAll >> (u + HH)) & 1u) != 0);
+				const uint32_t ext = !cw? (MAX? max (run[u], run[u + HH + 1])  : min (run[u], run[u + HH + 1]))
+				                        : (MAX? max (run2[u], run2[u + HH + 1]) : min (run2[u], run2[u + HH + 1]));     // cw: of the neighbours outside its run only
 				const uint32_t x   = k[u + HH];
 				if ((c < keepLo) || (c >= keepHi)) continue;
 				if (MAX)
 					{
 					if (ext > x + 1) continue;                     // certainly beaten: `fill`
 					if (x == 0)          isZero |= 1u << u;        // (then ext <= 1: among zeros a tie; a neighbour of word 1 is < 2^-1000: none here)
-					else if (x > ext + 1) isSure |= 1u << u;
+					else if (x > ext + 1) { if (cw) isFlat |= 1u << u;  else isSure |= 1u << u; }
 					else                  isNeed |= 1u << u;
 					}
 				else
 					{
 					if (x == 0) { isZero |= 1u << u;  continue; }  // nothing is below zero here: kept
 					if (ext + 1 < x) continue;                     // certainly beaten
-					if (x + 1 < ext) isSure |= 1u << u;
+					if (x + 1 < ext) { if (cw) isFlat |= 1u << u;  else isSure |= 1u << u; }
 					else             isNeed |= 1u << u;
 					}
+				}
+			if (CWM)
+				{
+				// leaders: the first cw base of a run inside this tile's computed stretch (cw, and the base before it is not --
+				// or is another tile's); only runs with a base to write need one, but a run has some forty blocks and one leader
+				const uint32_t cw16 = (cwAll >> HH) & 0xFFFFu, prev16 = (cwAll >> (HH - 1)) & 0xFFFFu;
+				uint32_t lead16 = cw16 & ~prev16;
+				if (blk == 0) lead16 |= cw16 & 1u;
+				cwLead = lead16;  cwFlat = isFlat;
 				}
 			}
 		}
@@ -327,9 +403,11 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 
 	if (PROBE)
 		{
-		int cnt = 4 * __popc (isNeed) + __popc (isSure);           // in quarter bases: a certain peak costs a lane, an undecided base sixteen
-		for (int off=32 ; off>0 ; off>>=1) cnt += __shfl_xor (cnt, off, 64);
+		int cnt = 4 * __popc (isNeed) + __popc (isSure) + __popc (cwLead);    // in quarter bases: a certain peak or a run's leader costs a lane, an undecided base sixteen
+		int flat = __popc (cwFlat);
+		for (int off=32 ; off>0 ; off>>=1) { cnt += __shfl_xor (cnt, off, 64);  flat += __shfl_xor (flat, off, 64); }
 		if ((lane == 0) && (cnt != 0)) atomicAdd (&ctl->probe, (uint32_t) cnt);   // (ctl->sampled is in quarter bases too)
+		if (CWM && (lane == 0) && (flat != 0)) atomicAdd (&ctl->flat, (uint32_t) flat);
 		return;
 		}
 
@@ -351,7 +429,7 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 				{
 				const int u = __ffs ((int) word) - 1;
 				word &= word - 1;
-				if (at < PK_SURE_CAP) sureList[at] = (uint16_t) (blk * HN_G + u);
+				if (at < SURE_CAP) sureList[at] = (uint16_t) (blk * HN_G + u);
 				else                  { isSure &= ~(1u << u);  isNeed |= 1u << u; }
 				at++;
 				}
@@ -381,16 +459,48 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 				}
 			}
 		}
+	// ---- CWM: the runs' leaders (a list like the certain peaks'), the last leader's block at or before every block
+	int leadIncl = -1;
+	if (CWM && !direct)
+		{
+		const int cnt = __popc (cwLead);
+		int incl = cnt;
+		for (int d=1 ; d<64 ; d*=2) { const int up = __shfl_up (incl, d, 64);  if (lane >= d) incl += up; }
+		const int waveTotal = __shfl (incl, 63, 64);
+		if (waveTotal != 0)
+			{
+			uint32_t base = 0;
+			if (lane == 0) base = atomicAdd (&nlead, (uint32_t) waveTotal);
+			base = (uint32_t) __shfl ((int) base, 0, 64);
+			uint32_t at = base + (uint32_t) (incl - cnt);
+			uint32_t word = cwLead;
+			while (word != 0)
+				{
+				const int u = __ffs ((int) word) - 1;
+				word &= word - 1;
+				if (at < PK_LEAD_CAP) leadList[at] = (uint16_t) (blk * HN_G + u);
+				at++;
+				}
+			}
+		leadIncl = (cwLead != 0)? blk : -1;
+		for (int d=1 ; d<64 ; d*=2) { const int up = __shfl_up (leadIncl, d, 64);  if (lane >= d) leadIncl = max (leadIncl, up); }
+		if (lane == 63) waveLead[wave] = leadIncl;
+		int flat = __popc (cwFlat);
+		for (int off=32 ; off>0 ; off>>=1) flat += __shfl_xor (flat, off, 64);
+		if ((lane == 0) && (flat != 0)) atomicAdd (&nflat, (uint32_t) flat);
+		}
 	if (live)                                                      // every block of 16 has its own half word: plain stores
 		{
 		reinterpret_cast<uint16_t*> (zeroBits)[blk] = (uint16_t) isZero;
-		reinterpret_cast<uint16_t*> (sureBits)[blk] = (uint16_t) (direct? 0u : isSure);
+		reinterpret_cast<uint16_t*> (sureBits)[blk] = (uint16_t) (direct? 0u : (isSure | cwFlat));     // (what its own lane writes)
 		}
 	__syncthreads ();
-	const int  sure    = (int) ((nsure < PK_SURE_CAP)? nsure : PK_SURE_CAP);
+	const int  sure    = (int) ((nsure < SURE_CAP)? nsure : SURE_CAP);
 	const int  nq      = (int) queued;
+	const int  nl      = CWM? (int) nlead : 0;
+	if (CWM && (nl > PK_LEAD_CAP)) direct = true;                  // (more runs than a tile of 4096 can hold a hundred bases apart: never; the exact kernel takes the tile whole)
 	// (cap < PK_NEED_INPLACE only under the tests' GDSP_PEAKS_QUEUE_CAP: they want the strips and their overflow exercised)
-	const bool inPlace = !direct && (nq != 0) && (nq <= PK_NEED_INPLACE) && (sure + nq * (2*HH + 1) <= HN_THREADS) && (cap >= PK_NEED_INPLACE);
+	const bool inPlace = !direct && (nq != 0) && (nq <= PK_NEED_INPLACE) && (sure + nl + nq * (2*HH + 1) <= HN_THREADS) && (cap >= PK_NEED_INPLACE);
 	if (p == 0)
 		{
 		const uint32_t q = direct? PK_WHOLE_TILE : inPlace? 0u : queued;
@@ -402,11 +512,14 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 	// ---- exact values of the certain peaks -- and of the neighbourhoods of the undecided bases settled in place -- one
 	//      lane each, from the staged inputs: tap by tap in the reference's order (sum.c:655-663); a certain peak is written
 	//      by the lane that evaluated it
-	const int evals = sure + (inPlace? nq * (2*HH + 1) : 0);
+	const int nbrs  = inPlace? nq * (2*HH + 1) : 0;
+	const int evals = direct? 0 : sure + nbrs + nl;                // (a tile taken whole by the exact kernel evaluates nothing here)
 	if (p < evals)
 		{
+		const bool lead = CWM && (p >= sure + nbrs);
 		const int  mine = (p < sure)? 0 : (p - sure) / (2*HH + 1);
-		const int  c = (p < sure)? (int) sureList[p] : (int) needList[mine] - HH + ((p - sure) - mine * (2*HH + 1));
+		const int  c = (p < sure)? (int) sureList[p] : lead? (int) leadList[p - sure - nbrs]
+		                         : (int) needList[mine] - HH + ((p - sure) - mine * (2*HH + 1));
 		const bool inside = (c >= validLo) && (c < validHi);       // (a neighbour outside the vector beats nothing; c is within the computed stretch either way)
 		const int e = G::LO + (inside? c : validLo);               // the window's first staged element
 		// element e+k sits at e+k + ((e+k) >> 4) in the image: with e = 16 q + r that is 17 q + r + k + ((r + k) >> 4), and
@@ -422,8 +535,9 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 			const double x = at16[k & 15][k + (k >> 4)];
 			a = FMA? __builtin_fma (tapsLds[k], x, a) : a + tapsLds[k] * x;
 			}
-		if (p < sure) out[compStart + c] = a;
-		else          exactVal[p - sure] = inside? a : (MAX? -INFINITY : INFINITY);
+		if (p < sure)  out[compStart + c] = a;
+		else if (lead) blockT[CWM? (c >> 4) : 0] = a;              // the value of every base of the run whose window lies inside it
+		else           exactVal[p - sure] = inside? a : (MAX? -INFINITY : INFINITY);
 		}
 	if (inPlace)                                                   // (uniform over the workgroup)
 		{
@@ -437,6 +551,24 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 #pragma unroll
 			for (int t=0 ; t<2*HH+1 ; t++) { if (t != HH) ext = MAX? fmax (ext, v[t]) : fmin (ext, v[t]); }
 			out[compStart + needList[p]] = (MAX? (ext > centre) : (ext < centre))? fill : centre;
+			}
+		}
+
+	if (CWM && !direct && (nflat != 0))                            // (uniform) the kept bases of flat stretches: their run's value
+		{
+		__syncthreads ();
+		if (cwFlat != 0)
+			{
+			int lb = leadIncl;
+			for (int w=0 ; w<wave ; w++) lb = max (lb, waveLead[w]);
+			const double T = blockT[(lb >= 0)? lb : 0];               // (lb >= 0: a flat base's run has a leader at or before it)
+			uint32_t word = cwFlat;
+			while (word != 0)
+				{
+				const int u = __ffs ((int) word) - 1;
+				word &= word - 1;
+				out[compStart + blk * HN_G + u] = T;
+				}
 			}
 		}
 
@@ -457,7 +589,7 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 		}
 	}
 
-template <int W, bool MAX, int HH>
+template <int W, bool MAX, int HH, bool CWM>
 __global__ __launch_bounds__(HN_THREADS)
 void peaks_probe_kernel (GdspBatch B, HannConsts<W, PK_E> K, GdspPeaksCtl* ctl)
 	{
@@ -466,20 +598,27 @@ void peaks_probe_kernel (GdspBatch B, HannConsts<W, PK_E> K, GdspPeaksCtl* ctl)
 	const uint32_t take  = (tiles < PK_PROBE_TILES)? tiles : PK_PROBE_TILES;
 	if (j >= take) return;
 	const uint32_t tile = (uint32_t) (((uint64_t) j * tiles) / take);
-	peaks_filter_tile<W, false, MAX, HH, true> (B.in[v], NULL, B.n[v], tile, K, NULL, 0.0, &ctl[v], NULL, NULL, 0, NULL, 0);
+	peaks_filter_tile<W, false, MAX, HH, true, CWM> (B.in[v], NULL, B.n[v], tile, K, NULL, 0.0, &ctl[v], NULL, NULL, 0, NULL, 0);
 	}
 
-template <int W, bool FMA, bool MAX, int HH>
+// The filter over the vectors of ONE form: plain, or (CWM) the form for vectors of flat stretches that writes a run's value
+// to all its bases -- which form a vector takes is the probe's count (read depth: flat), read back by the host between the
+// probe and this launch: the two forms in one kernel bring an LDS image each (one workgroup per CU), two launches over all
+// the vectors leave a workgroup per tile idle on the vectors that are the other's (5-8 % of a real-valued genome), and a
+// workgroup walking a group of tiles runs a third slower than a workgroup per tile.  S: the vectors of this form and the
+// grid over them; M: each one's number in the whole table (control words) and its first tile there (strips, counts, lists).
+struct PeaksSub { uint32_t v[GDSP_BATCH_MAX], gt0[GDSP_BATCH_MAX]; };
+template <int W, bool FMA, bool MAX, int HH, bool CWM>
 __global__ __launch_bounds__(HN_THREADS) __attribute__((amdgpu_waves_per_eu(3)))     // three workgroups per CU, like hann_blocks_kernel
-void peaks_filter_kernel (GdspBatch B, HannConsts<W, PK_E> K, const double* __restrict__ d_taps, double fill, GdspPeaksCtl* ctl, uint16_t* strips,
-                          uint32_t* counts, uint32_t cap, uint32_t* tileList)
+void peaks_filter_kernel (GdspBatch S, PeaksSub M, HannConsts<W, PK_E> K, const double* __restrict__ d_taps, double fill, GdspPeaksCtl* ctl,
+                          uint16_t* strips, uint32_t* counts, uint32_t cap, uint32_t* tileList)
 	{
-	const double* in;  double* out;  uint32_t n, v;
-	const uint32_t tile = gdsp_batch_tile (B, in, out, n, &v);
-	if (gdsp_peaks_takes_direct (ctl[v])) return;                  // (the probe is complete: an earlier launch on the same stream)
-	const uint32_t gt = B.tile0[v] + tile;                         // the tile's number in the grid: its strip and its count
-	peaks_filter_tile<W, FMA, MAX, HH, false> (in, out, n, tile, K, d_taps, fill, &ctl[v], strips + (size_t) gt * cap, counts + gt, cap,
-	                                           tileList + B.tile0[v], gt);
+	const double* in;  double* out;  uint32_t n, i;
+	const uint32_t tile = gdsp_batch_tile (S, in, out, n, &i);
+	const uint32_t v = M.v[i], gt = M.gt0[i] + tile;               // the tile's number in the whole table: its strip and its count
+	if (gdsp_peaks_takes_direct (ctl[v])) return;                  // (only where the host did not look: GDSP_PEAKS_FLAT=0)
+	peaks_filter_tile<W, FMA, MAX, HH, false, CWM> (in, out, n, tile, K, d_taps, fill, &ctl[v], strips + (size_t) gt * cap, counts + gt, cap,
+	                                                tileList + M.gt0[i], gt);
 	}
 
 // The exact kernel, for the bases whose comparison needs exact values (ties and near-ties): a workgroup takes a tile from
@@ -640,18 +779,47 @@ static int peaks_launch (const gdsp_batch_item* items, int count, const HannCons
 	const double* d_taps = NULL;                                   // the reference's window on the device (gdsp_fir.hip: cached per device)
 	rc = gdsp_smooth_taps_device (101, &d_taps);
 	if (rc != GDSP_OK) return rc;
-	hipLaunchKernelGGL ((peaks_probe_kernel<101, MAX, HH>), dim3(count * PK_PROBE_TILES), dim3(HN_THREADS), 0, s, B, K, w.ctl);
+	// GDSP_PEAKS_FLAT=0: no form for flat stretches (rounds 3-4a: the probe sends read depth to the direct kernel) and no read-back
+	const char* flatEnv = getenv ("GDSP_PEAKS_FLAT");
+	const bool  flatForm = !((flatEnv != NULL) && (strcmp (flatEnv, "0") == 0));
+	if (flatForm) hipLaunchKernelGGL ((peaks_probe_kernel<101, MAX, HH, true>),  dim3(count * PK_PROBE_TILES), dim3(HN_THREADS), 0, s, B, K, w.ctl);
+	else          hipLaunchKernelGGL ((peaks_probe_kernel<101, MAX, HH, false>), dim3(count * PK_PROBE_TILES), dim3(HN_THREADS), 0, s, B, K, w.ctl);
+	// which vectors take which form: the probe's counts, read back (the one wait of the route: ~15 us per table of up to 32
+	// vectors, 0.2 % of a genome-wide launch); without the flat form every vector that does not go direct is plain and the
+	// kernels decide by themselves
+	GdspPeaksCtl h_ctl[GDSP_BATCH_MAX];
+	memset (h_ctl, 0, sizeof(h_ctl));
+	if (flatForm)
+		{
+		GDSP_HIP_TRY (hipMemcpyAsync (h_ctl, w.ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, s));
+		GDSP_HIP_TRY (hipStreamSynchronize (s));
+		}
 	const int exactBlocks = 4096;
-	if (fma)
+	for (int form=0 ; form<(flatForm? 2 : 1) ; form++)
 		{
-		hipLaunchKernelGGL ((peaks_filter_kernel<101, true, MAX, HH>), dim3(tiles), dim3(HN_THREADS), 0, s, B, K, d_taps, fill, w.ctl, w.strips, w.counts, cap, w.tileList);
-		hipLaunchKernelGGL ((peaks_exact_kernel<101, true, MAX>), dim3(exactBlocks), dim3(HN_THREADS), 0, s, B, taps, HH, fill, w.ctl, w.strips, w.counts, cap, w.tileList);
+		std::vector<gdsp_batch_item> sub;
+		PeaksSub M;
+		memset (&M, 0, sizeof(M));
+		for (int v=0 ; v<count ; v++)
+			{
+			const GdspPeaksCtl& c = h_ctl[v];
+			const bool direct = flatForm && ((uint64_t) c.probe * 256u > (uint64_t) c.sampled * GDSP_PEAKS_DIRECT_NUM);    // (gdsp_peaks_takes_direct)
+			const bool flat   = flatForm && ((uint64_t) c.flat * 32u > (uint64_t) c.sampled);                              // (gdsp_peaks_is_flat)
+			if (direct || (flat != (form == 1))) continue;
+			M.v[sub.size ()] = (uint32_t) v;  M.gt0[sub.size ()] = B.tile0[v];
+			sub.push_back (items[v]);
+			}
+		if (sub.empty ()) continue;
+		GdspBatch S;
+		gdsp_batch_make (S, sub.data (), (int) sub.size (), [] (uint32_t n) { return ((uint64_t) n + stride - 1) / stride; });
+		const dim3 grid (S.tile0[GDSP_BATCH_MAX]), block (HN_THREADS);
+#define PK_FILTER(FMAV, CWMV) hipLaunchKernelGGL ((peaks_filter_kernel<101, FMAV, MAX, HH, CWMV>), grid, block, 0, s, S, M, K, d_taps, fill, w.ctl, w.strips, w.counts, cap, w.tileList)
+		if (form == 1) { if (fma) PK_FILTER (true, true);   else PK_FILTER (false, true); }
+		else           { if (fma) PK_FILTER (true, false);  else PK_FILTER (false, false); }
+#undef PK_FILTER
 		}
-	else
-		{
-		hipLaunchKernelGGL ((peaks_filter_kernel<101, false, MAX, HH>), dim3(tiles), dim3(HN_THREADS), 0, s, B, K, d_taps, fill, w.ctl, w.strips, w.counts, cap, w.tileList);
-		hipLaunchKernelGGL ((peaks_exact_kernel<101, false, MAX>), dim3(exactBlocks), dim3(HN_THREADS), 0, s, B, taps, HH, fill, w.ctl, w.strips, w.counts, cap, w.tileList);
-		}
+	if (fma) hipLaunchKernelGGL ((peaks_exact_kernel<101, true, MAX>),  dim3(exactBlocks), dim3(HN_THREADS), 0, s, B, taps, HH, fill, w.ctl, w.strips, w.counts, cap, w.tileList);
+	else     hipLaunchKernelGGL ((peaks_exact_kernel<101, false, MAX>), dim3(exactBlocks), dim3(HN_THREADS), 0, s, B, taps, HH, fill, w.ctl, w.strips, w.counts, cap, w.tileList);
 	GDSP_LAUNCH_CHECK ();
 	return gdsp_fir_extrema_gated_launch (items, count, w.ctl, h_taps, fma, HH, MAX, fill, stream);
 	}
