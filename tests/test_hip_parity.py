@@ -647,11 +647,21 @@ def _filter_cases(n, rng):
     x = _signal("real", n, rng); x[n // 3] = 2.0 ** 64; x[n // 3 + 200] = 2.0 ** 63.9; x[2 * n // 3] = 2.0 ** -64.5; x[2 * n // 3 + 300] = 2.0 ** -63.5
     cases["edges of the single-precision range"] = x
     cases["one part in 1e6 apart"] = 1000.0 + 1e-3 * np.sin(t / 40.0)   # smoothed values closer than single precision resolves
+    # runs of equal inputs around the window's length (a base whose whole window lies in one run is written the run's value,
+    # one chain of taps per run: the filter's form for flat stretches), steps of one in a deep signal, runs that return to
+    # the value before, a run of zeros between equal runs
+    x = np.empty(n); at = 0; k = 0
+    lens = [60, 100, 101, 102, 103, 150, 99, 300, 101, 1000, 205, 16, 500]
+    vals = [30.0, 31.0, 30.0, 29.0, 29.0, 57.0, 58.0, 0.0, 58.0, 3.0, 3.5, 3.0, 1e-3]
+    while at < n:
+        x[at: at + lens[k % len(lens)]] = vals[(k * 5) % len(vals)]
+        at += lens[k % len(lens)]; k += 1
+    cases["runs about a window long"] = x
     return cases
 
 
 PEAKS_ROUTES = ({}, {"GDSP_PEAKS_ROUTE": "filter"}, {"GDSP_PEAKS_ROUTE": "direct"}, {"GDSP_PEAKS_ROUTE": "filter", "GDSP_PEAKS_QUEUE_CAP": "7"},
-                {"GDSP_PEAKS_FILTER": "0"})
+                {"GDSP_PEAKS_FILTER": "0"}, {"GDSP_PEAKS_FLAT": "0"})
 
 
 @pytest.mark.parametrize("n", [2291, 2292, 2293, 2294, 3961, 3962, 3963, 3971, 3972, 3973, 3974, 4584, 7944, 7945, 20011])
