@@ -456,8 +456,8 @@ def other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_base
         if not args.nofuse and filtered:
             # the filtered route (gdsp_peaks.hip): block sums + interval test, then exact taps for what stays undecided
             fma = "false" if args.mode == "exact" else "true"
-            kernels = ["peaks_filter_kernel<101, %s, true, 5>" % fma, "peaks_exact_kernel<101, %s, true>" % fma,
-                       "peaks_probe_kernel<101, true, 5>", "fir_fixed_extrema_gated_kernel (leaves at once)"]
+            kernels = ["peaks_filter_kernel<101, %s, true, 5, false>" % fma, "peaks_exact_kernel<101, %s, true>" % fma,
+                       "peaks_probe_kernel<101, true, 5, true>", "fir_fixed_extrema_gated_kernel (leaves at once)"]
     if batch:
         kernels = [k if k.startswith(("pc_", "peaks_", "fir_fixed_extrema_gated")) else batch_name(k) for k in kernels]
     result = {"metric": "Gbases/sec on %s over 3.1 Gbp" % name, "value": round(total_bases / (wall_ms * 1e-3) / 1e9, 2),
