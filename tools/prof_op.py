@@ -59,6 +59,7 @@ RUN = {
     "smooth_hann50001": lambda: gd.smooth(real, 50001, out=b, mode=gd.FIR_HANN),
     "peaks_exact": lambda: gd.smooth_local_extrema(real, 101, 11, True, 0.0, out=b, mode=gd.FIR_EXACT),
     "peaks_fma": lambda: gd.smooth_local_extrema(real, 101, 11, True, 0.0, out=b, mode=gd.FIR_FMA),
+    "peaks_exact_depth": lambda: gd.smooth_local_extrema(depth, 101, 11, True, 0.0, out=b, mode=gd.FIR_EXACT),
     "morph_fused": lambda: gd.dilate_erode(depth, l, r, l, r, binarize=(0.0, False, 1.0, 0.0), out=b),
     "smooth_hann_batch": lambda: gd.smooth_batch(parts_in(real), 101, outs=parts_b, mode=gd.FIR_HANN),
     "smooth_exact_batch": lambda: gd.smooth_batch(parts_in(real), 101, outs=parts_b, mode=gd.FIR_EXACT),
