@@ -69,6 +69,10 @@ def main():
                          "taps, bit-identical to the reference")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink every chromosome (debugging only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-workloads", action="store_true",
+                    help="leave BASELINE configs[2..4] out of the line (they are timed and checked by default at one rank)")
+    ap.add_argument("--sustain", type=float, default=3.0,
+                    help="seconds the headline kernel is launched back to back for the `sustained` figure (0 = skip)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="debugging: every rank uses GPU 0 and the gloo backend, to exercise the N>1 code path "
                          "where only one GPU exists (numbers from such a run mean nothing)")
@@ -264,6 +268,27 @@ def main():
             r["fp64_valu_frac"] = round(flops / FP64_VALU_PEAK_TFLOPS, 4)
         return r
 
+    # ---- the headline kernel back to back for >= 3 s (HIP events on the launch stream): what the part sustains, beside
+    #      the K-step figure the contract asks for (20 steps are 0.16 s; FP64-heavy kernels settle at a lower clock)
+    sustained = None
+    if args.sustain > 0:
+        sus_steps = max(args.steps, int(np.ceil(args.sustain * 1e3 / max(dev_ms, 1e-3))))
+        sus_wall, sus_dev = timed(modes[args.mode], sus_steps, 0)
+        sustained = {"kernel": batch_name(KERNELS[args.mode]) if batch else KERNELS[args.mode], "fir_mode": args.mode,
+                     "steps": sus_steps, "seconds": round(sus_wall * sus_steps * 1e-3, 3),
+                     "ms_per_step": round(sus_wall, 4), "device_ms_per_step": round(sus_dev, 4),
+                     "value": round(total_bases / (sus_wall * 1e-3) / 1e9, 2), "unit": "Gbases/s",
+                     "frac_of_hbm_peak": round(BYTES_PER_BASE * max(sum(b - a for _, _, a, b in sh) for sh in shards)
+                                               / (sus_dev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "rel_diff_vs_ms_per_step": round((sus_wall - wall_ms) / wall_ms, 4),
+                     "note": "launches queued back to back, one device sync at the end; rel_diff = (sustained - ms_per_step) / ms_per_step"}
+
+    # ---- BASELINE configs[2..4] in the same process, each with its own check against the oracle (one rank: the
+    #      scaling runs time the metric only)
+    workloads = None
+    if world == 1 and args.sharding == "chromosomes" and not args.no_workloads:
+        workloads = bench_workloads(args, gd, torch, names, mine, lengths, total_bases, vin, vout, stream, timed, lane_of)
+
     result = {
         "metric": "Gbases/sec on smooth W=101 over 3.1 Gbp; HBM GB/s vs peak at 1/2/4/8 GPU",
         "value": round(total_bases / (wall_ms * 1e-3) / 1e9, 2),
@@ -293,6 +318,10 @@ def main():
     }
     if other_split is not None:
         result["other_sharding"] = other_split
+    if sustained is not None:
+        result["sustained"] = sustained
+    if workloads is not None:
+        result["workloads"] = workloads
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(gd, lengths, names, stream)
         result["cpu_baseline_all_cores"] = cpu_baseline_all_cores(gd, lengths, names, stream)
@@ -342,25 +371,26 @@ def piece_extent(piece, lengths):
     return max(0, a - half), min(lengths[c], b + half)
 
 
-def other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_bases, vin, vout, stream, timed_fn, lane_of,
-                   reduce_device="cuda"):
-    """BASELINE configs[2..4] in the bench harness: same signal, same timing discipline."""
+def make_workload(gd, torch, dist, args, workload, fir, nofuse, mine, lengths, src, vout, tmp, stream, lane_of,
+                  reduce_device="cuda", alone=False):
+    """One of BASELINE configs[2..4] over this rank's chromosomes: -> (name, credited B/base, step(_), extra, kernels).
+    src = the resident inputs (left intact), tmp = where the chain's result lands, vout = room for the unfused forms;
+    fir = arithmetic of smooth in front of localmax (exact | fma); alone = the percentile without its binarize."""
     S = stream.handle
-    tmp = {i: gd.DeviceVector(lengths[i]) for i in mine}
     batch = args.launch == "batch"
     n_mine = len(mine)
-    io_in_out = gd.batch_items([vin[i] for i in mine], [vout[i] for i in mine])
-    io_in_tmp = gd.batch_items([vin[i] for i in mine], [tmp[i] for i in mine])
+    io_in_out = gd.batch_items([src[i] for i in mine], [vout[i] for i in mine])
+    io_in_tmp = gd.batch_items([src[i] for i in mine], [tmp[i] for i in mine])
     io_out_tmp = gd.batch_items([vout[i] for i in mine], [tmp[i] for i in mine])
     io_tmp = gd.batch_items(None, [tmp[i] for i in mine])
     # index outputs follow strict comparisons of the smoothed values: direct taps only (hann -> fma)
-    mode = gd.FIR_EXACT if args.mode == "exact" else gd.FIR_FMA
+    mode = gd.FIR_EXACT if fir == "exact" else gd.FIR_FMA
     extra = {}
-    if args.workload == "peaks":          # configs[2]: smooth W=101 = localmax N=11
+    if workload == "peaks":          # configs[2]: smooth W=101 = localmax N=11
         name, bytes_per_base = "smooth W=101 = localmax N=11", 32
 
         def step(_):
-            if batch and args.nofuse:
+            if batch and nofuse:
                 gd.call("gdsp_smooth_batch", io_in_out, n_mine, WINDOW, mode, S)
                 gd.call("gdsp_local_extrema_batch", io_out_tmp, n_mine, 11, 1, 0.0, S)
                 return
@@ -368,17 +398,17 @@ def other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_base
                 gd.call("gdsp_smooth_local_extrema_batch", io_in_tmp, n_mine, WINDOW, mode, 11, 1, 0.0, S)
                 return
             for i in mine:
-                if args.nofuse:
-                    gd.smooth(vin[i], WINDOW, out=vout[i], mode=mode, stream=lane_of[i].handle)
+                if nofuse:
+                    gd.smooth(src[i], WINDOW, out=vout[i], mode=mode, stream=lane_of[i].handle)
                     gd.localmax(vout[i], 11, out=tmp[i], stream=lane_of[i].handle)
                 else:
-                    gd.smooth_local_extrema(vin[i], WINDOW, 11, True, 0.0, out=tmp[i], mode=mode, stream=lane_of[i].handle)
-    elif args.workload == "morph":        # configs[3]: dilate 1001 = erode 1001 = binarize
+                    gd.smooth_local_extrema(src[i], WINDOW, 11, True, 0.0, out=tmp[i], mode=mode, stream=lane_of[i].handle)
+    elif workload == "morph":        # configs[3]: dilate 1001 = erode 1001 = binarize
         name, bytes_per_base = "dilate 1001 = erode 1001 = binarize", 48
         left, right = gd.split_length(1001)
 
         def step(_):
-            if batch and args.nofuse:
+            if batch and nofuse:
                 gd.call("gdsp_dilate_batch", io_in_out, n_mine, left, right, 0.0, 1.0, 0.0, S)
                 gd.call("gdsp_erode_batch", io_out_tmp, n_mine, left, right, 0.0, 1.0, 0.0, S)
                 gd.call("gdsp_binarize_batch", io_tmp, n_mine, 0.0, 0, 1.0, 0.0, S)
@@ -388,16 +418,17 @@ def other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_base
                         1, 0.0, 0, 1.0, 0.0, S)
                 return
             for i in mine:
-                if args.nofuse:
-                    gd.dilate(vin[i], left, right, out=vout[i], stream=lane_of[i].handle)
+                if nofuse:
+                    gd.dilate(src[i], left, right, out=vout[i], stream=lane_of[i].handle)
                     gd.erode(vout[i], left, right, out=tmp[i], stream=lane_of[i].handle)
                     gd.binarize(tmp[i], 0.0, stream=lane_of[i].handle)
                 else:
-                    gd.dilate_erode(vin[i], left, right, left, right, binarize=(0.0, False, 1.0, 0.0), out=tmp[i], stream=lane_of[i].handle)
+                    gd.dilate_erode(src[i], left, right, left, right, binarize=(0.0, False, 1.0, 0.0), out=tmp[i], stream=lane_of[i].handle)
     else:                                 # configs[4]: percentile 99 = binarize --threshold=percentile99
-        name, bytes_per_base = "percentile 99 = binarize --threshold=percentile99", 24
-        for i in mine:
-            gd.call("gdsp_memcpy_d2d", tmp[i].ptr, vin[i].ptr, lengths[i] * 8, gd._sp(S))
+        name, bytes_per_base = ("percentile 99", 8) if alone else ("percentile 99 = binarize --threshold=percentile99", 24)
+        if nofuse and not alone:
+            for i in mine:
+                gd.call("gdsp_memcpy_d2d", tmp[i].ptr, src[i].ptr, lengths[i] * 8, gd._sp(S))
         device_allreduce = None
         if dist is not None:
             # the path's only collective, on the words where the library left them in HBM: the device address is
@@ -425,67 +456,201 @@ def other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_base
                         t.bitwise_xor_(TOP)
 
         def step(_):
-            if not args.nofuse:
+            if not nofuse and not alone:
                 # both operators in the percentile's own read of the signal (gdsp_percentiles_binarize)
-                cnt, vals, _outs, one_pass = gd.percentile_binarize([vin[i] for i in mine], [99000], which=0, outs=[tmp[i] for i in mine],
+                cnt, vals, _outs, one_pass = gd.percentile_binarize([src[i] for i in mine], [99000], which=0, outs=[tmp[i] for i in mine],
                                                                     device_allreduce=device_allreduce, stream=S)
                 extra["percentile99"], extra["sampled"], extra["binarize_in_one_pass"] = vals[0], cnt, bool(one_pass)
                 st = gd.percentile_stats()
                 extra["percentile_route"] = {gd.SELECT_RADIX: "radix", gd.SELECT_BRACKET: "bracket"}.get(st["route"])
                 extra["percentile_stats"] = st
                 return
-            cnt, vals = gd.percentile([vin[i] for i in mine], [99000], device_allreduce=device_allreduce, stream=S)
+            cnt, vals = gd.percentile([src[i] for i in mine], [99000], device_allreduce=device_allreduce, stream=S)
             extra["percentile99"], extra["sampled"] = vals[0], cnt
             st = gd.percentile_stats()
             extra["percentile_route"] = {gd.SELECT_RADIX: "radix", gd.SELECT_BRACKET: "bracket"}.get(st["route"])
             extra["percentile_stats"] = st
+            if alone:
+                return
             if batch:
                 gd.call("gdsp_binarize_batch", io_tmp, n_mine, float(vals[0]), 0, 1.0, 0.0, S)
                 return
             for i in mine:
                 gd.binarize(tmp[i], vals[0], stream=lane_of[i].handle)
-    wall_ms, dev_ms = timed_fn(None, args.steps, args.warmup, step=step)
-    bases_rank = max(sum(lengths[i] for i in sh) for sh in gd.lpt_shards(lengths, world))
-    moved_per_base = 16 if not args.nofuse else bytes_per_base        # a fused chain moves 8 B in and 8 B out per base in all
-    achieved = moved_per_base * bases_rank / (dev_ms * 1e-3) / 1e9            # bytes that actually cross HBM
-    credited = bytes_per_base * bases_rank / (dev_ms * 1e-3) / 1e9            # 16 B per operator executed
-    kernels = WORKLOAD_KERNELS[args.workload]["nofuse" if args.nofuse else "fused"]
-    if args.workload == "peaks":
-        kernels = [k.replace("FMA", "false" if args.mode == "exact" else "true") for k in kernels]
-        filtered = os.environ.get("GDSP_PEAKS_FILTER") not in (("0",) if args.mode == "exact" else ("0", "exact"))
-        if not args.nofuse and filtered:
+    kernels = (["pc_partition_tab_kernel<2, false, true, false>"] if alone
+               else WORKLOAD_KERNELS[workload]["nofuse" if nofuse else "fused"])
+    if workload == "peaks":
+        kernels = [k.replace("FMA", "false" if fir == "exact" else "true") for k in kernels]
+        filtered = os.environ.get("GDSP_PEAKS_FILTER") not in (("0",) if fir == "exact" else ("0", "exact"))
+        if not nofuse and filtered:
             # the filtered route (gdsp_peaks.hip): block sums + interval test, then exact taps for what stays undecided
-            fma = "false" if args.mode == "exact" else "true"
+            fma = "false" if fir == "exact" else "true"
             kernels = ["peaks_filter_kernel<101, %s, true, 5, false>" % fma, "peaks_exact_kernel<101, %s, true>" % fma,
                        "peaks_probe_kernel<101, true, 5, true>", "fir_fixed_extrema_gated_kernel (leaves at once)"]
     if batch:
         kernels = [k if k.startswith(("pc_", "peaks_", "fir_fixed_extrema_gated")) else batch_name(k) for k in kernels]
+    return name, bytes_per_base, step, extra, kernels
+
+
+def workload_roofline(gd, args, world, mine, lengths, dev_ms, bytes_per_base, moved_per_base, kernels):
+    """achieved / frac count the bytes that cross HBM; credited_by_survey_8d the 16 B per operator executed"""
+    batch = args.launch == "batch"
+    bases_rank = max(sum(lengths[i] for i in sh) for sh in gd.lpt_shards(lengths, world))
+    achieved = moved_per_base * bases_rank / (dev_ms * 1e-3) / 1e9            # bytes that actually cross HBM
+    credited = bytes_per_base * bases_rank / (dev_ms * 1e-3) / 1e9            # SURVEY 8(d): 16 B per operator executed
+    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": measured_traffic(kernels[0], moved_per_base * bases_rank / (1 if batch else max(1, len(mine)))),
+            "traffic_measured": traffic_source(kernels[0]),
+            "kernel": kernels[0], "kernels": kernels,
+            "hbm_bytes_per_base_moved": moved_per_base,
+            "credited_by_survey_8d": {"bytes_per_base": bytes_per_base, "achieved": round(credited, 1),
+                                      "frac": round(credited / HBM_PEAK_GBS, 4)},
+            "note": "achieved / frac count the bytes that cross HBM (a fused chain moves 16 B/base in all); "
+                    "credited_by_survey_8d counts 16 B per operator executed (8 B for the percentile pass), "
+                    "fused or not, and may therefore exceed what HBM delivers"}
+
+
+def other_workload(args, gd, torch, dist, rank, world, mine, lengths, total_bases, vin, vout, stream, timed_fn, lane_of,
+                   reduce_device="cuda"):
+    """`--workload peaks|morph|percentile`: ONE of BASELINE configs[2..4] as the whole line (tools, DESIGN.md, the
+    multi-rank tests); the driver's default run carries all of them under `workloads` (bench_workloads)."""
+    tmp = {i: gd.DeviceVector(lengths[i]) for i in mine}
+    fir = "exact" if args.mode == "exact" else "fma"
+    name, bytes_per_base, step, extra, kernels = make_workload(gd, torch, dist, args, args.workload, fir, args.nofuse, mine, lengths,
+                                                               vin, vout, tmp, stream, lane_of, reduce_device)
+    wall_ms, dev_ms = timed_fn(None, args.steps, args.warmup, step=step)
+    moved_per_base = 16 if not args.nofuse else bytes_per_base        # a fused chain moves 8 B in and 8 B out per base in all
+    batch = args.launch == "batch"
     result = {"metric": "Gbases/sec on %s over 3.1 Gbp" % name, "value": round(total_bases / (wall_ms * 1e-3) / 1e9, 2),
               "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
               "ms_per_step": round(wall_ms, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
               "dtype": "f64", "data": "synthetic",
               "config": {"workload": name + " on 24-chrom 3.1 Gbp synthetic signal", "bases": total_bases,
-                         "fir_mode": "exact" if args.mode == "exact" else "fma", "fused": not args.nofuse,
+                         "fir_mode": fir, "fused": not args.nofuse,
                          "library": gd.lib().gdsp_version().decode(),
                          "collectives": (None if dist is None else "gloo, host copy (one-GPU rehearsal)" if reduce_device == "cpu"
                                          else "rccl (torch.distributed nccl backend), device words"),
                          "streams": args.streams, "launch": "one launch per operator covers every chromosome of the rank" if batch
                                     else "one launch per operator and chromosome",
                          "sharding": "whole chromosomes, LPT over ranks"},
-              "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(achieved / HBM_PEAK_GBS, 4),
-                           "traffic": measured_traffic(kernels[0], moved_per_base * bases_rank / (1 if batch else max(1, len(mine)))),
-                           "traffic_measured": traffic_source(kernels[0]),
-                           "kernels": kernels,
-                           "hbm_bytes_per_base_moved": moved_per_base,
-                           "credited_by_survey_8d": {"bytes_per_base": bytes_per_base, "achieved": round(credited, 1),
-                                                     "frac": round(credited / HBM_PEAK_GBS, 4)},
-                           "note": "achieved / frac count the bytes that cross HBM (a fused chain moves 16 B/base in all); "
-                                   "credited_by_survey_8d counts 16 B per operator executed (8 B for the percentile pass), "
-                                   "fused or not, and may therefore exceed what HBM delivers"}}
+              "roofline": workload_roofline(gd, args, world, mine, lengths, dev_ms, bytes_per_base, moved_per_base, kernels)}
     result.update(extra)
     if rank == 0:
         print(json.dumps(result))
+
+
+def bench_workloads(args, gd, torch, names, mine, lengths, total_bases, vin, vout, stream, timed_fn, lane_of):
+    """BASELINE configs[2..4] in the driver's own run (one rank): each timed like the headline (same harness, same
+    resident signal, the reference's arithmetic) and checked against the CPU oracle right here.
+      configs[2]  smooth W=101 = localmax N=11, exact, fused (the filtered route) -- on the real-valued genome and on
+                  read depth (piecewise-constant integers, what coverage pipelines carry)
+      configs[3]  dilate 1001 = erode 1001 = binarize, fused
+      configs[4]  percentile 99 = binarize --threshold=percentile99, fused; and percentile 99 alone
+    A step = the chain over the 24 chromosomes (genodsp.c:900-936: every operator over every chromosome)."""
+    from oracle import cpu                           # the checker; never on the measured path
+    steps, warmup = max(3, min(args.steps, 10)), 2
+    tmp = {i: gd.DeviceVector(lengths[i]) for i in mine}
+    depth = {i: gd.DeviceVector(lengths[i]) for i in mine}
+    for i in mine:
+        gd.synth_coverage(SEED, i, 0, lengths[i], mode=0, out=depth[i], stream=stream.handle)
+    stream.sync()
+    k = max(mine, key=lambda i: lengths[i])          # the chromosome the window checks look at
+    n = lengths[k]
+    rng = np.random.default_rng(2)
+    span = min(4096, n)
+    starts = sorted(set([0, n - span] + [int(s) for s in rng.integers(0, max(1, n - span), 6)]))
+    left, right = gd.split_length(1001)
+
+    def windows_equal(out_vec, synth_mode, margin, chain):
+        """chain(oracle, stretch) on [s-margin, s+m+margin) of the regenerated input, cut to [s, s+m), against what the
+        HIP path left in out_vec: every bit"""
+        same = True
+        for s in starts:
+            m = min(span, n - s)
+            xlo, xhi = max(0, s - margin), min(n, s + m + margin)
+            want = chain(cpu.synth_coverage(SEED, k, xlo, xhi - xlo, synth_mode))[s - xlo:s - xlo + m]
+            got = out_vec.buf.download(np.float64, m, out_vec.offset + 8 * s)
+            same = same and got.tobytes() == np.ascontiguousarray(want, np.float64).tobytes()
+        return {"chromosome": names[k], "windows": len(starts), "window_len": span, "bit_identical": bool(same), "ok": bool(same),
+                "against": "oracle (CPU restatement of the reference's loops) on the regenerated stretches"}
+
+    peaks_chain = lambda x: cpu.local_extrema(cpu.smooth(x, WINDOW), 11, True, 0.0)
+    morph_chain = lambda x: cpu.binarize(cpu.erode(cpu.dilate(x, left, right), left, right), 0.0)
+    plan = [("peaks", "exact", vin, 1, "real-valued genome (the bench signal)", lambda: windows_equal(tmp[k], 1, 64, peaks_chain)),
+            ("peaks", "exact", depth, 0, "read depth (piecewise-constant integers)", lambda: windows_equal(tmp[k], 0, 64, peaks_chain)),
+            ("morph", None, vin, 1, "real-valued genome (the bench signal)", lambda: windows_equal(tmp[k], 1, 2304, morph_chain)),
+            ("percentile", None, vin, 1, "real-valued genome (the bench signal)", None),
+            ("percentile_alone", None, vin, 1, "real-valued genome (the bench signal)", None)]
+    out = []
+    counts = {}                                      # (value) -> (below, equal) over the genome, counted on the host once
+    for workload, fir, src, synth_mode, signal, check in plan:
+        alone = workload == "percentile_alone"
+        wl = "percentile" if alone else workload
+        name, bytes_per_base, step, extra, kernels = make_workload(gd, torch, None, args, wl, fir, False, mine, lengths, src, vout, tmp,
+                                                                   stream, lane_of, alone=alone)
+        wall_ms, dev_ms = timed_fn(None, steps, warmup, step=step)
+        moved = 8 if alone else 16
+        entry = {"workload": name + " on the 24-chrom 3.1 Gbp " + signal + (", smooth in the reference's arithmetic (exact), "
+                             "fused" if workload == "peaks" else ", one read of the signal" if alone else ", fused"),
+                 "config": "BASELINE configs[%d]" % {"peaks": 2, "morph": 3}.get(workload, 4),
+                 "value": round(total_bases / (wall_ms * 1e-3) / 1e9, 2), "unit": "Gbases/s",
+                 "ms_per_step": round(wall_ms, 4), "device_ms_per_step": round(dev_ms, 4), "steps": steps, "warmup": warmup,
+                 "roofline": workload_roofline(gd, args, 1, mine, lengths, dev_ms, bytes_per_base, moved, kernels)}
+        if check is not None:
+            entry["parity"] = check()
+        else:
+            entry["parity"] = percentile_check(gd, cpu, names, mine, lengths, vin, tmp, k, starts, span, extra, counts,
+                                               binarized=not alone)
+        for key in ("percentile99", "sampled", "percentile_route", "binarize_in_one_pass"):
+            if key in extra:
+                entry[key] = extra[key]
+        out.append(entry)
+    return out
+
+
+def percentile_check(gd, cpu, names, mine, lengths, vin, tmp, k, starts, span, extra, counts, binarized):
+    """The HIP path's genome-wide percentile held to the reference's definition without sorting 3.1 G values on the
+    host: the value is the order statistic of rank r = floor(count * p / 100) (percentile.c:587-589 as restated in
+    oracle/gdsp_oracle.c:orc_percentile, r clamped to count-1) exactly when  #(x < V) <= r < #(x <= V)  -- counted on the
+    host over every base of every chromosome, copied back from HBM.  The fused binarize output is then held to the
+    oracle's binarize at that value on sampled windows."""
+    from concurrent.futures import ThreadPoolExecutor
+    V = extra["percentile99"]
+    if V not in counts:
+        def count(x):
+            return int(np.count_nonzero(x < V)), int(np.count_nonzero(x == V))
+        below = equal = 0
+        with ThreadPoolExecutor(max(1, min(8, len(os.sched_getaffinity(0))))) as pool:
+            pending = []
+            for i in mine:                           # copies back one after the other, counting in the pool behind them
+                pending.append(pool.submit(count, vin[i].numpy()))
+                while len(pending) > 4:
+                    b, e = pending.pop(0).result()
+                    below, equal = below + b, equal + e
+            for f in pending:
+                b, e = f.result()
+                below, equal = below + b, equal + e
+        counts[V] = (below, equal)
+    below, equal = counts[V]
+    population = sum(lengths[i] for i in mine)
+    r = min(population - 1, int(float(population * 99000) / (100.0 * 1000)))
+    ok = bool(extra["sampled"] == population and below <= r < below + equal)
+    res = {"percentile99": V, "population": population, "rank": r, "values_below": below, "values_equal": equal,
+           "is_the_order_statistic": ok,
+           "against": "the reference's rank (percentile.c:587-589) by counting every base on the host"}
+    if binarized:
+        n = lengths[k]
+        same = True
+        for s in starts:
+            m = min(span, n - s)
+            want = cpu.binarize(cpu.synth_coverage(SEED, k, s, m, 1), V)
+            got = tmp[k].buf.download(np.float64, m, tmp[k].offset + 8 * s)
+            same = same and got.tobytes() == np.ascontiguousarray(want, np.float64).tobytes()
+        res.update({"binarize_chromosome": names[k], "binarize_windows": len(starts), "binarize_bit_identical": bool(same)})
+        ok = ok and same
+    res["ok"] = bool(ok)
+    return res
 
 
 def measured_traffic(kernel, algorithmic_bytes_per_launch):

@@ -23,7 +23,7 @@ def _free_port():
 
 def _bench(ranks, workload, scale, extra=()):
     common = ["bench.py", "--gpus", str(ranks), "--workload", workload, "--scale", str(scale), "--steps", "1",
-              "--warmup", "0", "--no-cpu-baseline"] + list(extra)
+              "--warmup", "0", "--no-cpu-baseline", "--sustain", "0.2"] + list(extra)
     if ranks == 1:
         cmd = [sys.executable] + common
     else:
@@ -125,3 +125,20 @@ def test_smooth_over_two_ranks_reports_both_splits_and_every_ranks_time():
     assert sum(alt["bases_per_rank"]) == two["config"]["bases"]
     assert max(alt["bases_per_rank"]) - min(alt["bases_per_rank"]) <= 1            # equal shares
     assert two["parity"]["ok"]
+
+
+def test_default_line_carries_the_other_baseline_configs_and_a_sustained_figure():
+    """The driver's one-rank run also times BASELINE configs[2..4] (`workloads`, each held to the oracle in the run) and
+    the headline kernel back to back (`sustained`); shrunk here, the keys and the checks are the full run's."""
+    one = _bench(1, "smooth", 0.02)
+    assert one["sustained"]["steps"] >= 1 and one["sustained"]["ms_per_step"] > 0
+    assert abs(one["sustained"]["rel_diff_vs_ms_per_step"]) < 10
+    got = one["workloads"]
+    assert [w["config"] for w in got] == ["BASELINE configs[2]", "BASELINE configs[2]", "BASELINE configs[3]",
+                                          "BASELINE configs[4]", "BASELINE configs[4]"]
+    for w in got:
+        assert w["parity"]["ok"] is True, w
+        assert w["value"] > 0 and w["roofline"]["frac"] > 0 and "credited_by_survey_8d" in w["roofline"]
+    assert got[3]["percentile99"] == got[4]["percentile99"] and got[3]["parity"]["is_the_order_statistic"]
+    two = _bench(2, "smooth", 0.02)
+    assert "workloads" not in two and "sustained" in two           # the scaling runs time the metric only
