@@ -36,7 +36,10 @@ def genome():
     return gold, chroms, reads
 
 
-SHARDINGS = {"chromosomes": [], "bases_3_shards": ["--gpus=3", "--sharding=bases"]}
+# the 8-shard rows are the contract's device count (BASELINE configs[3], [4]: "across 8xMI355X") rehearsed on the one GPU:
+# the LPT deal of 24 chromosomes over 8 devices, the genome cut into 8 stretches of bases, percentile's reductions over 8
+SHARDINGS = {"chromosomes": [], "bases_3_shards": ["--gpus=3", "--sharding=bases"],
+             "chromosomes_8_shards": ["--gpus=8", "--sharding=chromosomes"], "bases_8_shards": ["--gpus=8", "--sharding=bases"]}
 
 
 # configs[4] once more without `--preserve`: the reference needs it (its percentile sorts the signal in place,
@@ -50,6 +53,8 @@ EXTRA = {"config4_percentile_without_preserve": "config4_percentile"}
 def test_genome_scale_pipeline_prints_what_the_reference_prints(name, sharding, genome):
     gold, chroms, reads = genome
     recorded = EXTRA.get(name, name)
+    if sharding.endswith("_8_shards") and (name in EXTRA or name.startswith("config1")):
+        pytest.skip("the 8-shard rehearsal runs configs[2..4] as BASELINE spells them")
     if recorded not in gold["runs"]:
         pytest.skip("no recorded reference run for " + recorded)
     want = gold["runs"][recorded]

@@ -55,3 +55,16 @@ def test_seam_crossing_pipelines_do_not_read_memory_nobody_wrote(case, poison, t
     rc, out, err = run(case["args"], case["stdin"], case["chroms_text"], tmp_path, case.get("files"))
     assert rc == 0, err
     cli_compare.assert_digest(case, out, err)
+
+
+@pytest.mark.parametrize("sharding", ["chromosomes", "bases"])
+@pytest.mark.parametrize("case", DIGESTS[1::4], ids=[c["name"] for c in DIGESTS[1::4]])
+def test_seam_crossing_pipelines_over_eight_shards(case, sharding, tmp_path, monkeypatch):
+    """the contract's device count (BASELINE: 8 x MI355X) rehearsed on the one GPU: two or three chromosomes dealt over
+    eight devices leave most of them empty (--sharding=chromosomes), eight stretches of bases cut every chromosome
+    (--sharding=bases); either way the reference binary's bytes"""
+    monkeypatch.setenv("GDSP_OVERSUBSCRIBE_GPUS", "1")
+    rc, out, err = run(["--gpus=8", "--sharding=" + sharding] + case["args"], case["stdin"], case["chroms_text"], tmp_path,
+                       case.get("files"))
+    assert rc == 0, err
+    cli_compare.assert_digest(case, out, err)

@@ -37,6 +37,27 @@ def test_bench_genome_is_the_survey_genome():
     assert [n for _, n in bench.GENOME] == GENOME and sum(GENOME) == 3088269832
 
 
+def test_bench_pieces_at_the_contract_rank_counts():
+    """bench.py's two splits at 1/2/4/8 ranks: whole chromosomes dealt longest-first (every chromosome once, nobody
+    empty) and equal stretches of the concatenated genome (shares within one base, pieces in order, every base once)"""
+    import bench
+    import genodsp_amd as gd
+    for world in (1, 2, 4, 8):
+        whole = bench.shard_pieces(GENOME, world, "chromosomes", gd.lpt_shards)
+        assert sorted(c for sh in whole for c, _, _, _ in sh) == list(range(24)) and all(sh for sh in whole)
+        cut = bench.shard_pieces(GENOME, world, "bases", gd.lpt_shards)
+        shares = [sum(b - a for _, _, a, b in sh) for sh in cut]
+        assert sum(shares) == sum(GENOME) and max(shares) - min(shares) <= 1
+        seen = [0] * 24
+        for sh in cut:
+            for c, _, a, b in sh:
+                assert a == seen[c] and a < b <= GENOME[c]
+                seen[c] = b
+                lo, hi = bench.piece_extent((c, 0, a, b), GENOME)
+                assert lo == max(0, a - 50) and hi == min(GENOME[c], b + 50)
+        assert seen == GENOME
+
+
 def _np_histogram(vecs, window, lo, hi, shift, bits, prefix):
     """numpy stand-in for gdsp_select_histogram (same key image, same filter)."""
     nb = 1 << bits
@@ -91,11 +112,14 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_percentile_select_across_two_ranks():
+@pytest.mark.parametrize("world", [2, 8])
+def test_percentile_select_across_ranks(world):
+    """world 8 is the contract's rank count (BASELINE configs[4]: 8 x MI355X): five chromosomes over eight ranks leave
+    three ranks with nothing of their own, and they must still take part in every reduction and end with the values"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     out = [q.get(timeout=180) for _ in procs]
@@ -103,6 +127,6 @@ def test_percentile_select_across_two_ranks():
         p.join(timeout=60)
         assert p.exitcode == 0
     owned = sorted(i for _, _, mine in out for i in mine)
-    assert owned == [0, 1, 2, 3, 4]
+    assert owned == [0, 1, 2, 3, 4] and len(out) == world
     for rank, results, _ in out:
         assert all(results.values()), (rank, results)
