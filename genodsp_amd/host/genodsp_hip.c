@@ -439,18 +439,23 @@ static spec* vector_spec (char* vName)           /* the stretch being processed,
 	return find_chromosome_spec (vName);
 	}
 
+static void ensure_partners (void);   /* the partners' arena: waits for the helper thread, or allocates now (below) */
+
 valtype* partner_vector (char* vName)
 	{
 	spec* s = vector_spec (vName);
-	return (s == NULL)? NULL : ((xspec*) s)->partner;
+	if (s == NULL) return NULL;
+	ensure_partners ();
+	return ((xspec*) s)->partner;
 	}
 
-valtype* partner_of (spec* s) { return ((xspec*) s)->partner; }
+valtype* partner_of (spec* s) { ensure_partners ();  return ((xspec*) s)->partner; }
 
 /* the output an operator wrote into the partner becomes the signal; what was the signal is nobody's data any more
  * (GDSP_POISON: and is overwritten to prove it -- a later kernel that still reads it changes the output) */
 void flip_spec (spec* s)
 	{
+	ensure_partners ();
 	valtype* t = s->valVector;  s->valVector = ((xspec*) s)->partner;  ((xspec*) s)->partner = t;
 	valtype poison;
 	if (gdsp_poison (&poison))
@@ -667,27 +672,179 @@ static void deal_chromosomes (void)
 		}
 	}
 
-static void allocate_vectors (void)
+/* ---- allocation: ONE arena per device for the vectors and one for their partners, each a
+ * single gdsp_malloc, every vector sub-allocated at 256 bytes.  The arenas are made by a helper thread while the main
+ * thread reads and parses stdin (host/ingest.c produces records that do not depend on the device; the first batch of
+ * intervals to be applied waits for the vectors): start-up of the HIP runtime and the allocation -- seconds when the
+ * process before has just given 49 GB back -- run beside the parse instead of in front of it.  The partners' arena is
+ * made only when the parsed pipeline holds an out-of-place operator (pipeline_wants_partners), behind the vectors', and is
+ * waited for by the first operator that asks for a partner; an operator that asks without having been foreseen (a
+ * plug-in) gets it made on the spot.  Reference: genodsp.c:865-893 (allocate every vector, then read stdin). */
+#define ARENA_ALIGN 256
+static size_t arena_room (u32 length)
+	{ return ((((size_t) length + 2) * sizeof(valtype)) + ARENA_ALIGN - 1) & ~(size_t) (ARENA_ALIGN - 1); }
+
+static pthread_t       allocThread;
+static pthread_mutex_t allocLock = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t  allocCond = PTHREAD_COND_INITIALIZER;
+static int    allocThreaded  = false;                 /* a helper thread was started (and not yet joined) */
+static int    vectorsReady   = false, partnersReady = false, partnersPlanned = false;
+static double allocStartupMs = 0, allocVectorsMs = 0, allocPartnersMs = 0, allocWaitedMs = 0;
+static double now_ms (void);
+
+/* one arena on every device for `which` (0: the vectors, 1: the partners) of the whole chromosomes and of the stretches */
+static void make_arenas (int which)
 	{
+	for (int d=0 ; d<numDevices ; d++)
+		{
+		size_t bytes = 0;
+		for (int i=0 ; chromsSorted[i]!=NULL ; i++)
+			{ if (((xspec*) chromsSorted[i])->device == d) bytes += arena_room (chromsSorted[i]->length); }
+		for (int i=0 ; i<numPieces ; i++)
+			{ if (pieces[i].x.device == d) bytes += arena_room (pieces[i].x.pub.length); }
+		if (bytes == 0) continue;
+		char* base = NULL;
+		check_gdsp (use_device (d), "select device");
+		check_gdsp (gdsp_malloc ((void**) &base, bytes), which? "allocate the partners' arena" : "allocate the vectors' arena");
+		for (int i=0 ; chromsSorted[i]!=NULL ; i++)
+			{
+			spec*  s = chromsSorted[i];
+			xspec* x = (xspec*) s;
+			if (x->device != d) continue;
+			if (which) x->partner = (valtype*) base;
+			else
+				{
+				if (trackOperations) tracking_report ("allocate(%s / %s bytes)\n", s->chrom, ucommatize (s->length));
+				s->valVector = (valtype*) base;
+				check_gdsp (gdsp_fill (s->valVector, s->length, 0.0, devs[d].stream), "clear chromosome vector");
+				}
+			base += arena_room (s->length);
+			}
+		for (int i=0 ; i<numPieces ; i++)
+			{
+			piece* p = &pieces[i];
+			if (p->x.device != d) continue;
+			if (which) p->x.partner = (valtype*) base;  else p->x.pub.valVector = (valtype*) base;
+			base += arena_room (p->x.pub.length);
+			}
+		}
+	}
+
+static void* allocate_worker (void* arg)
+	{
+	(void) arg;
+	const double t0 = now_ms ();
+	int available = 0;
+	check_gdsp (gdsp_device_count (&available), "count GPUs");
+	if (available < 1) { fprintf (stderr, "[%s] no GPU visible\n", programName);  exit (EXIT_FAILURE); }
+	physicalDevices = available;
+	if ((available < numDevices) && (getenv ("GDSP_OVERSUBSCRIBE_GPUS") == NULL))
+		{
+		fprintf (stderr, "[%s] %d GPU(s) requested, %d visible (set GDSP_OVERSUBSCRIBE_GPUS=1 to run the\n"
+		                 "%d shards on the visible GPUs anyway)\n", programName, numDevices, available, numDevices);
+		exit (EXIT_FAILURE);
+		}
+	if ((reduceHow == reduce_rccl) && (numDevices > physicalDevices))
+		{ fprintf (stderr, "[%s] --reduce=rccl needs one GPU per shard (%d shards, %d GPUs)\n", programName, numDevices, physicalDevices);  exit (EXIT_FAILURE); }
 	for (int d=0 ; d<numDevices ; d++)
 		{
 		check_gdsp (use_device (d), "select device");
 		check_gdsp (gdsp_stream_create (&devs[d].stream), "create stream");
 		}
-	for (int i=0 ; chromsSorted[i]!=NULL ; i++)
-		{
-		spec*  s = chromsSorted[i];
-		xspec* x = (xspec*) s;
-		if (trackOperations)
-			tracking_report ("allocate(%s / %s bytes)\n", s->chrom, ucommatize (s->length));
-		check_gdsp (use_device (x->device), "select device");
-		currentDevice = x->device;
-		size_t bytes = ((size_t) s->length + 2) * sizeof(valtype);
-		check_gdsp (gdsp_malloc ((void**) &s->valVector, bytes), "allocate chromosome vector");
-		check_gdsp (gdsp_malloc ((void**) &x->partner,   bytes), "allocate chromosome vector");
-		check_gdsp (gdsp_fill (s->valVector, s->length, 0.0, devs[x->device].stream), "clear chromosome vector");
-		}
+	const double t1 = now_ms ();
+	make_arenas (0);
 	if (trackOperations) tracking_report ("allocate(--done--)\n");
+	for (int d=0 ; d<numDevices ; d++)                        /* (the vectors read as zeros before anybody is told they exist) */
+		{ check_gdsp (use_device (d), "select device");  check_gdsp (gdsp_stream_sync (devs[d].stream), "synchronise"); }
+	const double t2 = now_ms ();
+	pthread_mutex_lock (&allocLock);
+	allocStartupMs = t1 - t0;  allocVectorsMs = t2 - t1;
+	vectorsReady = true;
+	pthread_cond_broadcast (&allocCond);
+	pthread_mutex_unlock (&allocLock);
+	if (partnersPlanned)
+		{
+		make_arenas (1);
+		const double t3 = now_ms ();
+		pthread_mutex_lock (&allocLock);
+		allocPartnersMs = t3 - t2;
+		partnersReady = true;
+		pthread_cond_broadcast (&allocCond);
+		pthread_mutex_unlock (&allocLock);
+		}
+	check_gdsp (use_device (0), "select device");
+	return NULL;
+	}
+
+/* the main thread may touch the devices from here on (it has not so far: its current device is the runtime's default, 0) */
+static int vectorsSeen = false, partnersSeen = false;   /* the main thread's own copies: the shared flags are read under the lock */
+
+static void wait_for_vectors (void)
+	{
+	if (vectorsSeen) return;
+	const double t0 = now_ms ();
+	pthread_mutex_lock (&allocLock);
+	while (!vectorsReady) pthread_cond_wait (&allocCond, &allocLock);
+	pthread_mutex_unlock (&allocLock);
+	vectorsSeen = true;
+	allocWaitedMs += now_ms () - t0;
+	}
+
+static void ensure_partners (void)
+	{
+	if (partnersSeen) return;
+	wait_for_vectors ();
+	if (partnersPlanned)
+		{
+		const double t0 = now_ms ();
+		pthread_mutex_lock (&allocLock);
+		while (!partnersReady) pthread_cond_wait (&allocCond, &allocLock);
+		pthread_mutex_unlock (&allocLock);
+		partnersSeen = true;
+		allocWaitedMs += now_ms () - t0;
+		return;
+		}
+	/* nobody foresaw an out-of-place operator (a plug-in's): the helper thread has finished with the devices, make them now */
+	if (allocThreaded) { pthread_join (allocThread, NULL);  allocThreaded = false; }
+	const double t0 = now_ms ();
+	make_arenas (1);
+	check_gdsp (use_device (currentDevice), "select device");
+	allocPartnersMs = now_ms () - t0;
+	partnersPlanned = partnersReady = partnersSeen = true;
+	}
+
+/* does the parsed pipeline hold an operator that writes into a partner?  The built-in in-place operators are named;
+ * anything else (the out-of-place ones, operators linked in through GDSP_EXTRA_OPERATORS) counts as wanting one */
+static int pipeline_wants_partners (void)
+	{
+	static const opfunc_apply inPlace[] =
+		{ op_window_sum_apply, op_cumulative_sum_apply, op_add_apply, op_subtract_apply, op_add_constant_apply, op_invert_apply,
+		  op_multiply_apply, op_divide_apply, op_absolute_value_apply, op_clip_apply, op_erase_apply, op_binarize_apply,
+		  op_input_apply, op_output_apply, op_show_variables_apply, op_mask_apply, op_mask_not_apply, op_or_apply, op_and_apply,
+		  op_min_with_apply, op_max_with_apply, op_map_apply, op_min_in_interval_apply, op_max_in_interval_apply,
+		  op_clump_apply, op_skimp_apply };
+	if (shardBases) return true;                               /* (stretches and their runs: not worth a second rule) */
+	for (dspop* op=pipeline ; op!=NULL ; op=op->next)
+		{
+		int known = false;
+		for (size_t i=0 ; i<sizeof(inPlace)/sizeof(inPlace[0]) ; i++) { if (op->funcApply == inPlace[i]) known = true; }
+		if (op->funcApply == op_percentile_apply)                  /* (fused with the binarize behind it, it writes partners) */
+			known = !(fuseChains && (op->next != NULL) && (op->next->funcApply == op_binarize_apply));
+		if (!known) return true;
+		}
+	return false;
+	}
+
+/* start the allocation; beside the parse of stdin unless the progress lines are wanted in the reference's order */
+static void allocate_vectors (void)
+	{
+	partnersPlanned = pipeline_wants_partners ();
+	const char* e = getenv ("GDSP_ALLOC_THREAD");
+	if (trackOperations || ((e != NULL) && (e[0] == '0')))
+		{ allocate_worker (NULL);  return; }
+	if (pthread_create (&allocThread, NULL, allocate_worker, NULL) != 0)
+		{ allocate_worker (NULL);  return; }
+	allocThreaded = true;
 	}
 
 /* ------------------------------------------------- --sharding=bases: stretches ---- */
@@ -796,19 +953,6 @@ static void show_shards (void)
 		}
 	fprintf (stderr, "sharding=%s halo=%u makespan efficiency %.4f\n", shardBases? "bases" : "chromosomes", haloCap,
 	         (most == 0)? 1.0 : (double) total / ((double) most * numDevices));
-	}
-
-static void allocate_pieces (void)
-	{
-	for (int i=0 ; i<numPieces ; i++)
-		{
-		piece* p = &pieces[i];
-		check_gdsp (use_device (p->x.device), "select device");
-		size_t bytes = ((size_t) p->x.pub.length + 2) * sizeof(valtype);
-		check_gdsp (gdsp_malloc ((void**) &p->x.pub.valVector, bytes), "allocate stretch");
-		check_gdsp (gdsp_malloc ((void**) &p->x.partner,       bytes), "allocate stretch");
-		}
-	check_gdsp (use_device (currentDevice), "select device");
 	}
 
 static void copy_bases (valtype* dst, int dstDev, const valtype* src, int srcDev, u32 count)
@@ -998,6 +1142,7 @@ static void stage_chromosome (int ci, staging** out)
 	{
 	spec*    s  = chromsSorted[ci];
 	pending* p  = &pend[ci];
+	wait_for_vectors ();                                       /* (the first batch of a run: the arenas may still be in the making) */
 	select_device_of (s);
 	staging* st = &stage[currentDevice];
 	void*    stream = op_stream ();
@@ -1781,42 +1926,29 @@ int main (int argc, char** argv)
 		return EXIT_SUCCESS;
 		}
 
-	const double tStart = now_ms ();
-	int available = 0;
-	check_gdsp (gdsp_device_count (&available), "count GPUs");
-	if (available < 1) { fprintf (stderr, "[%s] no GPU visible\n", programName);  return EXIT_FAILURE; }
-	physicalDevices = available;
-	if ((available < numDevices) && (getenv ("GDSP_OVERSUBSCRIBE_GPUS") == NULL))
-		{
-		fprintf (stderr, "[%s] %d GPU(s) requested, %d visible (set GDSP_OVERSUBSCRIBE_GPUS=1 to run the\n"
-		                 "%d shards on the visible GPUs anyway)\n", programName, numDevices, available, numDevices);
-		return EXIT_FAILURE;
-		}
-
-	if ((reduceHow == reduce_rccl) && (numDevices > physicalDevices))
-		{ fprintf (stderr, "[%s] --reduce=rccl needs one GPU per shard (%d shards, %d GPUs)\n", programName, numDevices, physicalDevices);  return EXIT_FAILURE; }
-
 	sort_chromosomes_by_length ();
 	deal_chromosomes ();
 	if (shardBases) plan_pieces ();                            /* (before allocation: stretches count towards scratch sizes) */
-	const double tAlloc = now_ms ();
-	allocate_vectors ();
-	if (shardBases) allocate_pieces ();
-	if (reportGpu)                                             /* what a run spends before its first interval: the rest of its wall time is the teardown at exit */
-		{
-		u64 bases = 0;
-		for (int i=0 ; chromsSorted[i]!=NULL ; i++) bases += chromsSorted[i]->length;
-		sync_all_devices ();
-		wall_phase (NULL, "start-up (HIP runtime, devices)", tAlloc - tStart, (u64) numDevices, "devices", 0);
-		wall_phase (NULL, "allocate (vectors and partners)", now_ms () - tAlloc, bases, "values", 0);
-		}
+	const double tStart = now_ms ();
+	allocate_vectors ();                                       /* HIP start-up, one arena per device: beside the parse of stdin */
 
 	/* stdin is the signal unless the first operator is `input` (genodsp.c:891-893) */
 	if ((pipeline == NULL) || (strcmp (pipeline->name, "input") != 0))
 		{
 		double t0 = now_ms ();
 		read_intervals (stdin, valColumn, originOne, ri_overlapSum, /*clear*/ false, 0.0);
+		wait_for_vectors ();
 		if (reportGpu) { sync_all_devices ();  wall_phase (NULL, "input (stdin: parse, stage, apply)", now_ms () - t0, intervalsRead, "intervals", 0); }
+		}
+	wait_for_vectors ();
+	if (reportGpu)                                             /* what a run spends before its first operator; the helper thread's clock */
+		{
+		u64 bases = 0;
+		for (int i=0 ; chromsSorted[i]!=NULL ; i++) bases += chromsSorted[i]->length;
+		wall_phase (NULL, "start-up (HIP runtime, devices)", allocStartupMs, (u64) numDevices, "devices", 0);
+		wall_phase (NULL, allocThreaded? "allocate vectors (one arena per device; beside the input)" : "allocate vectors (one arena per device)",
+		            allocVectorsMs, bases, "values", 0);
+		wall_phase (NULL, "ready for the first operator (since start)", now_ms () - tStart, bases, "values", 0);
 		}
 
 	/* batching loop, genodsp.c:900-936: maximal runs of per-chromosome operators go
@@ -1948,7 +2080,16 @@ int main (int argc, char** argv)
 		if (reportGpu) { fflush (stdout);  wall_phase (NULL, "output (find runs, fetch, format)", now_ms () - t0, linesWritten - linesBefore, "lines", 0); }
 		}
 	sync_all_devices ();
-	if (reportGpu) report_gpu_times ();
+	if (allocThreaded) { pthread_join (allocThread, NULL);  allocThreaded = false; }
+	if (reportGpu)
+		{
+		u64 bases = 0;
+		for (int i=0 ; chromsSorted[i]!=NULL ; i++) bases += chromsSorted[i]->length;
+		if (partnersPlanned) wall_phase (NULL, "allocate partners (one arena per device; helper thread)", allocPartnersMs, bases, "values", 0);
+		else               wall_phase (NULL, "allocate partners (none: every operator works in place)", 0, 0, "values", 0);
+		wall_phase (NULL, "waited for the helper thread's allocations", allocWaitedMs, 0, "values", 0);
+		report_gpu_times ();
+		}
 
 	for (dspop* op=pipeline, *next ; op!=NULL ; op=next)
 		{ next = op->next;  free (op->name);  (*op->funcFree) (op); }

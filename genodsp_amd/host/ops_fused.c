@@ -97,8 +97,11 @@ int batch_apply_on_device (dspop* op, dspop* stopOp, spec** units, int nunits, i
 	if (next == stopOp) next = NULL;
 	gdsp_batch_item* items = (gdsp_batch_item*) calloc (nunits? nunits : 1, sizeof(gdsp_batch_item));
 	if (items == NULL) { fprintf (stderr, "out of memory\n");  exit (EXIT_FAILURE); }
+	/* (the in-place operators never ask for a partner: a pipeline of them alone runs without the partners' arena) */
+	const int inPlace = (f == op_binarize_apply) || (f == op_clip_apply) || (f == op_erase_apply)
+	                 || (f == op_add_constant_apply) || (f == op_absolute_value_apply);
 	for (int i=0 ; i<nunits ; i++)
-		{ items[i].d_in = units[i]->valVector;  items[i].d_out = partner_of (units[i]);  items[i].n = units[i]->length; }
+		{ items[i].d_in = units[i]->valVector;  items[i].d_out = inPlace? NULL : partner_of (units[i]);  items[i].n = units[i]->length; }
 	void* st = op_stream ();
 	int   consumed = 1, outOfPlace = true, rc = GDSP_OK;
 

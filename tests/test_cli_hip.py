@@ -327,6 +327,37 @@ def test_smooth_arithmetic_modes_on_the_command_line(tmp_path):
     assert rc != 0
 
 
+def test_hann_in_front_of_strict_comparisons_prints_the_fma_bytes(tmp_path):
+    """--smooth=hann is not shift invariant (equal windows can differ in their last bits), so a smooth that feeds
+    localmax / localmin is evaluated tap by tap with fused multiply-adds instead (ops_sum.c,
+    ops_fused.c): the peaks printed under --smooth=hann are byte for byte those of --smooth=fma, fused or with --nofuse,
+    in either launch order -- and the smoothed track itself (no comparison behind it) does differ between the two."""
+    import numpy as np
+    rng = np.random.default_rng(18)
+    chroms = "chrP 60000\nchrQ 9100\n"
+    lines = []
+    for c, n in (("chrP", 60000), ("chrQ", 9100)):
+        for _ in range(n // 12):
+            a = int(rng.integers(0, n - 250))
+            lines.append("%s %d %d %.3f" % (c, a, a + int(rng.integers(10, 250)), rng.random() * 5))
+    iv = "\n".join(lines) + "\n"
+    for tail in (["=", "localmax", "N=11"], ["=", "localmin", "N=7", "--infinity=99"],
+                 ["=", "addconst", "0.5", "=", "smooth", "W=101", "=", "localmax", "N=11", "=", "binarize"]):
+        got = {}
+        for mode in ("fma", "hann"):
+            for extra in ([], ["--nofuse"], ["--nobatch"], ["--nofuse", "--nobatch"]):
+                rc, out, err = run(["--precision=15", "--smooth=" + mode] + extra + ["=", "smooth", "W=101"] + tail, iv, chroms, tmp_path)
+                assert rc == 0, err
+                got[mode, tuple(extra)] = out
+        assert len(set(got.values())) == 1, tail
+        assert len(got["fma", ()].splitlines()) > 50
+    plain = {}
+    for mode in ("fma", "hann"):
+        rc, plain[mode], err = run(["--precision=17", "--smooth=" + mode, "=", "smooth", "W=101"], iv, chroms, tmp_path)
+        assert rc == 0, err
+    assert plain["fma"] != plain["hann"]             # the substitution is the comparison's, not the smooth's
+
+
 def _reads(rng, n_lines, chrom_len, with_values):
     lines = []
     for i in range(n_lines):

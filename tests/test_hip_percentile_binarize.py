@@ -153,3 +153,41 @@ def test_eight_percentiles_in_one_resident_call_equal_the_oracle(gd, monkeypatch
                 wcnt, wvals = cpu.percentile([x[: n // 2], x[n // 2:]], pts, **kw)
                 assert st["resident"] == 1, (name, kw, st)
             assert cnt == wcnt and bits_equal(np.array(vals), np.array(wvals)), (name, kw, vals, wvals)
+
+
+def test_infinities_and_signed_zeros_without_nans_are_held_to_the_oracle_on_every_route(gd, monkeypatch):
+    """A NaN-free population on which the reference's comparator (genodsp.c:2262-2270) IS an order: +-inf (inside the
+    population only when the bounds let them in: the defaults are -DBL_MAX / DBL_MAX, percentile.c:611-651 skips what lies
+    outside), +0 and -0 (equal under that order: a zero is compared as a value, its sign is the sort's leftover and not
+    pinned) and negative values.  Every route of a one-device call -- resident, resident with a launch per digit, the LDS
+    select giving up, chained, a read-back per digit -- gives the oracle's population and order statistics, and the fused
+    binarize the oracle's binarize at that value."""
+    n = 2_100_001
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(n) * 5.0
+    x[3::1013] = np.inf
+    x[7::1019] = -np.inf
+    x[11::29] = 0.0
+    x[13::31] = -0.0
+    assert not np.isnan(x).any()
+    parts = [x[: n // 2 + 3], x[n // 2 + 3:]]
+    vecs = [gd.DeviceVector.from_numpy(p) for p in parts]
+    pts = [30, 10000, 50000, 90000, 99950]           # -inf, a negative value, a zero, a positive value, +inf (bounds open)
+    for kw in ({"lo": -np.inf, "hi": np.inf}, {}, {"lo": -np.inf, "hi": 2.5}, {"lo": 0.0, "hi": np.inf}, {"lo": -np.inf, "hi": np.inf, "window": 3}):
+        wcnt, wvals = cpu.percentile(parts, pts, **kw)
+        if kw.get("lo") == -np.inf and kw.get("hi") == np.inf and "window" not in kw:
+            assert wvals[0] == -np.inf and wvals[2] == 0.0 and wvals[4] == np.inf
+        for route, env in ROUTES.items():
+            for k in ("GDSP_PERCENTILE_RESIDENT_OFF", "GDSP_PERCENTILE_CHAIN_OFF", "GDSP_PERCENTILE_LDS_SELECT", "GDSP_PERCENTILE_LDS_GIVEUP"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            cnt, vals = gd.percentile(vecs, pts, **kw)
+            assert cnt == wcnt, (route, kw)
+            for got, want in zip(vals, wvals):
+                assert got == want and (want == 0.0 or bits_equal(np.array([got]), np.array([want]))), (route, kw, vals, wvals)
+            for which in (0, 2, 4):
+                c2, v2, outs, one_pass = gd.percentile_binarize(vecs, pts, which=which, **kw)
+                assert c2 == wcnt and all(a == b for a, b in zip(v2, wvals)), (route, kw)
+                for p, o in zip(parts, outs):
+                    assert bits_equal(o.numpy(), cpu.binarize(p, wvals[which], False, 1.0, 0.0)), (route, kw, which)
