@@ -89,7 +89,14 @@ template <int W, int EE = HN_E> struct HannConsts
 // over the workgroup), and the staged inputs are still in the LDS image (no barrier after the last read).
 // With STATS, stats[wave] = { largest magnitude's high word, bit 0: a sign bit is set, bit 1: 0 < |x| < 2^-500 } of the wave's
 // 64 blocks (visible on return).
-template <int W, bool STATS = false, int EE = HN_E>
+// The LDS image has a pitch of 17 doubles per block of 16: the 17th slot of every block is never staged, read or written
+// by the block sums.  A kernel that must fit its LDS into a quarter of a CU's (gdsp_peaks.hip: image + block totals are
+// 40 KiB to the byte) keeps its few words of bookkeeping there: pad word i = the low word of block i's 17th slot.
+__device__ __forceinline__ uint32_t* hann_pad_word (double* lds, int i)
+	{ return reinterpret_cast<uint32_t*> (lds + i * HN_PITCH + HN_G); }
+
+// PADS: the four waves' verdicts live in pad words 0..3 instead of `huge` (which is then not used)
+template <int W, bool STATS = false, int EE = HN_E, bool PADS = false>
 __device__ __forceinline__ bool hann_tile_sums (double* lds, double (*tot)[HN_THREADS], uint32_t* huge,
                                                 const double* __restrict__ in, uint32_t n, int64_t e0,
                                                 const HannConsts<W, EE>& K, double (&acc)[HN_G], uint32_t (*stats)[2] = NULL)
@@ -174,7 +181,7 @@ __device__ __forceinline__ bool hann_tile_sums (double* lds, double (*tot)[HN_TH
 			}
 		tot[0][p] = a0;  tot[1][p] = ar;  tot[2][p] = ai;
 		const bool any = (__builtin_amdgcn_ballot_w64 (big >= HN_HUGE_HI) != 0);   // the 256 blocks are the whole tile
-		if ((p & 63) == 0) huge[p >> 6] = any? 1u : 0u;
+		if ((p & 63) == 0) { if (PADS) *hann_pad_word (lds, p >> 6) = any? 1u : 0u;  else huge[p >> 6] = any? 1u : 0u; }
 		if (STATS)
 			{
 			const uint32_t flags = ((__builtin_amdgcn_ballot_w64 ((signs >> 31) != 0) != 0)? 1u : 0u)
@@ -184,8 +191,13 @@ __device__ __forceinline__ bool hann_tile_sums (double* lds, double (*tot)[HN_TH
 			}
 		}
 	__syncthreads ();
-	const uint4 hg     = *reinterpret_cast<const uint4*> (huge);
-	const bool  direct = ((hg.x | hg.y | hg.z | hg.w) != 0);       // uniform over the workgroup
+	bool direct;                                                   // uniform over the workgroup
+	if (PADS) direct = ((*hann_pad_word (lds, 0) | *hann_pad_word (lds, 1) | *hann_pad_word (lds, 2) | *hann_pad_word (lds, 3)) != 0);
+	else
+		{
+		const uint4 hg = *reinterpret_cast<const uint4*> (huge);
+		direct = ((hg.x | hg.y | hg.z | hg.w) != 0);
+		}
 
 	// ---- phase 2: the middle stretch of one window per left end
 	if (live && !direct)

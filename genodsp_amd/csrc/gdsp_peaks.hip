@@ -42,6 +42,9 @@
 #ifndef PK_E
 #define PK_E 0
 #endif
+#ifndef PK_WAVES
+#define PK_WAVES       4                                  // workgroups per CU (= waves per SIMD) the filter is compiled for: 40 KiB of LDS and 128 registers let a fourth in
+#endif
 #define PK_HMAX        7                                  // neighbourhoods up to 15 bases: one lane of a 16-lane group per neighbour
 #define PK_PROBE_TILES 64
 #define PK_TILE_CAP    192                                // undecided bases a tile can queue (4.8 % of its 3974: nine times the average on real-valued coverage)
@@ -104,23 +107,40 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 	constexpr int    h = HH, sh = HH & 1;                          // sh keeps the first staged index even
 	constexpr int    stride = G::OUT - 2*h - 2*sh;                 // outputs kept per tile (even)
 	constexpr int    NW = HN_THREADS / 64;
+	// LDS: the staged image and the block totals, 40 KiB to the byte -- a quarter of a CU's, so that four workgroups fit
+	// (round 5; 44.7 KiB and three until then).  Everything else lives inside those two:
+	//   * what is alive while the block totals are (the waves' verdicts and statistics, the counters, the edge words
+	//     exchanged between waves, CWM's change bits) in the image's PAD slots -- the 17th double of each block of 16, which
+	//     nothing stages, reads or writes (gdsp_hann_tile.h: hann_pad_word).  Pad p: low word = slot p of the map below,
+	//     high word = chgBits[p] (CWM); the edge values of the double-precision path take whole pads (they come after the
+	//     change bits' last use)
+	//   * what is written only after the barrier that follows the block sums' last read of the totals (B1 below) ON the
+	//     totals: the bit maps, the lists, the exact values, the window's taps, CWM's run values
 	__shared__ __attribute__((aligned(16))) double lds[HN_THREADS * HN_PITCH];
-	__shared__ double tot[3][HN_THREADS];
-	__shared__ __attribute__((aligned(16))) uint32_t huge[NW];
-	__shared__ uint32_t stats[NW][2];
-	__shared__ double   edgeLo[NW][HH], edgeHi[NW][HH];            // a wave's first block's first HH values, its last block's last HH
-	__shared__ uint32_t zeroBits[HN_THREADS/2], sureBits[HN_THREADS/2];   // per block of 16 outputs (16 bits each): exact zeros; peaks evaluated in place
+	__shared__ __attribute__((aligned(16))) double tot[3][HN_THREADS];
+	constexpr int PAD_HUGE = 0, PAD_STATS = 4, PAD_NSURE = 8, PAD_QUEUED = 9, PAD_NLEAD = 10, PAD_NFLAT = 11, PAD_WLEAD = 12,
+	              PAD_ELO = 16, PAD_EHI = 16 + NW * PK_HMAX;
+	static_assert (PAD_EHI + NW * PK_HMAX <= HN_THREADS, "pad map");
+	(void) PAD_HUGE;
+	auto padW = [&] (int i) -> uint32_t& { return *hann_pad_word (lds, i); };
+	auto padD = [&] (int i) -> double&   { return lds[i * HN_PITCH + HN_G]; };
+	auto chgBitsAt = [&] (int i) -> uint32_t& { return hann_pad_word (lds, i)[1]; };
 	constexpr int SURE_CAP = CWM? PK_SURE_CAP - PK_LEAD_CAP : PK_SURE_CAP;
-	__shared__ uint16_t sureList[PK_SURE_CAP];
-	__shared__ uint16_t needList[PK_NEED_INPLACE];                 // the first undecided bases: settled in place when there are no more than these
-	__shared__ double   exactVal[PK_NEED_INPLACE * (2*HH + 1)];    // ... from the exact values of their neighbourhoods
-	__shared__ double   tapsLds[W];                                // the window, for the exact values (as scalar operands its 202 words crowd out the block sums' constants)
-	__shared__ uint32_t nsure, queued;
-	__shared__ uint16_t chgBits[CWM? HN_THREADS : 1];              // per staged block: element u differs from the element before it
-	__shared__ uint16_t leadList[CWM? PK_LEAD_CAP : 1];
-	__shared__ double   blockT[CWM? HN_THREADS : 1];               // per block of outputs that holds a leader: its run's value
-	__shared__ int      waveLead[CWM? NW : 1];
-	__shared__ uint32_t nlead, nflat;
+	char* const tb = reinterpret_cast<char*> (&tot[0][0]);
+	constexpr int OFF_ZERO = 0, OFF_SUREB = OFF_ZERO + 4 * (HN_THREADS/2), OFF_SUREL = OFF_SUREB + 4 * (HN_THREADS/2),
+	              OFF_NEEDL = OFF_SUREL + 2 * PK_SURE_CAP, OFF_EXACT = (OFF_NEEDL + 2 * PK_NEED_INPLACE + 7) & ~7,
+	              OFF_TAPS = OFF_EXACT + 8 * PK_NEED_INPLACE * (2*HH + 1), OFF_LEADL = OFF_TAPS + 8 * W,
+	              OFF_BLOCKT = (OFF_LEADL + 2 * PK_LEAD_CAP + 7) & ~7, OFF_END = OFF_BLOCKT + (CWM? 8 * HN_THREADS : 0);
+	static_assert (OFF_END <= (int) sizeof(tot), "the lists do not fit on the block totals");
+	uint32_t* const zeroBits = reinterpret_cast<uint32_t*> (tb + OFF_ZERO);    // per block of 16 outputs (16 bits each): exact zeros
+	uint32_t* const sureBits = reinterpret_cast<uint32_t*> (tb + OFF_SUREB);   // ... peaks evaluated in place
+	uint16_t* const sureList = reinterpret_cast<uint16_t*> (tb + OFF_SUREL);
+	uint16_t* const needList = reinterpret_cast<uint16_t*> (tb + OFF_NEEDL);   // the first undecided bases: settled in place when there are no more than these
+	double*   const exactVal = reinterpret_cast<double*>   (tb + OFF_EXACT);   // ... from the exact values of their neighbourhoods
+	double*   const tapsLds  = reinterpret_cast<double*>   (tb + OFF_TAPS);    // the window, for the exact values (as scalar operands its 202 words crowd out the block sums' constants)
+	uint16_t* const leadList = reinterpret_cast<uint16_t*> (tb + OFF_LEADL);
+	double*   const blockT   = reinterpret_cast<double*>   (tb + OFF_BLOCKT);  // (CWM) per block of outputs that holds a leader: its run's value
+	uint32_t& nsure = padW (PAD_NSURE), &queued = padW (PAD_QUEUED), &nlead = padW (PAD_NLEAD), &nflat = padW (PAD_NFLAT);
 
 	const int      p         = threadIdx.x, lane = p & 63, wave = p >> 6;
 	const int64_t  keepStart = (int64_t) tile * stride;            // first output this tile stores
@@ -134,10 +154,9 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 	const int      keepLo    = h + sh;                             // smoothed values [keepLo, keepHi) are this tile's outputs
 	const int      keepHi    = (keepLo + stride < validHi)? keepLo + stride : validHi;
 
-	if (p == 0) { nsure = 0;  queued = 0;  nlead = 0;  nflat = 0; }   // (the barriers of the block sums come before their first use)
-	if (!PROBE && (p < W)) tapsLds[p] = d_taps[p];
+	if (p == 0) { nsure = 0;  queued = 0;  nlead = 0;  nflat = 0; }   // (the barriers of the block sums come before their first use; staging leaves the pads alone)
 	double acc[HN_G];
-	bool direct = hann_tile_sums<W, false, PK_E> (lds, tot, huge, in, n, e0, K, acc);
+	bool direct = hann_tile_sums<W, false, PK_E, true> (lds, tot, NULL, in, n, e0, K, acc);
 
 	// ---- what the tile's inputs are like, from the own block in the LDS image (after the block sums: inside them, where
 	// the registers are fullest, the same few integer operations per element cost a fifth of the kernel): is a sign bit
@@ -155,10 +174,10 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 			smallest = min (smallest, key - 1u);                      // (a zero wraps to the top: ignored)
 			if (CWM) { const long long here = __double_as_longlong (xb[u]);  chg |= ((here != before) || ((p == 0) && (u == 0)))? (1u << u) : 0u;  before = here; }
 			}
-		if (CWM) chgBits[p] = (uint16_t) chg;
+		if (CWM) chgBitsAt (p) = chg;
 		const uint32_t flags = ((__builtin_amdgcn_ballot_w64 ((signs >> 31) != 0) != 0)? 1u : 0u)
 		                     | ((__builtin_amdgcn_ballot_w64 (smallest < 0x20B00000u - 1u) != 0)? 2u : 0u);
-		if (lane == 0) stats[wave][1] = flags;
+		if (lane == 0) padW (PAD_STATS + wave) = flags;
 		}
 
 	// the high words of the own block's smoothed values, as 32-bit integers (see the test below), and the words the
@@ -172,26 +191,25 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 		const bool inside = live && (c >= validLo) && (c < validHi);
 		k[HH + u] = inside? (uint32_t) (__double_as_longlong (acc[u]) >> 32) & 0x7FFFFFFFu : away;          // (-0.0 is a zero)
 		}
-	uint32_t* edgeLoK = reinterpret_cast<uint32_t*> (&edgeLo[0][0]);
-	uint32_t* edgeHiK = reinterpret_cast<uint32_t*> (&edgeHi[0][0]);
-	if (lane == 0)  { for (int t=0 ; t<HH ; t++) edgeLoK[wave*HH + t] = k[HH + t]; }
-	if (lane == 63) { for (int t=0 ; t<HH ; t++) edgeHiK[wave*HH + t] = k[HN_G + t]; }
+	if (lane == 0)  { for (int t=0 ; t<HH ; t++) padW (PAD_ELO + wave*HH + t) = k[HH + t]; }
+	if (lane == 63) { for (int t=0 ; t<HH ; t++) padW (PAD_EHI + wave*HH + t) = k[HN_G + t]; }
 #pragma unroll
 	for (int t=0 ; t<HH ; t++)
 		{
 		k[t]             = (uint32_t) __shfl_up   ((int) k[HN_G + t], 1, 64);          // the previous block's last HH words
 		k[HN_G + HH + t] = (uint32_t) __shfl_down ((int) k[HH + t],   1, 64);          // the next block's first HH
 		}
-	__syncthreads ();
+	__syncthreads ();                                              // B1: nobody reads the block totals any more
+	if (!PROBE && (p < W)) tapsLds[p] = d_taps[p];                 // (on the totals; read after the next barrier)
 #pragma unroll
 	for (int t=0 ; t<HH ; t++)
 		{
-		if (lane == 0)  k[t]             = (wave == 0)?    away : edgeHiK[(wave-1)*HH + t];
-		if (lane == 63) k[HN_G + HH + t] = (wave == NW-1)? away : edgeLoK[(wave+1)*HH + t];
+		if (lane == 0)  k[t]             = (wave == 0)?    away : padW (PAD_EHI + (wave-1)*HH + t);
+		if (lane == 63) k[HN_G + HH + t] = (wave == NW-1)? away : padW (PAD_ELO + (wave+1)*HH + t);
 		}
 	uint32_t flagsAll = 0;
 #pragma unroll
-	for (int w=0 ; w<NW ; w++) flagsAll |= stats[w][1];
+	for (int w=0 ; w<NW ; w++) flagsAll |= padW (PAD_STATS + w);
 	if (flagsAll & 2u) direct = true;
 	const bool nonneg = ((flagsAll & 1u) == 0);
 
@@ -242,8 +260,8 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 				{
 				unsigned long long w0 = 0, w1 = 0;
 #pragma unroll
-				for (int j=0 ; j<4 ; j++) { w0 |= (unsigned long long) chgBits[p - 7 + j] << (16*j);  w1 |= (unsigned long long) chgBits[p - 3 + j] << (16*j); }
-				unsigned long long w2 = (p + 1 < HN_THREADS)? chgBits[p + 1] : 0xFFFFull;
+				for (int j=0 ; j<4 ; j++) { w0 |= (unsigned long long) chgBitsAt (p - 7 + j) << (16*j);  w1 |= (unsigned long long) chgBitsAt (p - 3 + j) << (16*j); }
+				unsigned long long w2 = (p + 1 < HN_THREADS)? chgBitsAt (p + 1) : 0xFFFFull;
 				// (the probe only counts: where changes are dense it does not look further.  The filter must: a base's leader is
 				//  found through what its neighbours' threads conclude from the same bits, so every thread concludes exactly)
 				if (!PROBE || (__popcll (w0) + __popcll (w1) + __popcll (w2) <= 8))
@@ -317,10 +335,10 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 		for (int u=0 ; u<HN_G ; u++) amax = fmax (amax, fabs (xb[u]));
 		for (int off=32 ; off>0 ; off>>=1) amax = fmax (amax, __shfl_xor (amax, off, 64));
 		__syncthreads ();                                          // (the edge words have been read)
-		if (lane == 0) edgeLo[wave][0] = amax;
+		if (lane == 0) padD (PAD_ELO + wave*HH) = amax;
 		__syncthreads ();
 		amax = 0.0;
-		for (int w=0 ; w<NW ; w++) amax = fmax (amax, edgeLo[w][0]);
+		for (int w=0 ; w<NW ; w++) amax = fmax (amax, padD (PAD_ELO + w*HH));
 		__syncthreads ();
 		}
 	const double epsAbs = KAPPA * amax;
@@ -336,8 +354,8 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 		const bool inside = live && (c >= validLo) && (c < validHi);
 		v[HH + u] = !inside? never : (acc[u] == 0.0)? 0.0 : acc[u];
 		}
-	if (lane == 0)  { for (int t=0 ; t<HH ; t++) edgeLo[wave][t] = v[HH + t]; }
-	if (lane == 63) { for (int t=0 ; t<HH ; t++) edgeHi[wave][t] = v[HN_G + t]; }
+	if (lane == 0)  { for (int t=0 ; t<HH ; t++) padD (PAD_ELO + wave*HH + t) = v[HH + t]; }
+	if (lane == 63) { for (int t=0 ; t<HH ; t++) padD (PAD_EHI + wave*HH + t) = v[HN_G + t]; }
 #pragma unroll
 	for (int t=0 ; t<HH ; t++)
 		{
@@ -348,8 +366,8 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 #pragma unroll
 	for (int t=0 ; t<HH ; t++)
 		{
-		if (lane == 0)  v[t]             = (wave == 0)?    never : edgeHi[wave-1][t];
-		if (lane == 63) v[HN_G + HH + t] = (wave == NW-1)? never : edgeLo[wave+1][t];
+		if (lane == 0)  v[t]             = (wave == 0)?    never : padD (PAD_EHI + (wave-1)*HH + t);
+		if (lane == 63) v[HN_G + HH + t] = (wave == NW-1)? never : padD (PAD_ELO + (wave+1)*HH + t);
 		}
 
 	// ---- the interval test
@@ -484,7 +502,7 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 			}
 		leadIncl = (cwLead != 0)? blk : -1;
 		for (int d=1 ; d<64 ; d*=2) { const int up = __shfl_up (leadIncl, d, 64);  if (lane >= d) leadIncl = max (leadIncl, up); }
-		if (lane == 63) waveLead[wave] = leadIncl;
+		if (lane == 63) padW (PAD_WLEAD + wave) = (uint32_t) leadIncl;
 		int flat = __popc (cwFlat);
 		for (int off=32 ; off>0 ; off>>=1) flat += __shfl_xor (flat, off, 64);
 		if ((lane == 0) && (flat != 0)) atomicAdd (&nflat, (uint32_t) flat);
@@ -560,7 +578,7 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 		if (cwFlat != 0)
 			{
 			int lb = leadIncl;
-			for (int w=0 ; w<wave ; w++) lb = max (lb, waveLead[w]);
+			for (int w=0 ; w<wave ; w++) lb = max (lb, (int) padW (PAD_WLEAD + w));
 			const double T = blockT[(lb >= 0)? lb : 0];               // (lb >= 0: a flat base's run has a leader at or before it)
 			uint32_t word = cwFlat;
 			while (word != 0)
@@ -609,7 +627,7 @@ void peaks_probe_kernel (GdspBatch B, HannConsts<W, PK_E> K, GdspPeaksCtl* ctl)
 // grid over them; M: each one's number in the whole table (control words) and its first tile there (strips, counts, lists).
 struct PeaksSub { uint32_t v[GDSP_BATCH_MAX], gt0[GDSP_BATCH_MAX]; };
 template <int W, bool FMA, bool MAX, int HH, bool CWM>
-__global__ __launch_bounds__(HN_THREADS) __attribute__((amdgpu_waves_per_eu(3)))     // three workgroups per CU, like hann_blocks_kernel
+__global__ __launch_bounds__(HN_THREADS) __attribute__((amdgpu_waves_per_eu(PK_WAVES, PK_WAVES)))
 void peaks_filter_kernel (GdspBatch S, PeaksSub M, HannConsts<W, PK_E> K, const double* __restrict__ d_taps, double fill, GdspPeaksCtl* ctl,
                           uint16_t* strips, uint32_t* counts, uint32_t cap, uint32_t* tileList)
 	{

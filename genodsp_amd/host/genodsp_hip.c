@@ -835,6 +835,15 @@ static int pipeline_wants_partners (void)
 	return false;
 	}
 
+/* a complaint about the input ends the run (exit) while the helper thread may still be inside the HIP runtime, whose own
+ * exit handlers would then tear down what that thread is using: this handler, registered after the runtime's and therefore
+ * run before them, lets the helper finish first (when it is the helper itself that gives up -- no GPU -- there is nobody
+ * to wait for) */
+static void join_allocation_at_exit (void)
+	{
+	if (allocThreaded && !pthread_equal (pthread_self (), allocThread)) { pthread_join (allocThread, NULL);  allocThreaded = false; }
+	}
+
 /* start the allocation; beside the parse of stdin unless the progress lines are wanted in the reference's order */
 static void allocate_vectors (void)
 	{
@@ -842,6 +851,8 @@ static void allocate_vectors (void)
 	const char* e = getenv ("GDSP_ALLOC_THREAD");
 	if (trackOperations || ((e != NULL) && (e[0] == '0')))
 		{ allocate_worker (NULL);  return; }
+	gdsp_version ();                                           /* (the library, and with it the runtime's exit handlers, is loaded by now) */
+	atexit (join_allocation_at_exit);
 	if (pthread_create (&allocThread, NULL, allocate_worker, NULL) != 0)
 		{ allocate_worker (NULL);  return; }
 	allocThreaded = true;
@@ -2095,4 +2106,15 @@ int main (int argc, char** argv)
 		{ next = op->next;  free (op->name);  (*op->funcFree) (op); }
 	if (deviceComm != NULL) { gdsp_percentiles_use_comm (NULL);  gdsp_comm_destroy (deviceComm); }
 	return EXIT_SUCCESS;
+	}
+
+/* every exit() of the host sources arrives here (-Dexit=gdsp_exit, host/Makefile): a complaint about the input may end
+ * the run while the allocation helper thread is still inside the HIP runtime, and exit() runs the runtime's handlers
+ * under it.  Let it finish first (the helper itself -- no GPU visible -- has nobody to wait for). */
+#undef exit
+extern void exit (int status) __attribute__((noreturn));
+void gdsp_exit (int status)
+	{
+	join_allocation_at_exit ();
+	exit (status);
 	}
