@@ -171,8 +171,15 @@ static inline void gdsp_batch_make (GdspBatch& B, const gdsp_batch_item* items, 
 // kernel instead -- decided on the device, the same way by every block of every launch.
 struct GdspPeaksCtl { uint32_t count, overflow, probe, sampled, flat; };   // flat: bases of the probed tiles that would be written their run's value (gdsp_peaks.hip, CWM)
 #define GDSP_PEAKS_DIRECT_NUM 3u
-__device__ __forceinline__ bool gdsp_peaks_takes_direct (const GdspPeaksCtl& c) { return (uint64_t) c.probe * 256u > (uint64_t) c.sampled * GDSP_PEAKS_DIRECT_NUM; }
-__device__ __forceinline__ bool gdsp_peaks_is_flat (const GdspPeaksCtl& c) { return (uint64_t) c.flat * 32u > (uint64_t) c.sampled; }   // more than an eighth of the probed bases (sampled counts quarter bases)
+// (host and device decide by the same rule.  flat: more than an eighth of the probed bases would be written their run's
+//  value -- sampled counts quarter bases -- and the vector takes the filter's form for flat stretches; in a vector that is
+//  not flat those bases tie and are queued like any undecided base, four quarter bases each, so they count here)
+__host__ __device__ __forceinline__ bool gdsp_peaks_flat_form (const GdspPeaksCtl& c) { return (uint64_t) c.flat * 32u > (uint64_t) c.sampled; }
+__host__ __device__ __forceinline__ bool gdsp_peaks_takes_direct (const GdspPeaksCtl& c)
+	{
+	const uint64_t open = (uint64_t) c.probe + (gdsp_peaks_flat_form (c)? 0u : 4u * (uint64_t) c.flat);
+	return open * 256u > (uint64_t) c.sampled * GDSP_PEAKS_DIRECT_NUM;
+	}
 
 // gdsp_fir.hip: the direct fused kernel over a table of vectors, gated: a block works only when its vector takes the direct
 // route (probe) or its queue overflowed

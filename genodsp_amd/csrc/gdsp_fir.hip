@@ -588,7 +588,9 @@ extern "C" int gdsp_smooth_batch (const gdsp_batch_item* items, int nitems, uint
 	auto tilesOf = [] (uint32_t n) { return ((uint64_t) n + T - 1) / T; };
 	uint64_t total = 0;
 	for (int i=0 ; i<nitems ; i++) total += items[i].n;
-	if ((W == 101) && (mode == GDSP_FIR_EXACT) && gdsp_fir_slide_wanted (total))
+	bool aligned = true;                                           // (the slide forms load and store 16 bytes a lane; stretches of --sharding=bases may start on 8)
+	for (int i=0 ; i<nitems ; i++) aligned = aligned && gdsp_aligned16 (items[i].d_in) && gdsp_aligned16 (items[i].d_out);
+	if ((W == 101) && (mode == GDSP_FIR_EXACT) && aligned && gdsp_fir_slide_wanted (total))
 		return gdsp_fir_slide_batch (items, nitems, plan->h_taps, stream);
 	if (W == 101)
 		{

@@ -220,6 +220,10 @@ __device__ __forceinline__ void fs2_strip (const double* __restrict__ in, double
 			}
 		};
 	fetch (0, 0);
+	// The LDS-DMA loads land in LDS behind this wave's vmcnt: the OTHER wave reads those slots after the barrier, and a
+	// workgroup barrier does not wait for one wave's outstanding loads on another's behalf -- the issuing wave drains them
+	// itself before it joins (here and before the barrier that publishes block b+1, below)
+	__builtin_amdgcn_s_waitcnt (0x0f70);                           // vmcnt(0), the other counters left alone (gfx9 encoding)
 	__syncthreads ();                                              // (the taps too)
 	if (NB > 1) fetch (1, 1);
 	for (int b=0 ; b<NB ; b++)
@@ -240,6 +244,7 @@ __device__ __forceinline__ void fs2_strip (const double* __restrict__ in, double
 		for (int a=0 ; a<FS_NA - FS_B/2 ; a++) acc[a] = acc[a + FS_B/2];
 #pragma unroll
 		for (int a=FS_NA - FS_B/2 ; a<FS_NA ; a++) acc[a] = 0.0;
+		__builtin_amdgcn_s_waitcnt (0x0f70);                       // vmcnt(0): this wave's half of block b+1 has landed (see above)
 		__syncthreads ();                                          // block b's inputs are consumed and its outputs paired; block b+1's inputs have landed
 		if (b + 2 < NB) fetch (b + 2, buf);
 #pragma unroll

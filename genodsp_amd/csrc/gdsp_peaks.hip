@@ -821,8 +821,12 @@ static int peaks_launch (const gdsp_batch_item* items, int count, const HannCons
 		for (int v=0 ; v<count ; v++)
 			{
 			const GdspPeaksCtl& c = h_ctl[v];
-			const bool direct = flatForm && ((uint64_t) c.probe * 256u > (uint64_t) c.sampled * GDSP_PEAKS_DIRECT_NUM);    // (gdsp_peaks_takes_direct)
-			const bool flat   = flatForm && ((uint64_t) c.flat * 32u > (uint64_t) c.sampled);                              // (gdsp_peaks_is_flat)
+			// the rule of gdsp_common.h, which the kernels behind apply to the same words: a vector of flat stretches takes the
+			// CWM form; in any other the bases that would have been written their run's value tie and are queued, and count
+			// towards the direct kernel's threshold (sparse read depth with a few per cent of them would otherwise overflow its
+			// strips in the filter and run the direct kernel as well)
+			const bool flat   = flatForm && gdsp_peaks_flat_form (c);
+			const bool direct = flatForm && gdsp_peaks_takes_direct (c);
 			if (direct || (flat != (form == 1))) continue;
 			M.v[sub.size ()] = (uint32_t) v;  M.gt0[sub.size ()] = B.tile0[v];
 			sub.push_back (items[v]);

@@ -710,6 +710,194 @@ void cumsum_apply_kernel (double* __restrict__ v, uint32_t n, uint32_t nchunks, 
 // flight at 32 MiB -- two groups.  An order-free sum (the chunk totals kept exactly, in a wide fixed-point word, so
 // that any look-back grouping rounds to the same double) is the form that could still work; not built.)
 
+// ---------------------------------------------------- cumulative sum, one pass ----
+// Round 5.  What sank the three earlier single-pass forms (above) was (a) a SERIAL chain -- a group's running sum handed
+// from group to group, one hop of ~20 us under load per hop -- and (b) the chunk waiting for its prefix in LDS, which
+// caps what the chip holds in flight at 32 MiB.  This form has neither:
+//   * no chain.  Chunk c = (a, b, j) (4096 chunks of 4096 bases per super-group a, 64 per group b) needs
+//         prefix(c) = sum of S[a' < a]  +  sum of G[a][b' < b]  +  sum of T[a][b][j' < j]
+//     T = a chunk's own total, G = a group's, S = a super-group's.  Every chunk publishes T as soon as it has it; the
+//     LAST chunk of a group, which reads the other 63 totals anyway, publishes G, the last chunk of a super-group S.  A
+//     chunk's wait is therefore at most three hops deep whatever its place in the vector, and one in 63 cases of 64.
+//   * the association is FIXED: each of the three sums is a butterfly over the 64 lanes that fetched its terms (absent
+//     terms are +0), the three are added in one order, and a chunk's own scan is in registers in one order -- the bits do
+//     not depend on timing, run to run, and on exactly summable vectors (read depth) they are the reference's.
+//   * the chunk waits in REGISTERS (16 values a thread, loaded 16 bytes a lane, coalesced): 47 registers -> eight
+//     workgroups per CU, 64 MiB in flight chip-wide, and LDS holds 40 words.
+// A published word is value and flag at once (one 8-byte store / load at agent scope, no fence): the work area is filled
+// with the one bit pattern no total can take (an all-ones NaN; a total that comes out as exactly that is published as the
+// default NaN).  Workgroups take chunks in launch order -- the dispatcher hands them out in that order, so whatever a
+// chunk waits for was dispatched before it: no ticket counter (4.3 ms by itself in round 3).
+// 16 B/base moved (24 in the three launches above).
+#define CL_THREADS 256
+#define CL_CHUNK   4096
+#define CL_ROWS    (CL_CHUNK / (2 * CL_THREADS))          // 8 rows of 512 elements: thread t holds elements 512 u + 2 t, + 1
+#define CL_GROUP   64
+#define CL_SUPER   (CL_GROUP * CL_GROUP)
+#define CL_SENTINEL 0xFFFFFFFFFFFFFFFFull
+
+__device__ __forceinline__ void cl_publish (unsigned long long* slot, double v)
+	{
+	unsigned long long w = (unsigned long long) __double_as_longlong (v);
+	if (w == CL_SENTINEL) w = 0x7FF8000000000000ull;             // (a NaN either way; its payload is nobody's promise)
+	__hip_atomic_store (slot, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+
+// x of the lane a DPP control names; +0 where that lane does not exist or the destination lane is masked off.  Controls
+// (gfx9 encoding): 0x110 + n = row_shr:n (rows of 16 lanes), 0x142 / 0x143 = row_bcast:15 / :31, 0x138 = wave_shr:1
+template <int CTRL, int ROWS, int BANKS>
+__device__ __forceinline__ double cl_dpp_move0 (double x)
+	{
+	const int lo = __builtin_amdgcn_update_dpp (0, __double2loint (x), CTRL, ROWS, BANKS, true);
+	const int hi = __builtin_amdgcn_update_dpp (0, __double2hiint (x), CTRL, ROWS, BANKS, true);
+	return __hiloint2double (hi, lo);
+	}
+
+// inclusive sum over the 64 lanes in one fixed order: inside rows of 16 by doubling, then row 0 -> 1 and 2 -> 3, then 0..1 -> 2..3
+__device__ __forceinline__ double cl_wave_scan (double x)
+	{
+	x += cl_dpp_move0<0x111, 0xF, 0xF> (x);
+	x += cl_dpp_move0<0x112, 0xF, 0xF> (x);
+	x += cl_dpp_move0<0x114, 0xF, 0xF> (x);
+	x += cl_dpp_move0<0x118, 0xF, 0xF> (x);
+	x += cl_dpp_move0<0x142, 0xA, 0xF> (x);
+	x += cl_dpp_move0<0x143, 0xC, 0xF> (x);
+	return x;
+	}
+
+// the sum of slots[0 .. count) once every one of them has been published, count <= 64: lane i fetches slot i
+__device__ __forceinline__ double cl_gather (const unsigned long long* slots, int count, int lane)
+	{
+	unsigned long long w = 0;                                    // +0.0
+	if (lane < count)
+		{
+		for (;;)
+			{
+			w = __hip_atomic_load (slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (w != CL_SENTINEL) break;
+			__builtin_amdgcn_s_sleep (2);
+			}
+		}
+	double x = __longlong_as_double ((long long) w);
+	for (int off=32 ; off>0 ; off>>=1) x += __shfl_xor (x, off, 64);
+	return x;
+	}
+
+// WHOLE: every chunk of the grid is whole (the launch over the vector's n / 4096 whole chunks); the ragged last chunk, if
+// any, is a second launch of one workgroup (chunk0 = its number): its terms are all published by then
+#ifndef CL_WAVES
+#define CL_WAVES 6                                           // workgroups per CU: 76 registers without a spill
+#endif
+template <bool WHOLE>
+__global__ __launch_bounds__(CL_THREADS) __attribute__((amdgpu_waves_per_eu(CL_WAVES)))
+void cumsum_lookback_kernel (double* __restrict__ v, uint32_t n, uint32_t chunk0, unsigned long long* __restrict__ T,
+                             unsigned long long* __restrict__ G, unsigned long long* __restrict__ S)
+	{
+	__shared__ double waveTot[CL_ROWS][CL_THREADS/64];
+	__shared__ double part[4];                                   // sums of T, G, S terms; the chunk's own total
+	const uint32_t c = chunk0 + blockIdx.x;
+	const int      t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	const uint64_t s0 = (uint64_t) c * CL_CHUNK;
+	constexpr bool whole = WHOLE;
+
+	// ---- the chunk: 8 x 16 bytes per lane, coalesced
+	double2 x[CL_ROWS];
+	if (whole)
+		{
+		const double2* src = reinterpret_cast<const double2*> (v + s0);
+#pragma unroll
+		for (int u=0 ; u<CL_ROWS ; u++) x[u] = gdsp_ld2 (&src[u*CL_THREADS + t]);
+		}
+	else
+		{
+#pragma unroll
+		for (int u=0 ; u<CL_ROWS ; u++)
+			{
+			const uint64_t e = s0 + 2 * (uint64_t) (u*CL_THREADS + t);
+			x[u].x = (e     < n)? v[e]     : 0.0;
+			x[u].y = (e + 1 < n)? v[e + 1] : 0.0;
+			}
+		}
+
+	// ---- scan inside each row: pairs, then lanes (exclusive of the own pair), by DPP moves -- no LDS round trips
+	double before[CL_ROWS];                                      // sum of the row's elements before this thread's pair, own wave only
+#pragma unroll
+	for (int u=0 ; u<CL_ROWS ; u++)
+		{
+		const double incl = cl_wave_scan (x[u].x + x[u].y);
+		before[u] = cl_dpp_move0<0x138, 0xF, 0xF> (incl);           // wave_shr:1: the lane before's inclusive sum, +0 for lane 0
+		if (lane == 63) waveTot[u][wave] = incl;
+		}
+	__syncthreads ();
+	// ---- the 32 (row, wave) totals in order: one scan over 32 lanes of wave 0; its last lane has the chunk's total and
+	//      publishes it; then the three gathers, a wave each
+	const uint32_t j = c % CL_GROUP, b = (c / CL_GROUP) % CL_GROUP, a = c / CL_SUPER;
+	double* const flat = &waveTot[0][0];
+	if (wave == 0)
+		{
+		const double mine  = (lane < CL_ROWS * (CL_THREADS/64))? flat[lane] : 0.0;
+		const double incl  = cl_wave_scan (mine);
+		const double excl  = cl_dpp_move0<0x138, 0xF, 0xF> (incl);
+		const double total = __shfl (incl, CL_ROWS * (CL_THREADS/64) - 1, 64);
+		if (lane < CL_ROWS * (CL_THREADS/64)) flat[lane] = excl;   // (every lane has read its own word)
+		if (lane == 0) { cl_publish (&T[c], total);  part[3] = total; }
+		const double sumT = cl_gather (T + (c - j), (int) j, lane);
+		if ((j == CL_GROUP - 1) && (lane == 0)) cl_publish (&G[c / CL_GROUP], sumT + total);
+		if (lane == 0) part[0] = sumT;
+		}
+	else if (wave == 1)
+		{
+		const double sumG = cl_gather (G + (size_t) a * CL_GROUP, (int) b, lane);
+		if (lane == 0) part[1] = sumG;
+		}
+	else if (wave == 2)
+		{
+		double sumS = 0.0;
+		for (uint32_t a0=0 ; a0<a ; a0+=64)                      // (more than 64 super-groups: a vector beyond 2^30 bases)
+			sumS += cl_gather (S + a0, (int) ((a - a0 < 64)? a - a0 : 64), lane);
+		if (lane == 0) part[2] = sumS;
+		}
+	__syncthreads ();
+	const double sumT = part[0], sumG = part[1], sumS = part[2];
+	if ((t == 0) && (j == CL_GROUP - 1) && (b == CL_GROUP - 1)) cl_publish (&S[a], sumG + (sumT + part[3]));
+#pragma unroll
+	for (int u=0 ; u<CL_ROWS ; u++) before[u] = waveTot[u][wave] + before[u];
+	const double prefix = (sumS + sumG) + sumT;
+
+	// ---- the chunk's values
+	if (whole)
+		{
+		double2* dst = reinterpret_cast<double2*> (v + s0);
+#pragma unroll
+		for (int u=0 ; u<CL_ROWS ; u++)
+			{
+			const double base = prefix + before[u];
+			double2 o;
+			o.x = base + x[u].x;
+			o.y = o.x + x[u].y;
+			gdsp_st2 (&dst[u*CL_THREADS + t], o);
+			}
+		}
+	else
+		{
+#pragma unroll
+		for (int u=0 ; u<CL_ROWS ; u++)
+			{
+			const uint64_t e = s0 + 2 * (uint64_t) (u*CL_THREADS + t);
+			const double base = prefix + before[u];
+			const double o0 = base + x[u].x;
+			if (e     < n) v[e]     = o0;
+			if (e + 1 < n) v[e + 1] = o0 + x[u].y;
+			}
+		}
+	}
+
+static size_t cl_work_words (uint32_t n)
+	{
+	const size_t nchunks = ((size_t) n + CL_CHUNK - 1) / CL_CHUNK;
+	return nchunks + (nchunks + CL_GROUP - 1) / CL_GROUP + (nchunks + CL_SUPER - 1) / CL_SUPER + 8;
+	}
+
 // one flag per window for the two passes above, kept per (device, stream): calls on one stream follow one another,
 // calls on different streams must not share them
 struct WsFlags { int device;  void* stream;  size_t nwin;  unsigned char* d_done; };
@@ -824,7 +1012,10 @@ int gdsp_window_sum (double* d_v, uint32_t n, uint32_t W, double denom, int useA
 	}
 
 size_t gdsp_cumulative_sum_work (uint32_t n)
-	{ return ((((size_t) n + CS_CHUNK - 1) / CS_CHUNK) + 1) * sizeof(double); }
+	{
+	const size_t three = ((((size_t) n + CS_CHUNK - 1) / CS_CHUNK) + 1) * sizeof(double), one = cl_work_words (n) * sizeof(double);
+	return (one > three)? one : three;
+	}
 
 int gdsp_cumulative_sum (double* d_v, uint32_t n, void* d_work, void* stream)
 	{
@@ -834,6 +1025,22 @@ int gdsp_cumulative_sum (double* d_v, uint32_t n, void* d_work, void* stream)
 	double*        totals  = (double*) d_work;
 	hipStream_t    s       = gdsp_stream (stream);
 	GDSP_REQUIRE (gdsp_aligned16 (d_v), "vector must be 16-byte aligned");
+	// GDSP_CUMSUM=3: the three launches (rounds 1-4; A/B); default: one pass with a three-level look-back
+	static int passes = 0;
+	if (passes == 0) { const char* e = getenv ("GDSP_CUMSUM");  passes = ((e != NULL) && (e[0] == '3'))? 3 : 1; }
+	if (passes == 1)
+		{
+		const uint32_t nch = (uint32_t) (((uint64_t) n + CL_CHUNK - 1) / CL_CHUNK);
+		unsigned long long* T = (unsigned long long*) d_work;
+		unsigned long long* G = T + nch;
+		unsigned long long* S = G + (nch + CL_GROUP - 1) / CL_GROUP;
+		GDSP_HIP_TRY (hipMemsetAsync (d_work, 0xFF, cl_work_words (n) * sizeof(double), s));
+		const uint32_t nwhole = n / CL_CHUNK;
+		if (nwhole != 0) hipLaunchKernelGGL (cumsum_lookback_kernel<true>, dim3(nwhole), dim3(CL_THREADS), 0, s, d_v, n, 0u, T, G, S);
+		if (nwhole != nch) hipLaunchKernelGGL (cumsum_lookback_kernel<false>, dim3(1), dim3(CL_THREADS), 0, s, d_v, n, nwhole, T, G, S);
+		GDSP_LAUNCH_CHECK ();
+		return GDSP_OK;
+		}
 	hipLaunchKernelGGL (cumsum_totals_kernel,  dim3(nchunks), dim3(SU_THREADS), 0, s, d_v, n, nchunks, totals);
 	hipLaunchKernelGGL (cumsum_offsets_kernel, dim3(1),       dim3(CO_THREADS), 0, s, totals, nchunks);
 	hipLaunchKernelGGL (cumsum_apply_kernel,   dim3(nchunks), dim3(SU_THREADS), 0, s, d_v, n, nchunks, totals);
