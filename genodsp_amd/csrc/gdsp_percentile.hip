@@ -2147,7 +2147,7 @@ static int pc_resident (PcJob& J, const uint32_t* pThousandths, int np, uint32_t
 		}
 
 	// the counting pass reads its pivots (and the fused binarize its bracket) from R
-	const bool bounded = !((J.lo <= -DBL_MAX) && (J.hi >= DBL_MAX));
+	const bool bounded = !((J.lo == -DBL_MAX) && (J.hi == DBL_MAX));     // (hi = +inf keeps the +inf values: not the defaults)
 	PcPivots none;
 	memset (&none, 0, sizeof(none));
 	uint64_t padded = 0;
@@ -2309,6 +2309,10 @@ static int pc_run (const gdsp_select_source* sources, int nsources, uint32_t win
 	const bool defaultTarget = (sampleTarget == 0);
 	if (defaultTarget) sampleTarget = PC_SAMPLE_TARGET;
 	if (!(lo <= hi)) strategy = GDSP_SELECT_RADIX;                // only NaNs can pass such a filter: no brackets
+	// a lower bound of -infinity lets the -inf values in (percentile.c:559-561: !(v < lo)), and -inf is what the counting
+	// pass reads past the end of a vector: such a call -- the C ABI only; the command line spells infinity DBL_MAX --
+	// takes the plain route, whose passes filter value by value (round 5: the bracket route counted the padding in)
+	if (lo < -DBL_MAX) strategy = GDSP_SELECT_RADIX;
 
 	memset (pcStats, 0, sizeof(pcStats));
 	int homeDevice = 0;
@@ -2494,7 +2498,7 @@ static int pc_run (const gdsp_select_source* sources, int nsources, uint32_t win
 		}
 
 	// ---- 3. the counting pass (bounds as far out as the defaults only keep the infinities away)
-	const bool bounded = !((lo <= -DBL_MAX) && (hi >= DBL_MAX));
+	const bool bounded = !((lo == -DBL_MAX) && (hi == DBL_MAX));         // (hi = +inf keeps the +inf values: not the defaults)
 	// a fused binarize rests on the bracket of ITS percentile: a NaN end cannot be compared, an open end decides nothing
 	bool fuseUsable = false;
 	int  fuseJLo = -1, fuseJHi = -1;

@@ -769,6 +769,9 @@ __device__ __forceinline__ double cl_wave_scan (double x)
 __device__ __forceinline__ double cl_gather (const unsigned long long* slots, int count, int lane)
 	{
 	unsigned long long w = 0;                                    // +0.0
+#ifdef CL_NOWAIT                                                 // (timing experiment: wrong sums, no waits)
+	count = 0;
+#endif
 	if (lane < count)
 		{
 		for (;;)
