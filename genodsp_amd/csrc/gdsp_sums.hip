@@ -786,19 +786,6 @@ __device__ __forceinline__ double cl_gather (const unsigned long long* slots, in
 	return x;
 	}
 
-// Round 5b: the terms are kept in a tree of radix 16, and the first chunk of every group of 16 publishes the prefix in
-// front of its group -- so a chunk fetches at most 15 totals and ONE word more.  (With groups of 64 and every chunk
-// adding up its own 63 group totals and super-group totals, the polls -- uncached 8-byte loads on a few lines that every
-// resident chunk reads -- cost 0.2 ms per 249 Mbp: the pass ran at 0.53 of HBM with them and 0.69 with the waits
-// compiled out, whatever the number of workgroups per CU.)
-//   T[c]            chunk c's total                                   published by chunk c
-//   A[c/16]         the total of 16 chunks                            ... by the last of them, which fetches the others' T anyway
-//   B[c/256], C[c/4096], D[c/65536]   the same one level up each      ... by the last chunk of each
-//   PG[c/16]        everything before group c/16                      ... by the group's first chunk, from D, C, B and A terms
-// Nothing published depends on another chunk's PG: no chain, at most four hops deep at a boundary of 65536 chunks.
-#define CL_R 16
-struct ClTree { unsigned long long *T, *A, *B, *C, *D, *PG; };
-
 // WHOLE: every chunk of the grid is whole (the launch over the vector's n / 4096 whole chunks); the ragged last chunk, if
 // any, is a second launch of one workgroup (chunk0 = its number): its terms are all published by then
 #ifndef CL_WAVES
@@ -806,10 +793,11 @@ struct ClTree { unsigned long long *T, *A, *B, *C, *D, *PG; };
 #endif
 template <bool WHOLE>
 __global__ __launch_bounds__(CL_THREADS) __attribute__((amdgpu_waves_per_eu(CL_WAVES)))
-void cumsum_lookback_kernel (double* __restrict__ v, uint32_t n, uint32_t chunk0, ClTree K)
+void cumsum_lookback_kernel (double* __restrict__ v, uint32_t n, uint32_t chunk0, unsigned long long* __restrict__ T,
+                             unsigned long long* __restrict__ G, unsigned long long* __restrict__ S)
 	{
 	__shared__ double waveTot[CL_ROWS][CL_THREADS/64];
-	__shared__ double part[4];
+	__shared__ double part[4];                                   // sums of T, G, S terms; the chunk's own total
 	const uint32_t c = chunk0 + blockIdx.x;
 	const int      t = threadIdx.x, lane = t & 63, wave = t >> 6;
 	const uint64_t s0 = (uint64_t) c * CL_CHUNK;
@@ -844,9 +832,9 @@ void cumsum_lookback_kernel (double* __restrict__ v, uint32_t n, uint32_t chunk0
 		if (lane == 63) waveTot[u][wave] = incl;
 		}
 	__syncthreads ();
-	// ---- the 32 (row, wave) totals in order: one scan over 32 lanes of wave 0, whose lane 31 has the chunk's total
-	const uint32_t g = c / CL_R, j = c % CL_R;
-	const uint32_t ib = c / (CL_R*CL_R), ic = c / (CL_R*CL_R*CL_R), id = c / (CL_R*CL_R*CL_R*CL_R);
+	// ---- the 32 (row, wave) totals in order: one scan over 32 lanes of wave 0; its last lane has the chunk's total and
+	//      publishes it; then the three gathers, a wave each
+	const uint32_t j = c % CL_GROUP, b = (c / CL_GROUP) % CL_GROUP, a = c / CL_SUPER;
 	double* const flat = &waveTot[0][0];
 	if (wave == 0)
 		{
@@ -855,52 +843,29 @@ void cumsum_lookback_kernel (double* __restrict__ v, uint32_t n, uint32_t chunk0
 		const double excl  = cl_dpp_move0<0x138, 0xF, 0xF> (incl);
 		const double total = __shfl (incl, CL_ROWS * (CL_THREADS/64) - 1, 64);
 		if (lane < CL_ROWS * (CL_THREADS/64)) flat[lane] = excl;   // (every lane has read its own word)
-		if (lane == 0) cl_publish (&K.T[c], total);
-		const double sumT = cl_gather (K.T + (c - j), (int) j, lane);          // the chunks of the group before this one
+		if (lane == 0) { cl_publish (&T[c], total);  part[3] = total; }
+		const double sumT = cl_gather (T + (c - j), (int) j, lane);
+		if ((j == CL_GROUP - 1) && (lane == 0)) cl_publish (&G[c / CL_GROUP], sumT + total);
 		if (lane == 0) part[0] = sumT;
-		if (j == CL_R - 1)                                           // the last of 16 chunks: their total, and so on up
-			{
-			const double va = sumT + total;
-			if (lane == 0) cl_publish (&K.A[g], va);
-			if (g % CL_R == CL_R - 1)
-				{
-				const double vb = cl_gather (K.A + (g - (CL_R - 1)), CL_R - 1, lane) + va;
-				if (lane == 0) cl_publish (&K.B[ib], vb);
-				if (ib % CL_R == CL_R - 1)
-					{
-					const double vc = cl_gather (K.B + (ib - (CL_R - 1)), CL_R - 1, lane) + vb;
-					if (lane == 0) cl_publish (&K.C[ic], vc);
-					if (ic % CL_R == CL_R - 1)
-						{
-						const double vd = cl_gather (K.C + (ic - (CL_R - 1)), CL_R - 1, lane) + vc;
-						if (lane == 0) cl_publish (&K.D[id], vd);
-						}
-					}
-				}
-			}
 		}
-	else if (j != 0)
+	else if (wave == 1)
 		{
-		if (wave == 1) { const double pg = cl_gather (K.PG + g, 1, lane);  if (lane == 0) part[1] = pg; }
+		const double sumG = cl_gather (G + (size_t) a * CL_GROUP, (int) b, lane);
+		if (lane == 0) part[1] = sumG;
 		}
-	else                                                             // the first chunk of a group: what lies before the group
+	else if (wave == 2)
 		{
-		double r;
-		if (wave == 1) r = cl_gather (K.A + (g - g % CL_R), (int) (g % CL_R), lane);
-		if (wave == 2) r = cl_gather (K.B + (ib - ib % CL_R), (int) (ib % CL_R), lane);
-		if (wave == 3) r = cl_gather (K.C + (ic - ic % CL_R), (int) (ic % CL_R), lane) + cl_gather (K.D, (int) id, lane);
-		if (lane == 0) part[wave] = r;
+		double sumS = 0.0;
+		for (uint32_t a0=0 ; a0<a ; a0+=64)                      // (more than 64 super-groups: a vector beyond 2^30 bases)
+			sumS += cl_gather (S + a0, (int) ((a - a0 < 64)? a - a0 : 64), lane);
+		if (lane == 0) part[2] = sumS;
 		}
 	__syncthreads ();
-	double prefix;
-	if (j != 0) prefix = part[1] + part[0];
-	else
-		{
-		prefix = (part[3] + part[2]) + part[1];
-		if (t == 0) cl_publish (&K.PG[g], prefix);
-		}
+	const double sumT = part[0], sumG = part[1], sumS = part[2];
+	if ((t == 0) && (j == CL_GROUP - 1) && (b == CL_GROUP - 1)) cl_publish (&S[a], sumG + (sumT + part[3]));
 #pragma unroll
 	for (int u=0 ; u<CL_ROWS ; u++) before[u] = waveTot[u][wave] + before[u];
+	const double prefix = (sumS + sumG) + sumT;
 
 	// ---- the chunk's values
 	if (whole)
@@ -930,183 +895,10 @@ void cumsum_lookback_kernel (double* __restrict__ v, uint32_t n, uint32_t chunk0
 		}
 	}
 
-// ---- the same look-back with the waiting taken out of the data's way (GDSP_CUMSUM=2).  In the kernel above a chunk
-// sits in registers while its predecessors' totals travel -- and its predecessors are its contemporaries, dispatched a
-// moment before it, so nearly every chunk waits a hop or two and what the chip can hold in flight bounds the rate.  Here
-// every chunk is visited twice, by two workgroups a fixed LAG apart in launch order: a LEADER reads it, adds it up and
-// publishes its total (and its group's, its super-group's: the same three levels), keeping nothing; a FOLLOWER, LAG chunks
-// behind, finds every term it needs long published, reads the chunk again -- out of the Infinity Cache, which the LAG
-// chunks read and written in between (a few tens of MB) do not push it out of -- scans it and writes it.  HBM still moves
-// 16 B/base; the second read stays on the die.
-#ifndef CL_LAG
-#define CL_LAG 1024                                          // chunks between a chunk's two visits (32 MiB of input)
-#endif
-template <bool STREAM>
-__device__ __forceinline__ void cl_load_chunk (const double* __restrict__ v, uint64_t s0, int t, double2 (&x)[CL_ROWS])
-	{
-	const double2* src = reinterpret_cast<const double2*> (v + s0);
-#pragma unroll
-	for (int u=0 ; u<CL_ROWS ; u++) x[u] = STREAM? gdsp_ld2 (&src[u*CL_THREADS + t]) : src[u*CL_THREADS + t];
-	}
-
-__global__ __launch_bounds__(CL_THREADS) __attribute__((amdgpu_waves_per_eu(CL_WAVES)))
-void cumsum_lag_kernel (double* __restrict__ v, uint32_t nwhole, uint32_t lag, unsigned long long* __restrict__ T,
-                        unsigned long long* __restrict__ G, unsigned long long* __restrict__ S)
-	{
-	__shared__ double waveTot[CL_ROWS][CL_THREADS/64];
-	__shared__ double part[4];
-	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-	// position p of the launch -> (role, chunk): `lag` leaders first, then followers and leaders in turn, then the last followers
-	const uint32_t p = blockIdx.x, L = (lag < nwhole)? lag : nwhole;
-	bool leader;  uint32_t c;
-	if (p < L) { leader = true;  c = p; }
-	else
-		{
-		const uint32_t q = p - L, both = 2 * (nwhole - L);
-		if (q < both) { leader = (q & 1) != 0;  c = leader? L + q/2 : q/2; }
-		else          { leader = false;  c = (nwhole - L) + (q - both); }
-		}
-	const uint64_t s0 = (uint64_t) c * CL_CHUNK;
-	const uint32_t j = c % CL_GROUP, b = (c / CL_GROUP) % CL_GROUP, a = c / CL_SUPER;
-	double2 x[CL_ROWS];
-
-	if (leader)
-		{
-		cl_load_chunk<false> (v, s0, t, x);                          // (plain loads: the lines are wanted again)
-		double sum = 0.0;
-#pragma unroll
-		for (int u=0 ; u<CL_ROWS ; u++) sum += x[u].x + x[u].y;
-		const double incl = cl_wave_scan (sum);
-		if (lane == 63) waveTot[0][wave] = incl;
-		__syncthreads ();
-		if (wave != 0) return;
-		const double total = ((waveTot[0][0] + waveTot[0][1]) + waveTot[0][2]) + waveTot[0][3];
-		if (lane == 0) cl_publish (&T[c], total);
-		if (j != CL_GROUP - 1) return;                               // the last chunk of a group adds the group up
-		const double sumT = cl_gather (T + (c - j), (int) j, lane);
-		const double group = sumT + total;
-		if (lane == 0) cl_publish (&G[c / CL_GROUP], group);
-		if (b != CL_GROUP - 1) return;                               // ... of a super-group, the super-group
-		const double sumG = cl_gather (G + (size_t) a * CL_GROUP, (int) b, lane);
-		if (lane == 0) cl_publish (&S[a], sumG + group);
-		return;
-		}
-
-	// ---- follower: terms and chunk fetched together
-	cl_load_chunk<true> (v, s0, t, x);
-	if (wave == 0)      { const double r = cl_gather (T + (c - j), (int) j, lane);  if (lane == 0) part[0] = r; }
-	else if (wave == 1) { const double r = cl_gather (G + (size_t) a * CL_GROUP, (int) b, lane);  if (lane == 0) part[1] = r; }
-	else if (wave == 2)
-		{
-		double sumS = 0.0;
-		for (uint32_t a0=0 ; a0<a ; a0+=64) sumS += cl_gather (S + a0, (int) ((a - a0 < 64)? a - a0 : 64), lane);
-		if (lane == 0) part[2] = sumS;
-		}
-	else (void) cl_gather (T + c, 1, lane);                         // the chunk's own leader has read it: it may be overwritten (in place)
-	double before[CL_ROWS];
-#pragma unroll
-	for (int u=0 ; u<CL_ROWS ; u++)
-		{
-		const double incl = cl_wave_scan (x[u].x + x[u].y);
-		before[u] = cl_dpp_move0<0x138, 0xF, 0xF> (incl);
-		if (lane == 63) waveTot[u][wave] = incl;
-		}
-	__syncthreads ();
-	double* const flat = &waveTot[0][0];
-	if (wave == 3)
-		{
-		const double mine = (lane < CL_ROWS * (CL_THREADS/64))? flat[lane] : 0.0;
-		const double excl = cl_dpp_move0<0x138, 0xF, 0xF> (cl_wave_scan (mine));
-		if (lane < CL_ROWS * (CL_THREADS/64)) flat[lane] = excl;
-		}
-	__syncthreads ();
-	const double prefix = (part[2] + part[1]) + part[0];
-	double2* dst = reinterpret_cast<double2*> (v + s0);
-#pragma unroll
-	for (int u=0 ; u<CL_ROWS ; u++)
-		{
-		const double base = prefix + (waveTot[u][wave] + before[u]);
-		double2 o;
-		o.x = base + x[u].x;
-		o.y = o.x + x[u].y;
-		gdsp_st2 (&dst[u*CL_THREADS + t], o);
-		}
-	}
-
-// the ragged last chunk behind cumsum_lag_kernel: one workgroup, every term published by then
-__global__ __launch_bounds__(CL_THREADS)
-void cumsum_lag_tail_kernel (double* __restrict__ v, uint32_t n, uint32_t c, const unsigned long long* __restrict__ T,
-                             const unsigned long long* __restrict__ G, const unsigned long long* __restrict__ S)
-	{
-	__shared__ double waveTot[CL_ROWS][CL_THREADS/64];
-	__shared__ double part[4];
-	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-	const uint64_t s0 = (uint64_t) c * CL_CHUNK;
-	const uint32_t j = c % CL_GROUP, b = (c / CL_GROUP) % CL_GROUP, a = c / CL_SUPER;
-	double2 x[CL_ROWS];
-#pragma unroll
-	for (int u=0 ; u<CL_ROWS ; u++)
-		{
-		const uint64_t e = s0 + 2 * (uint64_t) (u*CL_THREADS + t);
-		x[u].x = (e     < n)? v[e]     : 0.0;
-		x[u].y = (e + 1 < n)? v[e + 1] : 0.0;
-		}
-	if (wave == 0)      { const double r = cl_gather (T + (c - j), (int) j, lane);  if (lane == 0) part[0] = r; }
-	else if (wave == 1) { const double r = cl_gather (G + (size_t) a * CL_GROUP, (int) b, lane);  if (lane == 0) part[1] = r; }
-	else if (wave == 2)
-		{
-		double sumS = 0.0;
-		for (uint32_t a0=0 ; a0<a ; a0+=64) sumS += cl_gather (S + a0, (int) ((a - a0 < 64)? a - a0 : 64), lane);
-		if (lane == 0) part[2] = sumS;
-		}
-	double before[CL_ROWS];
-#pragma unroll
-	for (int u=0 ; u<CL_ROWS ; u++)
-		{
-		const double incl = cl_wave_scan (x[u].x + x[u].y);
-		before[u] = cl_dpp_move0<0x138, 0xF, 0xF> (incl);
-		if (lane == 63) waveTot[u][wave] = incl;
-		}
-	__syncthreads ();
-	double* const flat = &waveTot[0][0];
-	if (wave == 3)
-		{
-		const double mine = (lane < CL_ROWS * (CL_THREADS/64))? flat[lane] : 0.0;
-		const double excl = cl_dpp_move0<0x138, 0xF, 0xF> (cl_wave_scan (mine));
-		if (lane < CL_ROWS * (CL_THREADS/64)) flat[lane] = excl;
-		}
-	__syncthreads ();
-	const double prefix = (part[2] + part[1]) + part[0];
-#pragma unroll
-	for (int u=0 ; u<CL_ROWS ; u++)
-		{
-		const uint64_t e = s0 + 2 * (uint64_t) (u*CL_THREADS + t);
-		const double o0 = (prefix + (waveTot[u][wave] + before[u])) + x[u].x;
-		if (e     < n) v[e]     = o0;
-		if (e + 1 < n) v[e + 1] = o0 + x[u].y;
-		}
-	}
-
-static size_t cl_level (size_t nchunks, size_t per) { return (nchunks + per - 1) / per + 1; }
 static size_t cl_work_words (uint32_t n)
 	{
 	const size_t nchunks = ((size_t) n + CL_CHUNK - 1) / CL_CHUNK;
-	const size_t tree = nchunks + 2 * cl_level (nchunks, CL_R) + cl_level (nchunks, CL_R*CL_R) + cl_level (nchunks, CL_R*CL_R*CL_R)
-	                  + cl_level (nchunks, CL_R*CL_R*CL_R*CL_R);
-	const size_t lag  = nchunks + cl_level (nchunks, CL_GROUP) + cl_level (nchunks, CL_SUPER);     // (GDSP_CUMSUM=2)
-	return ((tree > lag)? tree : lag) + 8;
-	}
-static ClTree cl_tree (void* d_work, uint32_t n)
-	{
-	const size_t nchunks = ((size_t) n + CL_CHUNK - 1) / CL_CHUNK;
-	ClTree K;
-	K.T  = (unsigned long long*) d_work;
-	K.A  = K.T + nchunks;
-	K.PG = K.A + cl_level (nchunks, CL_R);
-	K.B  = K.PG + cl_level (nchunks, CL_R);
-	K.C  = K.B + cl_level (nchunks, CL_R*CL_R);
-	K.D  = K.C + cl_level (nchunks, CL_R*CL_R*CL_R);
-	return K;
+	return nchunks + (nchunks + CL_GROUP - 1) / CL_GROUP + (nchunks + CL_SUPER - 1) / CL_SUPER + 8;
 	}
 
 // one flag per window for the two passes above, kept per (device, stream): calls on one stream follow one another,
@@ -1238,28 +1030,17 @@ int gdsp_cumulative_sum (double* d_v, uint32_t n, void* d_work, void* stream)
 	GDSP_REQUIRE (gdsp_aligned16 (d_v), "vector must be 16-byte aligned");
 	// GDSP_CUMSUM=3: the three launches (rounds 1-4; A/B); default: one pass with a three-level look-back
 	static int passes = 0;
-	if (passes == 0) { const char* e = getenv ("GDSP_CUMSUM");  passes = ((e != NULL) && (e[0] == '3'))? 3 : ((e != NULL) && (e[0] == '2'))? 2 : 1; }
-	if (passes != 3)
+	if (passes == 0) { const char* e = getenv ("GDSP_CUMSUM");  passes = ((e != NULL) && (e[0] == '3'))? 3 : 1; }
+	if (passes == 1)
 		{
 		const uint32_t nch = (uint32_t) (((uint64_t) n + CL_CHUNK - 1) / CL_CHUNK);
+		unsigned long long* T = (unsigned long long*) d_work;
+		unsigned long long* G = T + nch;
+		unsigned long long* S = G + (nch + CL_GROUP - 1) / CL_GROUP;
 		GDSP_HIP_TRY (hipMemsetAsync (d_work, 0xFF, cl_work_words (n) * sizeof(double), s));
 		const uint32_t nwhole = n / CL_CHUNK;
-		const ClTree K = cl_tree (d_work, n);
-		if ((nwhole != 0) && (passes == 2))
-			{
-			static uint32_t lag = 0;
-			if (lag == 0) { const char* e = getenv ("GDSP_CUMSUM_LAG");  lag = ((e != NULL) && (atoll (e) > 0))? (uint32_t) atoll (e) : CL_LAG; }
-			unsigned long long* T = (unsigned long long*) d_work;
-			unsigned long long* G = T + nch;
-			unsigned long long* S = G + cl_level (nch, CL_GROUP);
-			hipLaunchKernelGGL (cumsum_lag_kernel, dim3(2 * nwhole), dim3(CL_THREADS), 0, s, d_v, nwhole, lag, T, G, S);
-			if (nwhole != nch) hipLaunchKernelGGL (cumsum_lag_tail_kernel, dim3(1), dim3(CL_THREADS), 0, s, d_v, n, nwhole, T, G, S);
-			}
-		else
-			{
-			if (nwhole != 0)   hipLaunchKernelGGL (cumsum_lookback_kernel<true>,  dim3(nwhole), dim3(CL_THREADS), 0, s, d_v, n, 0u, K);
-			if (nwhole != nch) hipLaunchKernelGGL (cumsum_lookback_kernel<false>, dim3(1),      dim3(CL_THREADS), 0, s, d_v, n, nwhole, K);
-			}
+		if (nwhole != 0) hipLaunchKernelGGL (cumsum_lookback_kernel<true>, dim3(nwhole), dim3(CL_THREADS), 0, s, d_v, n, 0u, T, G, S);
+		if (nwhole != nch) hipLaunchKernelGGL (cumsum_lookback_kernel<false>, dim3(1), dim3(CL_THREADS), 0, s, d_v, n, nwhole, T, G, S);
 		GDSP_LAUNCH_CHECK ();
 		return GDSP_OK;
 		}
