@@ -722,13 +722,24 @@ void cumsum_apply_kernel (double* __restrict__ v, uint32_t n, uint32_t nchunks, 
 //   * the association is FIXED: each of the three sums is a butterfly over the 64 lanes that fetched its terms (absent
 //     terms are +0), the three are added in one order, and a chunk's own scan is in registers in one order -- the bits do
 //     not depend on timing, run to run, and on exactly summable vectors (read depth) they are the reference's.
-//   * the chunk waits in REGISTERS (16 values a thread, loaded 16 bytes a lane, coalesced): 47 registers -> eight
-//     workgroups per CU, 64 MiB in flight chip-wide, and LDS holds 40 words.
+//   * the chunk waits in REGISTERS (16 values a thread, loaded 16 bytes a lane, coalesced; its scans are DPP moves, no
+//     LDS round trips): 76 registers -> six workgroups per CU, 48 MiB in flight chip-wide, and LDS holds 36 words.
 // A published word is value and flag at once (one 8-byte store / load at agent scope, no fence): the work area is filled
 // with the one bit pattern no total can take (an all-ones NaN; a total that comes out as exactly that is published as the
 // default NaN).  Workgroups take chunks in launch order -- the dispatcher hands them out in that order, so whatever a
 // chunk waits for was dispatched before it: no ticket counter (4.3 ms by itself in round 3).
 // 16 B/base moved (24 in the three launches above).
+// Measured, 249 Mbp (tools/bench_scan.py, tools/exp_scan.sh; profiles/r05_scan_variants.txt): 0.946 ms = 0.53 of HBM on
+// 16 B/base, read depth and real values alike, against 1.016 ms for the three launches (GDSP_CUMSUM=3 keeps them).  With
+// the waits compiled out (-DCL_NOWAIT: wrong sums) the same kernel takes 0.725 ms (0.69): what the waits cost does not
+// depend on how many workgroups a CU holds (4 or 6: 0.944 / 0.946 ms; 8, with spills, 1.12) -- a chunk's terms come from
+// its contemporaries, which publish when it does, so it waits about one store-to-load round trip behind its own loads,
+// and that trip queues in the same memory pipelines as the stream.  Two forms built to take the wait out of the data's
+// way were slower: a tree of radix 16 in which a group's first chunk publishes the prefix in front of the group (a
+// chunk fetches <= 15 totals and one word: fewer polls, one hop deeper) 0.982 ms; every chunk visited twice by
+// workgroups a fixed lag apart, the first adding it up and publishing, the second -- its terms long there -- reading it
+// again out of the Infinity Cache and writing it: 1.04-1.05 ms at lags of 256 / 1024 / 4096 chunks (the second read
+// costs what the first does).
 #define CL_THREADS 256
 #define CL_CHUNK   4096
 #define CL_ROWS    (CL_CHUNK / (2 * CL_THREADS))          // 8 rows of 512 elements: thread t holds elements 512 u + 2 t, + 1
