@@ -746,6 +746,12 @@ void cumsum_apply_kernel (double* __restrict__ v, uint32_t n, uint32_t nchunks, 
 #define CL_GROUP   64
 #define CL_SUPER   (CL_GROUP * CL_GROUP)
 #define CL_SENTINEL 0xFFFFFFFFFFFFFFFFull
+#ifndef CL_TSTRIDE
+#define CL_TSTRIDE 1                                         // 8-byte words from one chunk's total to the next (32: a 256-byte line each)
+#endif
+#ifndef CL_SLEEP
+#define CL_SLEEP 2                                           // x 64 cycles between two tries of a poll
+#endif
 
 __device__ __forceinline__ void cl_publish (unsigned long long* slot, double v)
 	{
@@ -777,19 +783,29 @@ __device__ __forceinline__ double cl_wave_scan (double x)
 	}
 
 // the sum of slots[0 .. count) once every one of them has been published, count <= 64: lane i fetches slot i
+template <int STRIDE = 1>
 __device__ __forceinline__ double cl_gather (const unsigned long long* slots, int count, int lane)
 	{
 	unsigned long long w = 0;                                    // +0.0
 #ifdef CL_NOWAIT                                                 // (timing experiment: wrong sums, no waits)
 	count = 0;
 #endif
+#ifndef CL_NOSPIN1
+	// the newest term is the last to arrive: ONE lane waits for it (a 64-byte request per try where the 64-lane fetch is
+	// four lines, and every waiting chunk on the chip tries again as soon as its last try has come back), then all fetch
+	if ((count > 0) && (lane == 0))
+		{
+		while (__hip_atomic_load (slots + (size_t) (count - 1) * STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == CL_SENTINEL)
+			__builtin_amdgcn_s_sleep (CL_SLEEP);
+		}
+#endif
 	if (lane < count)
 		{
 		for (;;)
 			{
-			w = __hip_atomic_load (slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			w = __hip_atomic_load (slots + (size_t) lane * STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			if (w != CL_SENTINEL) break;
-			__builtin_amdgcn_s_sleep (2);
+			__builtin_amdgcn_s_sleep (CL_SLEEP);
 			}
 		}
 	double x = __longlong_as_double ((long long) w);
@@ -854,8 +870,8 @@ void cumsum_lookback_kernel (double* __restrict__ v, uint32_t n, uint32_t chunk0
 		const double excl  = cl_dpp_move0<0x138, 0xF, 0xF> (incl);
 		const double total = __shfl (incl, CL_ROWS * (CL_THREADS/64) - 1, 64);
 		if (lane < CL_ROWS * (CL_THREADS/64)) flat[lane] = excl;   // (every lane has read its own word)
-		if (lane == 0) { cl_publish (&T[c], total);  part[3] = total; }
-		const double sumT = cl_gather (T + (c - j), (int) j, lane);
+		if (lane == 0) { cl_publish (&T[(size_t) c * CL_TSTRIDE], total);  part[3] = total; }
+		const double sumT = cl_gather<CL_TSTRIDE> (T + (size_t) (c - j) * CL_TSTRIDE, (int) j, lane);
 		if ((j == CL_GROUP - 1) && (lane == 0)) cl_publish (&G[c / CL_GROUP], sumT + total);
 		if (lane == 0) part[0] = sumT;
 		}
@@ -909,7 +925,7 @@ void cumsum_lookback_kernel (double* __restrict__ v, uint32_t n, uint32_t chunk0
 static size_t cl_work_words (uint32_t n)
 	{
 	const size_t nchunks = ((size_t) n + CL_CHUNK - 1) / CL_CHUNK;
-	return nchunks + (nchunks + CL_GROUP - 1) / CL_GROUP + (nchunks + CL_SUPER - 1) / CL_SUPER + 8;
+	return nchunks * CL_TSTRIDE + (nchunks + CL_GROUP - 1) / CL_GROUP + (nchunks + CL_SUPER - 1) / CL_SUPER + 8;
 	}
 
 // one flag per window for the two passes above, kept per (device, stream): calls on one stream follow one another,
@@ -1046,7 +1062,7 @@ int gdsp_cumulative_sum (double* d_v, uint32_t n, void* d_work, void* stream)
 		{
 		const uint32_t nch = (uint32_t) (((uint64_t) n + CL_CHUNK - 1) / CL_CHUNK);
 		unsigned long long* T = (unsigned long long*) d_work;
-		unsigned long long* G = T + nch;
+		unsigned long long* G = T + (size_t) nch * CL_TSTRIDE;
 		unsigned long long* S = G + (nch + CL_GROUP - 1) / CL_GROUP;
 		GDSP_HIP_TRY (hipMemsetAsync (d_work, 0xFF, cl_work_words (n) * sizeof(double), s));
 		const uint32_t nwhole = n / CL_CHUNK;

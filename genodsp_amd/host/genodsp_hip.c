@@ -1678,6 +1678,9 @@ static void report_gpu_times (void)
 	fprintf (stderr, "[%s] --report=gpu: %d device%s (%s); event = HIP-event ms summed over a step's calls on the slowest device,\n"
 	                 "  wall = host clock with the devices drained (steps that mix host and device work)\n",
 	         programName, numDevices, (numDevices == 1)? "" : "s", gdsp_version ());
+	if (!batchLaunches)
+		fprintf (stderr, "  launches: one per operator and chromosome%s; --batch gives one per operator and device\n",
+		         trackOperations? " (--progress=operations keeps the reference's order)" : " (--nobatch)");
 	fprintf (stderr, "  %-34s %6s %16s %-9s %10s %5s %10s %9s %6s\n", "step", "calls", "units", "", "ms", "clock", "Gbases/s", "GB/s", "B/base");
 	for (int i=0 ; i<numPhases ; i++)
 		{

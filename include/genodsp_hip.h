@@ -97,7 +97,11 @@ int gdsp_smooth           (const double* d_in, double* d_out, uint32_t n, uint32
 
 /* `= smooth W = localmax|localmin N` in one pass (sum.c:616-676 feeding minmax.c:1183-1227 /
  * :981-1022): the smoothed tile is tested in LDS and only the peaks track is written.
- * Bit-identical to gdsp_smooth followed by gdsp_local_extrema.  Fusable for W=101, N<=129. */
+ * Bit-identical to gdsp_smooth followed by gdsp_local_extrema.  Fusable for W=101, N<=129.
+ * Synchronisation: for W=101 and N<=15 the call takes the filtered route (gdsp_peaks.hip), which reads a probe's counts
+ * back to choose each vector's form: it WAITS for the stream once per table of <= 32 vectors (everything queued on the
+ * stream before it included) and cannot be captured into a graph.  GDSP_PEAKS_FLAT=0 keeps the decision on the device
+ * (no wait; vectors of flat stretches then take the direct kernel), GDSP_PEAKS_FILTER=0 the direct kernel throughout. */
 int gdsp_smooth_local_extrema_fusable (uint32_t W, uint32_t N);
 int gdsp_smooth_local_extrema (const double* d_in, double* d_out, uint32_t n, uint32_t W, int mode,
                                uint32_t N, int wantMax, double fill, void* stream);
