@@ -137,7 +137,6 @@ void pc_sample_tab_kernel (PcSampleTab T, uint32_t window, double lo, double hi,
 #define PC_LS_KEYS    8192                                     // keys one workgroup can sort in LDS (the cell that holds a candidates' rank)
 #define PC_LS_SUB     2048                                     // the strided share of a list a grid is laid on
 #define PC_RES_BINS   (1 << 13)
-#define PC_CHIST      256                                      // cells of the candidates' coarse histogram
 #define PC_RES_SAMPLE 0
 #define PC_RES_CAND   1
 enum { PC_RES_OK = 0, PC_RES_FEW = 1, PC_RES_PIVOTS = 2, PC_RES_DISAGREE = 3, PC_RES_NOFUSE = 4 };
@@ -163,11 +162,6 @@ struct PcResident
 	// its rank lies in, and whether the candidates' answer has been written already
 	uint64_t grid[PC_RES_MAXP][PC_LS_GRID];
 	uint32_t gridN[PC_RES_MAXP], candDone[PC_RES_MAXP];
-	// round 5, one percentile on one device: the counting pass also counts its candidates into PC_CHIST even cells across the
-	// bracket (cell = (key - histLo) >> histShift), so that one launch behind it knows the cell of the rank before it looks at
-	// a candidate (pc_ls_hist_pick_kernel)
-	uint32_t histOn, histShift;
-	uint64_t histLo;
 #ifdef PC_RES_TIMING
 	unsigned long long dbg[2][5][8];
 #endif
@@ -185,13 +179,6 @@ struct PcResHist                                               // behind the PcR
 	};
 struct PcPts { uint32_t v[PC_RES_MAXP];  int n; };
 #define PC_RES_STATE_BYTES ((sizeof(PcResident) + 255) / 256 * 256)
-// the candidates' coarse histogram: in the second half of the slab behind the state (the grids' cell counters use the
-// first few hundred words of the first half); zero between calls like the rest
-__device__ __forceinline__ uint32_t* pc_cand_hist (const PcResident* R)
-	{
-	PcResHist* H = reinterpret_cast<PcResHist*> (reinterpret_cast<char*> (const_cast<PcResident*> (R)) + PC_RES_STATE_BYTES);
-	return &H->slab[0][1][0];
-	}
 
 // FUSE: `= percentile P = binarize --threshold=percentileP` in the same read (logical.c:216-268 behind percentile.c:392-751).
 // The threshold T -- the percentile -- is not known yet, but its bracket [vLo, vHi] is: a value above vHi is above T, a
@@ -220,16 +207,7 @@ void pc_partition_body (const double* __restrict__ v, uint32_t n, uint32_t windo
 	__shared__ uint64_t wbuf[PC_THREADS/64][PC_WAVE_BUF];
 	__shared__ uint32_t wcount[PC_THREADS/64][NC];
 	__shared__ uint32_t ubuf[FUSE? PC_THREADS/64 : 1][FUSE? PC_WAVE_BUF : 1];
-	__shared__ uint32_t chist[PC_CHIST];                       // the candidates this workgroup kept, by cell of the bracket (resident route, one percentile)
 	uint32_t uheld = 0;                                        // undecided positions waiting in this wave's buffer (wave uniform)
-	const bool     histOn   = (res != NULL) && (res->histOn != 0);
-	const uint64_t histLo   = histOn? res->histLo : 0;
-	const uint32_t histShift = histOn? res->histShift : 0;
-	if (histOn)
-		{
-		for (int q=threadIdx.x ; q<PC_CHIST ; q+=PC_THREADS) chist[q] = 0;
-		__syncthreads ();
-		}
 
 	const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const size_t   npop = DENSE? (size_t) n : ((size_t) n + window - 1) / window;
@@ -252,16 +230,7 @@ void pc_partition_body (const double* __restrict__ v, uint32_t n, uint32_t windo
 		unsigned long long base = 0;
 		if (lane == 0) base = atomicAdd (candCount, (unsigned long long) held);
 		base = __shfl (base, 0, 64);
-		for (uint32_t i=lane ; i<held ; i+=64)
-			{
-			const uint64_t key = wbuf[wave][i];
-			if (base + i < cap) cand[base + i] = key;
-			if (histOn)                                            // (a few candidates per thousand values: an LDS atomic each)
-				{
-				const uint64_t cell = (key - histLo) >> histShift;
-				atomicAdd (&chist[(cell < PC_CHIST)? (uint32_t) cell : PC_CHIST - 1], 1u);
-				}
-			}
+		for (uint32_t i=lane ; i<held ; i+=64) { if (base + i < cap) cand[base + i] = wbuf[wave][i]; }
 		held = 0;
 		};
 
@@ -505,11 +474,6 @@ void pc_partition_body (const double* __restrict__ v, uint32_t n, uint32_t windo
 		const int slot = (t == 0)? PC_CTR_GELO : (t == 1)? PC_CTR_GTHI : (t == 2)? PC_CTR_NANPOS : (t == 3)? PC_CTR_NANNEG
 		               : (t == 4)? PC_CTR_NEGINF : (t < 5+M)? PC_CTR_GT + (t-5) : PC_CTR_EQ + (t-5-M);
 		if (c) atomicAdd (ctr + (size_t) (blockIdx.x % PC_REPL) * PC_CTR_WORDS + slot, c);
-		}
-	if (histOn)                                                    // (every flush lies before the barrier above)
-		{
-		uint32_t* cells = pc_cand_hist (res);
-		for (int q=threadIdx.x ; q<PC_CHIST ; q+=PC_THREADS) { if (chist[q]) atomicAdd (&cells[q], chist[q]); }
 		}
 	}
 
@@ -1014,6 +978,14 @@ void pc_res_digit_kernel (const uint64_t* __restrict__ keys, const unsigned long
 // kept, sorts them in LDS and reads the answer off.  Four launches instead of ten per percentile -- two plus two per
 // further percentile.  What the grids miss (a rank outside four standard deviations, a cell too big for LDS, a list kept
 // past its capacity) marks the percentile for the plain route (how = 2), like a rank outside its bracket always has.
+// (Round 5 built the form sketched in round 4's notes for ONE percentile -- the counting pass also counts its candidates
+// into 256 even cells across the bracket, so that ONE launch behind it knows the rank's cell before it looks at a key,
+// keeps that cell's keys and sorts them: no strided sort to lay a grid, no pass that counts every candidate per grid
+// cell.  Per kernel it does what it should (candidates' launches 35 + 73 us -> 53 per 145 Mbp), per call it is worth
+// 15-40 us of 565 (profiles/r05_percentile_hist.txt), and it was taken out again: the cells' flush -- some sixty
+// global atomics per workgroup on 256 addresses -- costs the genome-wide call 0.6-0.9 ms of 4.45 (47 k workgroups), and
+// even cells in key space cannot answer what the grid does: a median of read depth puts millions of equal keys into one
+// cell (the grid counts a key's ties apart), so the two-launch form would have had to stay behind it for every call.)
 // Bitonic, ascending; n a power of two <= PC_LS_KEYS; ends with the workgroup in step.  A workgroup barrier per stage made
 // a sort of 8192 keys 91 barriers long -- ~55 us on a chip that a single workgroup does not bring up to speed
 // (profiles/r04_percentile_lds_steps.txt).  So wave w owns the pairs of keys n/16 w .. n/16 (w+1) - 1: every stage whose
@@ -1171,17 +1143,9 @@ __device__ __forceinline__ bool pc_ls_last (PcResHist* H, uint32_t* sLast)
 	}
 
 // the pivots of the counting pass out of every percentile's bracket (host: pc_run, the end of step 2)
-__device__ __noinline__ void pc_res_pivots_body (PcResident* __restrict__ R, int np, int fuseWhich, int wantHist)      // (one thread)
+__device__ __noinline__ void pc_res_pivots_body (PcResident* __restrict__ R, int np, int fuseWhich)      // (one thread)
 	{
 	if (R->status != PC_RES_OK) return;
-	// one percentile with a bracket closed at both ends: its candidates are the keys strictly between the ends, and the
-	// counting pass can cut that stretch of keys into PC_CHIST even cells (the widest power of two that fits)
-	if (wantHist && (np == 1) && !R->openLo[0] && !R->openHi[0] && (R->bHi[0] > R->bLo[0] + 1))
-		{
-		const uint64_t width = R->bHi[0] - R->bLo[0] - 1;          // keys that can be candidates
-		const int bits = 64 - __clzll ((long long) width);
-		R->histLo = R->bLo[0] + 1;  R->histShift = (bits > 8)? (uint32_t) (bits - 8) : 0u;  R->histOn = 1;
-		}
 	uint64_t piv[2*PC_RES_MAXP];
 	int m = 0;
 	for (int i=0 ; i<np ; i++)
@@ -1228,17 +1192,17 @@ __device__ __noinline__ void pc_res_pivots_body (PcResident* __restrict__ R, int
 		}
 	}
 
-__global__ void pc_res_pivots_kernel (PcResident* __restrict__ R, int np, int fuseWhich, int wantHist)
+__global__ void pc_res_pivots_kernel (PcResident* __restrict__ R, int np, int fuseWhich)
 	{
 	if ((threadIdx.x != 0) || (blockIdx.x != 0)) return;
-	pc_res_pivots_body (R, np, fuseWhich, wantHist);
+	pc_res_pivots_body (R, np, fuseWhich);
 	}
 
 // SAMPLE stage, second launch: every key of the subsample into its cell of every percentile's grid; the last workgroup
 // turns the counts into brackets (what digit 0's rank decision and the last digit's pick did: pc_res_digit_kernel).
 __global__ __launch_bounds__(PC_RES_THREADS)
 void pc_ls_grid_kernel (const uint64_t* __restrict__ keys, unsigned long long slots, PcPts pts, PcResident* __restrict__ R, PcResHist* __restrict__ H,
-                        int fuseWhich, int wantHist)               // (the last workgroup goes on to the pivots: pc_res_pivots_body, a launch less)
+                        int fuseWhich)                              // (round 5: the last workgroup goes on to lay the pivots, pc_res_pivots_body: a launch less)
 	{
 	__shared__ uint64_t grid[PC_RES_MAXP][PC_LS_GRID];
 	__shared__ uint32_t gn[PC_RES_MAXP];
@@ -1335,7 +1299,7 @@ void pc_ls_grid_kernel (const uint64_t* __restrict__ keys, unsigned long long sl
 		}
 	__syncthreads ();
 	for (int q=p ; q<np*2*PC_LS_CELLS ; q+=PC_RES_THREADS) H->slab[0][0][q] = 0;
-	if (p == 0) { H->ticket = 0;  pc_res_pivots_body (R, np, fuseWhich, wantHist); }      // (the brackets above were written by this workgroup: visible behind its barrier)
+	if (p == 0) { H->ticket = 0;  pc_res_pivots_body (R, np, fuseWhich); }      // (the brackets above were written by this workgroup: visible behind its barrier)
 	}
 
 // CAND stage, first launch: one workgroup.  A strided 8192 of percentile `which`'s candidates in scope, sorted; a list
@@ -1526,108 +1490,6 @@ void pc_ls_cand_pick_kernel (const uint64_t* __restrict__ keys, const unsigned l
 		}
 	__syncthreads ();
 	if (p < 2*PC_LS_CELLS) H->slab[0][0][p] = 0;
-	if (p == 0) { H->ticket = 0;  H->compactCount = 0; }
-	}
-
-// CAND stage in ONE launch (round 5; one percentile, a bracket closed at both ends): the counting pass has left the
-// candidates' counts per cell of the bracket (pc_cand_hist), so every workgroup knows the cell that holds the rank before
-// it looks at a key: it keeps its share of that cell's keys (a thousand or so of a quarter of a million), the last
-// workgroup sorts them and reads the answer off.  No strided sort to lay a grid (pc_ls_cand_sub_kernel), no pass that
-// counts all candidates per grid cell (pc_ls_cand_pick_kernel): 35 + 70 us and a launch gap less per 249 Mbp call.
-// What it cannot settle (no histogram: an open bracket; a cell beyond a workgroup's LDS; the test hook) is left to the
-// host's digit passes over the candidate list (how = 3), like the two-launch form's give-ups.
-__global__ __launch_bounds__(PC_RES_THREADS)
-void pc_ls_hist_pick_kernel (const uint64_t* __restrict__ keys, const unsigned long long* __restrict__ countPtr, unsigned long long countCap,
-                             PcResident* __restrict__ R, PcResHist* __restrict__ H, uint64_t* __restrict__ kept, unsigned long long keptCap, int giveUp)
-	{
-	__shared__ uint64_t a[PC_LS_KEYS];
-	__shared__ uint32_t h[PC_CHIST];
-	__shared__ uint32_t sLast, sCount;
-	__shared__ int      sCell;
-	__shared__ unsigned long long sBefore, sTotal;
-	if ((R->status != PC_RES_OK) || (R->how[0] != 1) || R->candDone[0]) return;
-	const int p = threadIdx.x, lane = p & 63;
-	if (!R->histOn || giveUp) { if ((p == 0) && (blockIdx.x == 0)) R->how[0] = 3;  return; }     // (nobody has touched the ticket)
-	const uint32_t* cells = pc_cand_hist (R);
-	if (p < PC_CHIST) h[p] = cells[p];
-	if (p == 0) sCount = 0;
-	__syncthreads ();
-	const unsigned long long rank = R->rankIn[0], inBin = R->binCount[0];
-	if (p < 64)                                                    // cells 4 lane .. 4 lane + 3
-		{
-		const unsigned long long c0 = h[4*lane], c1 = h[4*lane + 1], c2 = h[4*lane + 2], c3 = h[4*lane + 3], mine = c0 + c1 + c2 + c3;
-		unsigned long long incl = mine;
-		for (int d=1 ; d<64 ; d*=2) { const unsigned long long up = __shfl_up (incl, d, 64);  if (lane >= d) incl += up; }
-		const unsigned long long total = __shfl (incl, 63, 64), before = incl - mine;
-		if (lane == 0) { sTotal = total;  sCell = -1;  sBefore = 0; }
-		__builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier ();
-		if ((rank >= before) && (rank < incl))
-			{
-			int cell = 4*lane;  unsigned long long b = before;
-			if (rank >= b + c0) { b += c0;  cell++;  if (rank >= b + c1) { b += c1;  cell++;  if (rank >= b + c2) { b += c2;  cell++; } } }
-			sCell = cell;  sBefore = b;
-			}
-		}
-	__syncthreads ();
-	const int cell = sCell;
-	if ((sTotal != inBin) || (cell < 0))                           // (uniform over the grid: every workgroup sees the same words)
-		{ if ((p == 0) && (blockIdx.x == 0)) R->status = PC_RES_DISAGREE;  return; }
-	const uint32_t want = h[cell];
-	if (want > PC_LS_KEYS) { if ((p == 0) && (blockIdx.x == 0)) R->how[0] = 3;  return; }
-	unsigned long long count = *countPtr;
-	if (count > countCap) count = countCap;
-	const uint64_t keyLo = R->scopeLo[0], keyHi = R->scopeHi[0], hLo = R->histLo;
-	const uint32_t hShift = R->histShift;
-	const size_t stride = (size_t) gridDim.x * PC_RES_THREADS;
-	for (size_t i = (size_t) blockIdx.x * PC_RES_THREADS + p ; i < count ; i += 8*stride)
-		{
-		uint64_t k[8];
-#pragma unroll
-		for (int u=0 ; u<8 ; u++) k[u] = (i + u*stride < count)? keys[i + u*stride] : PC_NO_KEY;
-#pragma unroll
-		for (int u=0 ; u<8 ; u++)
-			{
-			const uint64_t c = (k[u] - hLo) >> hShift;
-			const bool mine = (k[u] != PC_NO_KEY) && (k[u] >= keyLo) && (k[u] <= keyHi)
-			                  && ((int) ((c < PC_CHIST)? c : PC_CHIST - 1) == cell);
-			const uint64_t mask = __ballot (mine);
-			if (mask == 0) continue;
-			uint32_t base = 0;
-			if (lane == 0) base = atomicAdd (&sCount, (uint32_t) __popcll (mask));
-			base = (uint32_t) __shfl ((int) base, 0, 64);
-			const uint32_t at = base + (uint32_t) __popcll (mask & ((1ULL << lane) - 1));
-			if (mine && (at < PC_LS_KEYS)) a[at] = k[u];               // (the whole cell fits: want <= PC_LS_KEYS)
-			}
-		}
-	__syncthreads ();
-		{
-		const uint32_t mine = sCount;
-		if (p == 0) sBefore = (mine == 0)? 0 : atomicAdd (&H->compactCount, (unsigned long long) mine);
-		__syncthreads ();
-		const unsigned long long base = sBefore;
-		for (uint32_t i=p ; i<mine ; i+=PC_RES_THREADS) { if (base + i < keptCap) kept[base + i] = a[i]; }
-		}
-	if (!pc_ls_last (H, &sLast)) return;
-
-	// ---- the last workgroup: the cell's keys, sorted
-	const unsigned long long nkept = H->compactCount;
-	unsigned long long before = 0;
-	for (int q=0 ; q<cell ; q++) before += h[q];                   // (the same words in every thread)
-	if ((nkept != want) || (nkept > keptCap)) { if (p == 0) R->status = PC_RES_DISAGREE; }
-	else
-		{
-		for (unsigned long long i=p ; i<nkept ; i+=PC_RES_THREADS) a[i] = kept[i];
-		int n = 2;
-		while ((unsigned long long) n < nkept) n <<= 1;
-		for (unsigned long long i=nkept+p ; i<(unsigned long long) n ; i+=PC_RES_THREADS) a[i] = ~0ULL;
-		__syncthreads ();
-		pc_ls_sort (a, n);
-		if (p == 0) { R->values[0] = gdsp_value_of (a[rank - before]);  R->candDone[0] = 1; }
-		}
-	__syncthreads ();
-	uint32_t* clear = pc_cand_hist (R);
-	if (p < PC_CHIST) clear[p] = 0;
 	if (p == 0) { H->ticket = 0;  H->compactCount = 0; }
 	}
 
@@ -2279,10 +2141,6 @@ static int pc_resident (PcJob& J, const uint32_t* pThousandths, int np, uint32_t
 	const char* lsEnv = getenv ("GDSP_PERCENTILE_LDS_SELECT");
 	const bool  lds = !split && (ND == 1) && !((lsEnv != NULL) && (strcmp (lsEnv, "0") == 0));
 	const int fuseWhich = (J.fuse != NULL)? J.fuse->which : -1;
-	// one percentile: its candidates are counted per cell of the bracket by the counting pass itself, and one launch
-	// answers it (pc_ls_hist_pick_kernel); GDSP_PERCENTILE_HIST=0 keeps the two launches per percentile (A/B, tests)
-	const char* chEnv = getenv ("GDSP_PERCENTILE_HIST");
-	const bool  candHist = lds && (np == 1) && !((chEnv != NULL) && (strcmp (chEnv, "0") == 0));
 	// subsample, then the ranks either side of every percentile's target: five digits each, no answer awaited
 	PC_TRY (pc_sample_launch (J, sstride));
 	if (lds)
@@ -2291,7 +2149,7 @@ static int pc_resident (PcJob& J, const uint32_t* pThousandths, int np, uint32_t
 		const uint32_t blocks = (uint32_t) std::min<unsigned long long> (PC_RES_MAXB, std::max<unsigned long long> (1, (slots + 16383) / 16384));
 		hipLaunchKernelGGL (pc_ls_sub_kernel, dim3(1), dim3(PC_RES_THREADS), 0, st[0], (const uint64_t*) J.scratch[0]->sample, slots, pts, R[0]);
 		hipLaunchKernelGGL (pc_ls_grid_kernel, dim3(blocks), dim3(PC_RES_THREADS), 0, st[0], (const uint64_t*) J.scratch[0]->sample, slots, pts, R[0], H[0],
-		                    fuseWhich, candHist? 1 : 0);
+		                    fuseWhich);
 		GDSP_LAUNCH_CHECK ();
 		}
 	else
@@ -2300,7 +2158,7 @@ static int pc_resident (PcJob& J, const uint32_t* pThousandths, int np, uint32_t
 	for (size_t d=0 ; (d<ND) && !lds ; d++)                      // (with the selects in LDS the grid launch's last workgroup has laid the pivots)
 		{
 		GDSP_HIP_TRY (hipSetDevice (J.devices[d]));
-		hipLaunchKernelGGL (pc_res_pivots_kernel, dim3(1), dim3(64), 0, st[d], R[d], np, fuseWhich, 0);
+		hipLaunchKernelGGL (pc_res_pivots_kernel, dim3(1), dim3(64), 0, st[d], R[d], np, fuseWhich);
 		GDSP_LAUNCH_CHECK ();
 		}
 
@@ -2344,11 +2202,6 @@ static int pc_resident (PcJob& J, const uint32_t* pThousandths, int np, uint32_t
 		PcDevice* sc = J.scratch[0];
 		const unsigned long long* countPtr = (const unsigned long long*) sc->ctr + (size_t) PC_REPL * PC_CTR_WORDS;
 		const uint32_t blocks = (uint32_t) std::min<size_t> (4 * PC_RES_MAXB, std::max<size_t> (4, sc->candCap / 65536));
-		if (candHist)
-			hipLaunchKernelGGL (pc_ls_hist_pick_kernel, dim3(blocks), dim3(PC_RES_THREADS), 0, st[0], (const uint64_t*) sc->cand, countPtr,
-			                    (unsigned long long) sc->candCap, R[0], H[0], sc->sample, (unsigned long long) sc->sampleCap,
-			                    (getenv ("GDSP_PERCENTILE_LDS_GIVEUP") != NULL)? 1 : 0);
-		else
 		for (int i=0 ; i<np ; i++)
 			{
 			hipLaunchKernelGGL (pc_ls_cand_sub_kernel, dim3(1), dim3(PC_RES_THREADS), 0, st[0], (const uint64_t*) sc->cand, countPtr,
