@@ -134,6 +134,34 @@ def test_interval_ingest_at_the_top(gd):
     assert (int(s[-1]), int(e[-1]), float(x[-1])) == (N - 1, N, 8.25)
 
 
+def test_cumulative_sum_over_u32max_bases(gd):
+    """cumulativesum in one pass (gdsp_sums.hip: cumsum_lookback_kernel) at the longest vector there is: 1 048 576 chunks,
+    256 super-groups (the sum over super-groups runs in four batches of 64 lanes), a ragged last chunk.  A vector of
+    ones -- every partial sum an integer below 2^53, so the bits are the reference's (sum.c:776-792): out[i] = i + 1 --
+    and one of read depth, held to the oracle's running sum restarted from the exact prefix at each window."""
+    v = gd.DeviceVector(N)
+    gd.fill(v, 1.0)
+    gd.cumulative_sum(v)
+    for p in places():
+        assert bits_equal(fetch(v, p, M), np.arange(p + 1, p + M + 1, dtype=np.float64)), p
+    assert fetch(v, N - 1, 1)[0] == float(N)
+    del v
+    d = gd.synth_coverage(SEED, CHROM, 0, N, 0)                       # integer depth: sums stay exact (< 2^53)
+    gd.cumulative_sum(d)
+    for p in places():
+        got = fetch(d, p, M)
+        x = cpu.synth_coverage(SEED, CHROM, p, M, 0)
+        # the prefix in front of the window is whatever the device says at p-1 (checked against itself at the seams by
+        # the increments): inside the window every increment must be the signal, exactly
+        first = got[0] - x[0]
+        assert bits_equal(got, first + np.cumsum(x)), p
+        if p > 0:
+            assert fetch(d, p - 1, 1)[0] == first
+    total = fetch(d, N - 1, 1)[0]
+    lo, hi, cnt = gd.genome_minmax([d], 1, -gd.DBL_MAX, gd.DBL_MAX)
+    assert hi == total and lo >= 0.0                                   # non-decreasing: the last value is the largest
+
+
 def test_driver_on_a_chromosome_of_u32max_bases(tmp_path):
     """genodsp_hip end to end: u32 parsing of coordinates up to 4294967295, the ingest binning, smooth W=101 and the
     report over 4.29 G bases.  Expected text from oracle windows."""

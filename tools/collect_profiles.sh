@@ -1,7 +1,7 @@
 #!/bin/bash
 # gpurun_out/ (scratch) -> profiles/ (tracked): the round's bench lines, kernel stats and per-operator summaries
 # usage: tools/collect_profiles.sh [round tag, default r03] [library build id for traffic.json]
-R=${1:-r04}
+R=${1:-r05}
 # the library the summaries must have been measured on: the last commit that touched the kernels or their headers
 ID=${2:-$(git log -1 --format=%h --abbrev=12 -- genodsp_amd/csrc include)}
 G=gpurun_out; P=profiles

@@ -1,7 +1,7 @@
 #!/bin/bash
 # the round's measured numbers (one GPU): bench line, BASELINE configs[2..4], the bench under rocprofv3, per-operator table
 # usage: tools/run_round.sh [outdir] [round tag, default r03]
-out=${1:-gpurun_out}; R=${2:-r04}
+out=${1:-gpurun_out}; R=${2:-r05}
 export TMPDIR=/tmp
 python bench.py --steps 20 --warmup 3 > $out/${R}_bench_smooth_hann.json 2> $out/${R}_bench_smooth_hann.err
 : > $out/${R}_bench_workloads.jsonl
