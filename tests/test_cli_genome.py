@@ -42,8 +42,8 @@ SHARDINGS = {"chromosomes": [], "bases_3_shards": ["--gpus=3", "--sharding=bases
              "chromosomes_8_shards": ["--gpus=8", "--sharding=chromosomes"], "bases_8_shards": ["--gpus=8", "--sharding=bases"]}
 
 
-EIGHT = {("config2_peaks", "bases_8_shards"), ("config3_morphology", "chromosomes_8_shards"), ("config4_percentile", "bases_8_shards"),
-         ("config4_percentile_without_preserve", "chromosomes_8_shards")}
+EIGHT = {("config2_peaks", "bases_8_shards"), ("config3_morphology", "chromosomes_8_shards"),
+         ("config4_percentile_without_preserve", "bases_8_shards")}
 
 # configs[4] once more without `--preserve`: the reference needs it (its percentile sorts the signal in place,
 # percentile.c:34-36, and the command line restores it from the text it wrote); here the signal is never touched, the same
