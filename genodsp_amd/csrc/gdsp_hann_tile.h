@@ -95,8 +95,25 @@ template <int W, int EE = HN_E> struct HannConsts
 __device__ __forceinline__ uint32_t* hann_pad_word (double* lds, int i)
 	{ return reinterpret_cast<uint32_t*> (lds + i * HN_PITCH + HN_G); }
 
+// -DPK_STAMPS (experiments only, tools/exp_peaks_stamps.sh): thread 0 of every workgroup adds the core-clock cycles since its
+// entry to pkStamps[i] at point i (one workgroup in 128: every workgroup's seven atomics on one line made the kernel four
+// times slower); the entry time waits in pad slot 210 (the plain form only: CWM keeps its change bits in every pad)
+#ifdef PK_STAMPS
+__device__ unsigned long long pkStamps[16];
+#define PK_STAMP0(lds)   do { if ((threadIdx.x == 0) && ((blockIdx.x & 127) == 0)) { *reinterpret_cast<long long*> ((lds) + 210 * HN_PITCH + HN_G) = clock64 ();  atomicAdd (&pkStamps[15], 1ULL); } } while (0)
+#define PK_STAMP(lds, i) do { if ((threadIdx.x == 0) && ((blockIdx.x & 127) == 0)) atomicAdd (&pkStamps[i], (unsigned long long) (clock64 () - *reinterpret_cast<long long*> ((lds) + 210 * HN_PITCH + HN_G))); } while (0)
+#else
+#define PK_STAMP0(lds)   do { } while (0)
+#define PK_STAMP(lds, i) do { } while (0)
+#endif
+
 // PADS: the four waves' verdicts live in pad words 0..3 instead of `huge` (which is then not used)
-template <int W, bool STATS = false, int EE = HN_E, bool PADS = false>
+// SSTATS (with PADS; gdsp_peaks.hip): what the tile's inputs are like is found while they are STAGED, on the values in
+// the loading registers -- the largest magnitude's verdict (pad words 0..3, instead of phase 1's look at every element)
+// and, per wave, pad word HN_PAD_STATS + wave = { bit 0: a sign bit is set, bit 1: 0 < |x| < 2^-500 }.  The same elements
+// as the 256 own blocks: the whole staged tile.
+#define HN_PAD_STATS 4
+template <int W, bool STATS = false, int EE = HN_E, bool PADS = false, bool SSTATS = false>
 __device__ __forceinline__ bool hann_tile_sums (double* lds, double (*tot)[HN_THREADS], uint32_t* huge,
                                                 const double* __restrict__ in, uint32_t n, int64_t e0,
                                                 const HannConsts<W, EE>& K, double (&acc)[HN_G], uint32_t (*stats)[2] = NULL)
@@ -106,6 +123,15 @@ __device__ __forceinline__ bool hann_tile_sums (double* lds, double (*tot)[HN_TH
 	const bool live = (p >= G::HALO_L) && (p < HN_THREADS - G::HALO_R);
 
 	// ---- stage 4096 elements, zero outside the chromosome
+	uint32_t sSigns = 0, sSmallest = 0xFFFFFFFFu, sBig = 0;       // (SSTATS) of the elements this thread stages
+	auto look = [&] (double x)
+		{
+		const uint32_t hi = (uint32_t) (__double_as_longlong (x) >> 32), lo = (uint32_t) __double_as_longlong (x);
+		const uint32_t m  = hi & 0x7FFFFFFFu;
+		sSigns |= hi;
+		sBig = max (sBig, m);
+		sSmallest = min (sSmallest, (m | min (lo, 1u)) - 1u);         // 0 only for a zero, which wraps to the top: ignored; a denormal's key is >= 1
+		};
 	if ((e0 >= 0) && (e0 + HN_ELEMS <= (int64_t) n))
 		{
 		const double2* src = reinterpret_cast<const double2*> (in + e0);
@@ -118,6 +144,7 @@ __device__ __forceinline__ bool hann_tile_sums (double* lds, double (*tot)[HN_TH
 			const int e = 2 * (u*HN_THREADS + p);
 			double* dst = lds + e + (e >> 4);
 			dst[0] = r[u].x;  dst[1] = r[u].y;
+			if (SSTATS) { look (r[u].x);  look (r[u].y); }
 			}
 		}
 	else
@@ -125,10 +152,20 @@ __device__ __forceinline__ bool hann_tile_sums (double* lds, double (*tot)[HN_TH
 		for (int e=p ; e<HN_ELEMS ; e+=HN_THREADS)
 			{
 			const int64_t g = e0 + e;
-			lds[e + (e >> 4)] = ((g >= 0) && (g < (int64_t) n))? in[g] : 0.0;
+			const double  x = ((g >= 0) && (g < (int64_t) n))? in[g] : 0.0;
+			lds[e + (e >> 4)] = x;
+			if (SSTATS) look (x);
 			}
 		}
+	if (SSTATS)
+		{
+		const uint32_t flags = ((__builtin_amdgcn_ballot_w64 ((sSigns >> 31) != 0) != 0)? 1u : 0u)
+		                     | ((__builtin_amdgcn_ballot_w64 (sSmallest < 0x20B00000u - 1u) != 0)? 2u : 0u);
+		const bool any = (__builtin_amdgcn_ballot_w64 (sBig >= HN_HUGE_HI) != 0);
+		if ((p & 63) == 0) { *hann_pad_word (lds, HN_PAD_STATS + (p >> 6)) = flags;  *hann_pad_word (lds, p >> 6) = any? 1u : 0u; }
+		}
 	__syncthreads ();
+	if (PADS) PK_STAMP (lds, 1);                                   // staged (the tile's loads have landed)
 
 	// ---- phase 0: the E taps at either end of each of the 16 windows, directly
 #pragma unroll
@@ -167,7 +204,7 @@ __device__ __forceinline__ bool hann_tile_sums (double* lds, double (*tot)[HN_TH
 		for (int u=0 ; u<HN_G ; u++)
 			{
 			const double x = xb[u];
-			big = max (big, hann_magnitude_hi (x));
+			if (!SSTATS) big = max (big, hann_magnitude_hi (x));
 			if (STATS)
 				{
 				const uint32_t hi = (uint32_t) (__double_as_longlong (x) >> 32), lo = (uint32_t) __double_as_longlong (x);
@@ -180,8 +217,11 @@ __device__ __forceinline__ bool hann_tile_sums (double* lds, double (*tot)[HN_TH
 			P0[u] = a0;  Pr[u] = ar;  Pi[u] = ai;
 			}
 		tot[0][p] = a0;  tot[1][p] = ar;  tot[2][p] = ai;
-		const bool any = (__builtin_amdgcn_ballot_w64 (big >= HN_HUGE_HI) != 0);   // the 256 blocks are the whole tile
-		if ((p & 63) == 0) { if (PADS) *hann_pad_word (lds, p >> 6) = any? 1u : 0u;  else huge[p >> 6] = any? 1u : 0u; }
+		if (!SSTATS)
+			{
+			const bool any = (__builtin_amdgcn_ballot_w64 (big >= HN_HUGE_HI) != 0);   // the 256 blocks are the whole tile
+			if ((p & 63) == 0) { if (PADS) *hann_pad_word (lds, p >> 6) = any? 1u : 0u;  else huge[p >> 6] = any? 1u : 0u; }
+			}
 		if (STATS)
 			{
 			const uint32_t flags = ((__builtin_amdgcn_ballot_w64 ((signs >> 31) != 0) != 0)? 1u : 0u)
@@ -191,6 +231,7 @@ __device__ __forceinline__ bool hann_tile_sums (double* lds, double (*tot)[HN_TH
 			}
 		}
 	__syncthreads ();
+	if (PADS) PK_STAMP (lds, 2);                                   // phase 1 (own block's prefix sums), its barrier
 	bool direct;                                                   // uniform over the workgroup
 	if (PADS) direct = ((*hann_pad_word (lds, 0) | *hann_pad_word (lds, 1) | *hann_pad_word (lds, 2) | *hann_pad_word (lds, 3)) != 0);
 	else

@@ -96,6 +96,23 @@ __global__ void peaks_init_kernel (GdspPeaksCtl* ctl, GdspBatch B, uint32_t stri
 // windows overlap in >= 94 elements) and tie exactly -- only the others are compared, on the high words as always; a cw
 // base they do not beat, with margin, is written T of its run, which the run's first cw base of the tile (its leader)
 // gets from the same chain of taps as the certain peaks; without margin it is queued like any undecided base.
+// inclusive sum / maximum over the 64 lanes by DPP moves (a lane that has no source, or is masked off, receives 0 -- the
+// identity of both for values >= 0): no LDS round trips, where six __shfl_up steps cost six (ds_bpermute) -- the three
+// scans behind the interval test were ~2000 cycles of a workgroup's ~27 000 by round 5's stamps
+template <int CTRL, int ROWS> __device__ __forceinline__ int pk_dpp0 (int x) { return __builtin_amdgcn_update_dpp (0, x, CTRL, ROWS, 0xF, true); }
+__device__ __forceinline__ int pk_wave_sum_scan (int x)
+	{
+	x += pk_dpp0<0x111, 0xF> (x);  x += pk_dpp0<0x112, 0xF> (x);  x += pk_dpp0<0x114, 0xF> (x);  x += pk_dpp0<0x118, 0xF> (x);
+	x += pk_dpp0<0x142, 0xA> (x);  x += pk_dpp0<0x143, 0xC> (x);               // row 0 -> 1 and 2 -> 3, then rows 0..1 -> 2..3
+	return x;
+	}
+__device__ __forceinline__ int pk_wave_max_scan (int x)                        // x >= 0
+	{
+	x = max (x, pk_dpp0<0x111, 0xF> (x));  x = max (x, pk_dpp0<0x112, 0xF> (x));  x = max (x, pk_dpp0<0x114, 0xF> (x));
+	x = max (x, pk_dpp0<0x118, 0xF> (x));  x = max (x, pk_dpp0<0x142, 0xA> (x));  x = max (x, pk_dpp0<0x143, 0xC> (x));
+	return x;
+	}
+
 template <int W, bool FMA, bool MAX, int HH, bool PROBE, bool CWM>
 __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t tile,
                                                    const HannConsts<W, PK_E>& K, const double* __restrict__ d_taps, double fill, GdspPeaksCtl* ctl,
@@ -118,7 +135,7 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 	//     totals: the bit maps, the lists, the exact values, the window's taps, CWM's run values
 	__shared__ __attribute__((aligned(16))) double lds[HN_THREADS * HN_PITCH];
 	__shared__ __attribute__((aligned(16))) double tot[3][HN_THREADS];
-	constexpr int PAD_HUGE = 0, PAD_STATS = 4, PAD_NSURE = 8, PAD_QUEUED = 9, PAD_NLEAD = 10, PAD_NFLAT = 11, PAD_WLEAD = 12,
+	constexpr int PAD_HUGE = 0, PAD_STATS = HN_PAD_STATS, PAD_NSURE = 8, PAD_QUEUED = 9, PAD_NLEAD = 10, PAD_NFLAT = 11, PAD_WLEAD = 12,
 	              PAD_ELO = 16, PAD_EHI = 16 + NW * PK_HMAX;
 	static_assert (PAD_EHI + NW * PK_HMAX <= HN_THREADS, "pad map");
 	(void) PAD_HUGE;
@@ -137,7 +154,12 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 	uint16_t* const sureList = reinterpret_cast<uint16_t*> (tb + OFF_SUREL);
 	uint16_t* const needList = reinterpret_cast<uint16_t*> (tb + OFF_NEEDL);   // the first undecided bases: settled in place when there are no more than these
 	double*   const exactVal = reinterpret_cast<double*>   (tb + OFF_EXACT);   // ... from the exact values of their neighbourhoods
-	double*   const tapsLds  = reinterpret_cast<double*>   (tb + OFF_TAPS);    // the window, for the exact values (as scalar operands its 202 words crowd out the block sums' constants)
+	// the window, for the exact values (as scalar operands its 202 words crowd out the block sums' constants): in the plain
+	// form in pads PAD_TAPS .. PAD_TAPS + W - 1, fetched while the tile's loads are in flight; CWM keeps its change bits in
+	// every pad's high word, so there the taps go on the block totals, fetched behind B1 (and waited for before the lists' barrier)
+	constexpr int PAD_TAPS = 100;
+	static_assert (PAD_TAPS + W <= HN_THREADS, "pad map");
+	auto tapAt = [&] (int k) -> double& { return CWM? reinterpret_cast<double*> (tb + OFF_TAPS)[k] : lds[(PAD_TAPS + k) * HN_PITCH + HN_G]; };
 	uint16_t* const leadList = reinterpret_cast<uint16_t*> (tb + OFF_LEADL);
 	double*   const blockT   = reinterpret_cast<double*>   (tb + OFF_BLOCKT);  // (CWM) per block of outputs that holds a leader: its run's value
 	uint32_t& nsure = padW (PAD_NSURE), &queued = padW (PAD_QUEUED), &nlead = padW (PAD_NLEAD), &nflat = padW (PAD_NFLAT);
@@ -155,29 +177,29 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 	const int      keepHi    = (keepLo + stride < validHi)? keepLo + stride : validHi;
 
 	if (p == 0) { nsure = 0;  queued = 0;  nlead = 0;  nflat = 0; }   // (the barriers of the block sums come before their first use; staging leaves the pads alone)
+	if (!PROBE && !CWM && (p < W)) tapAt (p) = d_taps[p];
 	double acc[HN_G];
-	bool direct = hann_tile_sums<W, false, PK_E, true> (lds, tot, NULL, in, n, e0, K, acc);
+	if (!PROBE) PK_STAMP0 (lds);
+	bool direct = hann_tile_sums<W, false, PK_E, true, true> (lds, tot, NULL, in, n, e0, K, acc);
+	if (!PROBE) PK_STAMP (lds, 3);                                 // phase 2 (the middle stretch) done in thread 0
 
-	// ---- what the tile's inputs are like, from the own block in the LDS image (after the block sums: inside them, where
-	// the registers are fullest, the same few integer operations per element cost a fifth of the kernel): is a sign bit
-	// set, is there a nonzero magnitude below 2^-500.  stats[wave][1] = { bit 0, bit 1 }; read after the next barrier.
+	// ---- what the tile's inputs are like (is a sign bit set, is there a nonzero magnitude below 2^-500) was found while
+	// they were staged, on the loading registers (hann_tile_sums, SSTATS: pad word PAD_STATS + wave; until round 5 a look at
+	// the own block in the LDS image here -- sixteen more LDS reads and a hundred integer instructions a thread).  CWM: the
+	// own block's change bits.
+	if (CWM)
 		{
 		const double* xb = lds + p * HN_PITCH;
-		uint32_t signs = 0, smallest = 0xFFFFFFFFu, chg = 0;
-		long long before = (CWM && (p > 0))? __double_as_longlong (lds[(p - 1) * HN_PITCH + HN_G - 1]) : 0;
+		uint32_t chg = 0;
+		long long before = (p > 0)? __double_as_longlong (lds[(p - 1) * HN_PITCH + HN_G - 1]) : 0;
 #pragma unroll
 		for (int u=0 ; u<HN_G ; u++)
 			{
-			const uint32_t hi = (uint32_t) (__double_as_longlong (xb[u]) >> 32), lo = (uint32_t) __double_as_longlong (xb[u]);
-			signs |= hi;
-			const uint32_t key = (hi & 0x7FFFFFFFu) | min (lo, 1u);    // 0 only for a zero; a denormal's is 1
-			smallest = min (smallest, key - 1u);                      // (a zero wraps to the top: ignored)
-			if (CWM) { const long long here = __double_as_longlong (xb[u]);  chg |= ((here != before) || ((p == 0) && (u == 0)))? (1u << u) : 0u;  before = here; }
+			const long long here = __double_as_longlong (xb[u]);
+			chg |= ((here != before) || ((p == 0) && (u == 0)))? (1u << u) : 0u;
+			before = here;
 			}
-		if (CWM) chgBitsAt (p) = chg;
-		const uint32_t flags = ((__builtin_amdgcn_ballot_w64 ((signs >> 31) != 0) != 0)? 1u : 0u)
-		                     | ((__builtin_amdgcn_ballot_w64 (smallest < 0x20B00000u - 1u) != 0)? 2u : 0u);
-		if (lane == 0) padW (PAD_STATS + wave) = flags;
+		chgBitsAt (p) = chg;
 		}
 
 	// the high words of the own block's smoothed values, as 32-bit integers (see the test below), and the words the
@@ -196,11 +218,12 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 #pragma unroll
 	for (int t=0 ; t<HH ; t++)
 		{
-		k[t]             = (uint32_t) __shfl_up   ((int) k[HN_G + t], 1, 64);          // the previous block's last HH words
-		k[HN_G + HH + t] = (uint32_t) __shfl_down ((int) k[HH + t],   1, 64);          // the next block's first HH
+		k[t]             = (uint32_t) pk_dpp0<0x138, 0xF> ((int) k[HN_G + t]);         // wave_shr:1: the previous block's last HH words
+		k[HN_G + HH + t] = (uint32_t) pk_dpp0<0x130, 0xF> ((int) k[HH + t]);           // wave_shl:1: the next block's first HH (the wave's end lanes: below)
 		}
 	__syncthreads ();                                              // B1: nobody reads the block totals any more
-	if (!PROBE && (p < W)) tapsLds[p] = d_taps[p];                 // (on the totals; read after the next barrier)
+	if (!PROBE) PK_STAMP (lds, 4);                                 // statistics, high words, edges, barrier B1
+	if (!PROBE && CWM && (p < W)) tapAt (p) = d_taps[p];           // (on the totals; read after the next barrier)
 #pragma unroll
 	for (int t=0 ; t<HH ; t++)
 		{
@@ -433,9 +456,8 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 	if (!direct)
 		{
 		const int cnt = __popc (isSure);
-		int incl = cnt;
-		for (int d=1 ; d<64 ; d*=2) { const int up = __shfl_up (incl, d, 64);  if (lane >= d) incl += up; }
-		const int waveTotal = __shfl (incl, 63, 64);
+		const int incl = pk_wave_sum_scan (cnt);
+		const int waveTotal = __builtin_amdgcn_readlane (incl, 63);
 		if (waveTotal != 0)                                        // (uniform over the wave)
 			{
 			uint32_t base = 0;
@@ -457,9 +479,8 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 	if (!direct)
 		{
 		const int cnt = __popc (isNeed);
-		int incl = cnt;
-		for (int d=1 ; d<64 ; d*=2) { const int up = __shfl_up (incl, d, 64);  if (lane >= d) incl += up; }
-		const int waveTotal = __shfl (incl, 63, 64);
+		const int incl = pk_wave_sum_scan (cnt);
+		const int waveTotal = __builtin_amdgcn_readlane (incl, 63);
 		if (waveTotal != 0)
 			{
 			uint32_t base = 0;
@@ -482,9 +503,8 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 	if (CWM && !direct)
 		{
 		const int cnt = __popc (cwLead);
-		int incl = cnt;
-		for (int d=1 ; d<64 ; d*=2) { const int up = __shfl_up (incl, d, 64);  if (lane >= d) incl += up; }
-		const int waveTotal = __shfl (incl, 63, 64);
+		const int incl = pk_wave_sum_scan (cnt);
+		const int waveTotal = __builtin_amdgcn_readlane (incl, 63);
 		if (waveTotal != 0)
 			{
 			uint32_t base = 0;
@@ -501,7 +521,7 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 				}
 			}
 		leadIncl = (cwLead != 0)? blk : -1;
-		for (int d=1 ; d<64 ; d*=2) { const int up = __shfl_up (leadIncl, d, 64);  if (lane >= d) leadIncl = max (leadIncl, up); }
+		leadIncl = pk_wave_max_scan (leadIncl + 1) - 1;                  // (-1: no leader at or before this block in the wave)
 		if (lane == 63) padW (PAD_WLEAD + wave) = (uint32_t) leadIncl;
 		int flat = __popc (cwFlat);
 		for (int off=32 ; off>0 ; off>>=1) flat += __shfl_xor (flat, off, 64);
@@ -513,6 +533,7 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 		reinterpret_cast<uint16_t*> (sureBits)[blk] = (uint16_t) (direct? 0u : (isSure | cwFlat));     // (what its own lane writes)
 		}
 	__syncthreads ();
+	if (!PROBE) PK_STAMP (lds, 5);                                 // classification, lists, their barrier
 	const int  sure    = (int) ((nsure < SURE_CAP)? nsure : SURE_CAP);
 	const int  nq      = (int) queued;
 	const int  nl      = CWM? (int) nlead : 0;
@@ -546,12 +567,36 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 		const double* at16[16];
 #pragma unroll
 		for (int j=0 ; j<16 ; j++) at16[j] = lds + (e + (e >> 4)) + ((j >= 16 - (e & 15))? 1 : 0);
+		// (in batches of reads, then products, then sums: left to itself the compiler fetches two to four taps ahead and the
+		//  chain -- wave 0's, while the workgroup's LDS waits for it -- sits out an LDS round trip every few taps: 55 cycles
+		//  a tap by round 5's stamps, 41 in batches)
 		double a = 0.0;
+		constexpr int KB = 17, NB = (W + KB - 1) / KB;               // 101 = 5 x 17 + 16
 #pragma unroll
-		for (int k=0 ; k<W ; k++)
+		for (int b=0 ; b<NB ; b++)
 			{
-			const double x = at16[k & 15][k + (k >> 4)];
-			a = FMA? __builtin_fma (tapsLds[k], x, a) : a + tapsLds[k] * x;
+			double xv[KB], wv[KB];                                   // (two batches in flight -- the next one's reads behind this one's sums -- spill 130 registers)
+#pragma unroll
+			for (int j=0 ; j<KB ; j++)
+				{
+				const int k = b * KB + j;
+				if (k < W) { xv[j] = at16[k & 15][k + (k >> 4)];  wv[j] = tapAt (k); }
+				}
+			__builtin_amdgcn_sched_barrier (0);                      // every read of the batch before its first product
+			if (FMA)
+				{
+#pragma unroll
+				for (int j=0 ; j<KB ; j++) { if (b * KB + j < W) a = __builtin_fma (wv[j], xv[j], a); }
+				}
+			else
+				{
+#pragma unroll
+				for (int j=0 ; j<KB ; j++) { if (b * KB + j < W) xv[j] = wv[j] * xv[j]; }      // the products, then the sums in order
+				__builtin_amdgcn_sched_barrier (0);
+#pragma unroll
+				for (int j=0 ; j<KB ; j++) { if (b * KB + j < W) a = a + xv[j]; }
+				}
+			__builtin_amdgcn_sched_barrier (0);
 			}
 		if (p < sure)  out[compStart + c] = a;
 		else if (lead) blockT[CWM? (c >> 4) : 0] = a;              // the value of every base of the run whose window lies inside it
@@ -572,6 +617,31 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 			}
 		}
 
+	if (!PROBE) PK_STAMP (lds, 6);                                 // thread 0's exact values (wave 0's chain of taps), in-place settling
+	// ---- the tile's other outputs: zero where an exact zero stands, `fill` elsewhere (a queued base is rewritten by the
+	//      exact kernel); pairs, 16 bytes per lane; a pair that holds a certain peak leaves that element to its lane
+	// (a wave that has evaluated exact values has done its share: the others divide the tile between them, and the
+	//  workgroup is done when the slower of the two jobs is, not after one behind the other -- round 5's stamps: the chain
+	//  of taps and the store loop were 17 % and 15 % of a workgroup's life, one behind the other in wave 0.  Giving wave 0
+	//  a seventh of the stores for balance made the loop's own cost in wave 0 four times what it saved)
+	double* dst = out + keepStart;
+	const int  chainWaves = (evals + 63) / 64;                     // waves 0 .. chainWaves-1 ran the chain of taps (uniform)
+	const bool share      = (chainWaves >= 1) && (chainWaves < NW) && !inPlace;
+	const int  q          = share? p - 64 * chainWaves : p, qn = share? HN_THREADS - 64 * chainWaves : HN_THREADS;
+	for (int c = keepLo + 2*q ; (q >= 0) && (c < keepHi) ; c += 2*qn)     // (keepLo is even)
+		{
+		const uint32_t two  = zeroBits[c >> 5] >> (c & 31);
+		const uint32_t skip = (sureBits[c >> 5] >> (c & 31)) & 3u;
+		const double r0 = (two & 1u)? 0.0 : fill, r1 = (two & 2u)? 0.0 : fill;
+		if ((skip == 0) && (c + 1 < keepHi)) gdsp_st2 (reinterpret_cast<double2*> (dst + (c - keepLo)), make_double2 (r0, r1));
+		else
+			{
+			if ((skip & 1u) == 0)                        dst[c - keepLo]     = r0;
+			if (((skip & 2u) == 0) && (c + 1 < keepHi)) dst[c - keepLo + 1] = r1;
+			}
+		}
+	// (CWM's flat bases after the store loop, not before it: their values wait for the leaders' chains in the first waves,
+	//  and the other waves have the tile's stores to issue meanwhile)
 	if (CWM && !direct && (nflat != 0))                            // (uniform) the kept bases of flat stretches: their run's value
 		{
 		__syncthreads ();
@@ -590,21 +660,7 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 			}
 		}
 
-	// ---- the tile's other outputs: zero where an exact zero stands, `fill` elsewhere (a queued base is rewritten by the
-	//      exact kernel); pairs, 16 bytes per lane; a pair that holds a certain peak leaves that element to its lane
-	double* dst = out + keepStart;
-	for (int c = keepLo + 2*p ; c < keepHi ; c += 2*HN_THREADS)    // (keepLo is even)
-		{
-		const uint32_t two  = zeroBits[c >> 5] >> (c & 31);
-		const uint32_t skip = (sureBits[c >> 5] >> (c & 31)) & 3u;
-		const double r0 = (two & 1u)? 0.0 : fill, r1 = (two & 2u)? 0.0 : fill;
-		if ((skip == 0) && (c + 1 < keepHi)) gdsp_st2 (reinterpret_cast<double2*> (dst + (c - keepLo)), make_double2 (r0, r1));
-		else
-			{
-			if ((skip & 1u) == 0)                        dst[c - keepLo]     = r0;
-			if (((skip & 2u) == 0) && (c + 1 < keepHi)) dst[c - keepLo + 1] = r1;
-			}
-		}
+	if (!PROBE) PK_STAMP (lds, 7);                                 // the store loop issued
 	}
 
 template <int W, bool MAX, int HH, bool CWM>
@@ -718,6 +774,16 @@ void peaks_exact_kernel (GdspBatch B, PeaksTaps<W> taps, int h, double fill, con
 			}
 		}
 	}
+
+#ifdef PK_STAMPS
+extern "C" int gdsp_peaks_stamps (unsigned long long* out, int clear)
+	{
+	GDSP_HIP_TRY (hipDeviceSynchronize ());
+	GDSP_HIP_TRY (hipMemcpyFromSymbol (out, HIP_SYMBOL (pkStamps), 16 * sizeof(unsigned long long)));
+	if (clear) { unsigned long long z[16] = { 0 };  GDSP_HIP_TRY (hipMemcpyToSymbol (HIP_SYMBOL (pkStamps), z, sizeof(z))); }
+	return GDSP_OK;
+	}
+#endif
 
 // ------------------------------------------------------------------- host ----
 struct PeaksWork { int device;  void* stream;  GdspPeaksCtl* ctl;  uint16_t* strips;  uint32_t* counts;  uint32_t* tileList;  size_t tiles; };
