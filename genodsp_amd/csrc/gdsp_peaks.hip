@@ -685,12 +685,14 @@ struct PeaksSub { uint32_t v[GDSP_BATCH_MAX], gt0[GDSP_BATCH_MAX]; };
 template <int W, bool FMA, bool MAX, int HH, bool CWM>
 __global__ __launch_bounds__(HN_THREADS) __attribute__((amdgpu_waves_per_eu(PK_WAVES, PK_WAVES)))
 void peaks_filter_kernel (GdspBatch S, PeaksSub M, HannConsts<W, PK_E> K, const double* __restrict__ d_taps, double fill, GdspPeaksCtl* ctl,
-                          uint16_t* strips, uint32_t* counts, uint32_t cap, uint32_t* tileList)
+                          uint16_t* strips, uint32_t* counts, uint32_t cap, uint32_t* tileList, int gate)
 	{
 	const double* in;  double* out;  uint32_t n, i;
 	const uint32_t tile = gdsp_batch_tile (S, in, out, n, &i);
 	const uint32_t v = M.v[i], gt = M.gt0[i] + tile;               // the tile's number in the whole table: its strip and its count
-	if (gdsp_peaks_takes_direct (ctl[v])) return;                  // (only where the host did not look: GDSP_PEAKS_FLAT=0)
+	// (only where the host did not look -- GDSP_PEAKS_FLAT=0: otherwise a load every workgroup would wait for before it
+	//  may issue its tile's)
+	if (gate && gdsp_peaks_takes_direct (ctl[v])) return;
 	peaks_filter_tile<W, FMA, MAX, HH, false, CWM> (in, out, n, tile, K, d_taps, fill, &ctl[v], strips + (size_t) gt * cap, counts + gt, cap,
 	                                                tileList + M.gt0[i], gt);
 	}
@@ -901,7 +903,7 @@ static int peaks_launch (const gdsp_batch_item* items, int count, const HannCons
 		GdspBatch S;
 		gdsp_batch_make (S, sub.data (), (int) sub.size (), [] (uint32_t n) { return ((uint64_t) n + stride - 1) / stride; });
 		const dim3 grid (S.tile0[GDSP_BATCH_MAX]), block (HN_THREADS);
-#define PK_FILTER(FMAV, CWMV) hipLaunchKernelGGL ((peaks_filter_kernel<101, FMAV, MAX, HH, CWMV>), grid, block, 0, s, S, M, K, d_taps, fill, w.ctl, w.strips, w.counts, cap, w.tileList)
+#define PK_FILTER(FMAV, CWMV) hipLaunchKernelGGL ((peaks_filter_kernel<101, FMAV, MAX, HH, CWMV>), grid, block, 0, s, S, M, K, d_taps, fill, w.ctl, w.strips, w.counts, cap, w.tileList, flatForm? 0 : 1)
 		if (form == 1) { if (fma) PK_FILTER (true, true);   else PK_FILTER (false, true); }
 		else           { if (fma) PK_FILTER (true, false);  else PK_FILTER (false, false); }
 #undef PK_FILTER
