@@ -100,8 +100,13 @@ __device__ __forceinline__ uint32_t* hann_pad_word (double* lds, int i)
 // times slower); the entry time waits in pad slot 210 (the plain form only: CWM keeps its change bits in every pad)
 #ifdef PK_STAMPS
 __device__ unsigned long long pkStamps[16];
-#define PK_STAMP0(lds)   do { if ((threadIdx.x == 0) && ((blockIdx.x & 127) == 0)) { *reinterpret_cast<long long*> ((lds) + 210 * HN_PITCH + HN_G) = clock64 ();  atomicAdd (&pkStamps[15], 1ULL); } } while (0)
-#define PK_STAMP(lds, i) do { if ((threadIdx.x == 0) && ((blockIdx.x & 127) == 0)) atomicAdd (&pkStamps[i], (unsigned long long) (clock64 () - *reinterpret_cast<long long*> ((lds) + 210 * HN_PITCH + HN_G))); } while (0)
+// (the entry time in the LOW words of pads 210 and 211: CWM keeps its change bits in every pad's high word)
+__device__ __forceinline__ void pk_stamp_set (double* lds)
+	{ const long long t = clock64 ();  *hann_pad_word (lds, 210) = (uint32_t) t;  *hann_pad_word (lds, 211) = (uint32_t) (t >> 32); }
+__device__ __forceinline__ long long pk_stamp_get (double* lds)
+	{ return (long long) (((unsigned long long) *hann_pad_word (lds, 211) << 32) | *hann_pad_word (lds, 210)); }
+#define PK_STAMP0(lds)   do { if ((threadIdx.x == 0) && ((blockIdx.x & 127) == 0)) { pk_stamp_set (lds);  atomicAdd (&pkStamps[15], 1ULL); } } while (0)
+#define PK_STAMP(lds, i) do { if ((threadIdx.x == 0) && ((blockIdx.x & 127) == 0)) atomicAdd (&pkStamps[i], (unsigned long long) (clock64 () - pk_stamp_get (lds))); } while (0)
 #else
 #define PK_STAMP0(lds)   do { } while (0)
 #define PK_STAMP(lds, i) do { } while (0)

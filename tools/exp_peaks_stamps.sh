@@ -14,7 +14,7 @@ n = 248956422
 L = C.CDLL(gd.SO_PATH)
 names = ["", "staged (loads landed, first barrier)", "phase 1 + barrier", "phase 2 (thread 0)", "statistics, words, edges, B1",
          "classification, lists, barrier", "exact values (wave 0's chain), in place", "store loop issued"]
-for kind, mode in (("real-valued", 1),):
+for kind, mode in (("real-valued", 1), ("read depth", 0)):
     v = gd.synth_coverage(20240611, 0, 0, n, mode)
     out = v.like()
     S = gd.Stream()
