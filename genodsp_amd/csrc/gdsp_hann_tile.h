@@ -118,7 +118,10 @@ __device__ __forceinline__ long long pk_stamp_get (double* lds)
 // and, per wave, pad word HN_PAD_STATS + wave = { bit 0: a sign bit is set, bit 1: 0 < |x| < 2^-500 }.  The same elements
 // as the 256 own blocks: the whole staged tile.
 #define HN_PAD_STATS 4
-template <int W, bool STATS = false, int EE = HN_E, bool PADS = false, bool SSTATS = false>
+// RAW (gdsp_peaks.hip): the results are left without the window's normalisation (acc = S - C, not scale x (S - C)): the
+// interval test on high words compares, and a positive factor changes no comparison; with EE = 0 there is no direct-tap
+// sum to add either -- 32 vector instructions a thread less
+template <int W, bool STATS = false, int EE = HN_E, bool PADS = false, bool SSTATS = false, bool RAW = false>
 __device__ __forceinline__ bool hann_tile_sums (double* lds, double (*tot)[HN_THREADS], uint32_t* huge,
                                                 const double* __restrict__ in, uint32_t n, int64_t e0,
                                                 const HannConsts<W, EE>& K, double (&acc)[HN_G], uint32_t (*stats)[2] = NULL)
@@ -273,7 +276,7 @@ __device__ __forceinline__ bool hann_tile_sums (double* lds, double (*tot)[HN_TH
 				const double zr = (sr + Tr) + Pr[u];
 				const double zi = (si + Ti) + Pi[u];
 				const double c  = __builtin_fma (K.demC[u], zr, -(K.demS[u] * zi));
-				acc[u] = K.scale * ((z0 - c) + acc[u]);
+				acc[u] = RAW? ((EE == 0)? (z0 - c) : ((z0 - c) + acc[u])) : K.scale * ((z0 - c) + acc[u]);
 				}
 			}
 		T0 += s0;  Tr += sr;  Ti += si;                            // that block is whole for the remaining windows
@@ -289,7 +292,7 @@ __device__ __forceinline__ bool hann_tile_sums (double* lds, double (*tot)[HN_TH
 			const double zr = (sr + Tr) + Pr[u];
 			const double zi = (si + Ti) + Pi[u];
 			const double c  = __builtin_fma (K.demC[u], zr, -(K.demS[u] * zi));
-			acc[u] = K.scale * ((z0 - c) + acc[u]);
+			acc[u] = RAW? ((EE == 0)? (z0 - c) : ((z0 - c) + acc[u])) : K.scale * ((z0 - c) + acc[u]);
 			}
 		}
 	return direct;

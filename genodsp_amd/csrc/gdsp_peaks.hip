@@ -147,7 +147,9 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 	constexpr int OFF_ZERO = 0, OFF_SUREB = OFF_ZERO + 4 * (HN_THREADS/2), OFF_SUREL = OFF_SUREB + 4 * (HN_THREADS/2),
 	              OFF_NEEDL = OFF_SUREL + 2 * PK_SURE_CAP, OFF_EXACT = (OFF_NEEDL + 2 * PK_NEED_INPLACE + 7) & ~7,
 	              OFF_TAPS = OFF_EXACT + 8 * PK_NEED_INPLACE * (2*HH + 1), OFF_LEADL = OFF_TAPS + 8 * W,
-	              OFF_BLOCKT = (OFF_LEADL + 2 * PK_LEAD_CAP + 7) & ~7, OFF_END = OFF_BLOCKT + (CWM? 8 * HN_THREADS : 0);
+	              OFF_RUNT = (OFF_LEADL + 2 * PK_LEAD_CAP + 7) & ~7, OFF_FLATB = OFF_RUNT + (CWM? 8 * PK_LEAD_CAP : 0),
+	              OFF_LEADOF = OFF_FLATB + (CWM? 4 * (HN_THREADS/2) : 0), OFF_BLKRUN = OFF_LEADOF + (CWM? HN_THREADS : 0),
+	              OFF_END = OFF_BLKRUN + (CWM? HN_THREADS : 0);
 	static_assert (OFF_END <= (int) sizeof(tot), "the lists do not fit on the block totals");
 	uint32_t* const zeroBits = reinterpret_cast<uint32_t*> (tb + OFF_ZERO);    // per block of 16 outputs (16 bits each): exact zeros
 	uint32_t* const sureBits = reinterpret_cast<uint32_t*> (tb + OFF_SUREB);   // ... peaks evaluated in place
@@ -161,7 +163,13 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 	static_assert (PAD_TAPS + W <= HN_THREADS, "pad map");
 	auto tapAt = [&] (int k) -> double& { return CWM? reinterpret_cast<double*> (tb + OFF_TAPS)[k] : lds[(PAD_TAPS + k) * HN_PITCH + HN_G]; };
 	uint16_t* const leadList = reinterpret_cast<uint16_t*> (tb + OFF_LEADL);
-	double*   const blockT   = reinterpret_cast<double*>   (tb + OFF_BLOCKT);  // (CWM) per block of outputs that holds a leader: its run's value
+	// CWM: a run's value per LEADER (the first base of the run in the tile whose window lies inside it; at most PK_LEAD_CAP a
+	// tile), the flat bases as a bit map like the zeros', and per block of 16 outputs the number of its leader / of the
+	// leader of the run its flat bases belong to (a block meets one run: two runs' such bases lie a window apart)
+	double*   const runT     = reinterpret_cast<double*>   (tb + OFF_RUNT);
+	uint32_t* const flatBits = reinterpret_cast<uint32_t*> (tb + OFF_FLATB);
+	uint8_t*  const leaderOf = reinterpret_cast<uint8_t*>  (tb + OFF_LEADOF);
+	uint8_t*  const blockRun = reinterpret_cast<uint8_t*>  (tb + OFF_BLKRUN);
 	uint32_t& nsure = padW (PAD_NSURE), &queued = padW (PAD_QUEUED), &nlead = padW (PAD_NLEAD), &nflat = padW (PAD_NFLAT);
 
 	const int      p         = threadIdx.x, lane = p & 63, wave = p >> 6;
@@ -180,7 +188,7 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 	if (!PROBE && !CWM && (p < W)) tapAt (p) = d_taps[p];
 	double acc[HN_G];
 	if (!PROBE) PK_STAMP0 (lds);
-	bool direct = hann_tile_sums<W, false, PK_E, true, true> (lds, tot, NULL, in, n, e0, K, acc);
+	bool direct = hann_tile_sums<W, false, PK_E, true, true, true> (lds, tot, NULL, in, n, e0, K, acc);     // (RAW: acc = S - C, the scale applied where magnitudes matter)
 	if (!PROBE) PK_STAMP (lds, 3);                                 // phase 2 (the middle stretch) done in thread 0
 
 	// ---- what the tile's inputs are like (is a sign bit set, is there a nonzero magnitude below 2^-500) was found while
@@ -375,7 +383,7 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 		{
 		const int  c      = blk * HN_G + u;
 		const bool inside = live && (c >= validLo) && (c < validHi);
-		v[HH + u] = !inside? never : (acc[u] == 0.0)? 0.0 : acc[u];
+		v[HH + u] = !inside? never : (acc[u] == 0.0)? 0.0 : K.scale * acc[u];     // (the intervals are absolute: the window's normalisation belongs in)
 		}
 	if (lane == 0)  { for (int t=0 ; t<HH ; t++) padD (PAD_ELO + wave*HH + t) = v[HH + t]; }
 	if (lane == 63) { for (int t=0 ; t<HH ; t++) padD (PAD_EHI + wave*HH + t) = v[HN_G + t]; }
@@ -516,7 +524,7 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 				{
 				const int u = __ffs ((int) word) - 1;
 				word &= word - 1;
-				if (at < PK_LEAD_CAP) leadList[at] = (uint16_t) (blk * HN_G + u);
+				if (at < PK_LEAD_CAP) { leadList[at] = (uint16_t) (blk * HN_G + u);  leaderOf[blk] = (uint8_t) at; }
 				at++;
 				}
 			}
@@ -530,7 +538,8 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 	if (live)                                                      // every block of 16 has its own half word: plain stores
 		{
 		reinterpret_cast<uint16_t*> (zeroBits)[blk] = (uint16_t) isZero;
-		reinterpret_cast<uint16_t*> (sureBits)[blk] = (uint16_t) (direct? 0u : (isSure | cwFlat));     // (what its own lane writes)
+		reinterpret_cast<uint16_t*> (sureBits)[blk] = (uint16_t) (direct? 0u : isSure);               // (what its own lane writes)
+		if (CWM) reinterpret_cast<uint16_t*> (flatBits)[blk] = (uint16_t) (direct? 0u : cwFlat);
 		}
 	__syncthreads ();
 	if (!PROBE) PK_STAMP (lds, 5);                                 // classification, lists, their barrier
@@ -599,7 +608,7 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 			__builtin_amdgcn_sched_barrier (0);
 			}
 		if (p < sure)  out[compStart + c] = a;
-		else if (lead) blockT[CWM? (c >> 4) : 0] = a;              // the value of every base of the run whose window lies inside it
+		else if (lead) runT[CWM? p - sure - nbrs : 0] = a;         // the value of every base of the run whose window lies inside it
 		else           exactVal[p - sure] = inside? a : (MAX? -INFINITY : INFINITY);
 		}
 	if (inPlace)                                                   // (uniform over the workgroup)
@@ -632,6 +641,7 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 		{
 		const uint32_t two  = zeroBits[c >> 5] >> (c & 31);
 		const uint32_t skip = (sureBits[c >> 5] >> (c & 31)) & 3u;
+		if (CWM && (((flatBits[c >> 5] >> (c & 31)) & 3u) != 0)) continue;      // (a pair with a flat base: the pass behind the leaders' chains)
 		const double r0 = (two & 1u)? 0.0 : fill, r1 = (two & 2u)? 0.0 : fill;
 		if ((skip == 0) && (c + 1 < keepHi)) gdsp_st2 (reinterpret_cast<double2*> (dst + (c - keepLo)), make_double2 (r0, r1));
 		else
@@ -644,18 +654,30 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 	//  and the other waves have the tile's stores to issue meanwhile)
 	if (CWM && !direct && (nflat != 0))                            // (uniform) the kept bases of flat stretches: their run's value
 		{
-		__syncthreads ();
+		// which run a block's flat bases belong to: the last leader at or before the block (this wave's by the scan above, the
+		// waves' before it by their last words); then, behind the barrier the chains end at, every pair that holds a flat base
+		// is written whole -- 16 bytes a lane like the rest of the tile (until round 5 a lane wrote each flat base of its
+		// block by itself: sixteen 8-byte stores a lane to sixty-four lines a wave, 1.5 x the tile's bytes at the memory)
 		if (cwFlat != 0)
 			{
 			int lb = leadIncl;
 			for (int w=0 ; w<wave ; w++) lb = max (lb, (int) padW (PAD_WLEAD + w));
-			const double T = blockT[(lb >= 0)? lb : 0];               // (lb >= 0: a flat base's run has a leader at or before it)
-			uint32_t word = cwFlat;
-			while (word != 0)
+			blockRun[blk] = leaderOf[(lb >= 0)? lb : 0];             // (lb >= 0: a flat base's run has a leader at or before it)
+			}
+		__syncthreads ();
+		for (int c = keepLo + 2*p ; c < keepHi ; c += 2*HN_THREADS)
+			{
+			const uint32_t fl = (flatBits[c >> 5] >> (c & 31)) & 3u;
+			if (fl == 0) continue;
+			const uint32_t two  = zeroBits[c >> 5] >> (c & 31);
+			const uint32_t skip = (sureBits[c >> 5] >> (c & 31)) & 3u;
+			const double   T    = runT[blockRun[c >> 4]];
+			const double r0 = (fl & 1u)? T : (two & 1u)? 0.0 : fill, r1 = (fl & 2u)? T : (two & 2u)? 0.0 : fill;
+			if ((skip == 0) && (c + 1 < keepHi)) gdsp_st2 (reinterpret_cast<double2*> (dst + (c - keepLo)), make_double2 (r0, r1));
+			else
 				{
-				const int u = __ffs ((int) word) - 1;
-				word &= word - 1;
-				out[compStart + blk * HN_G + u] = T;
+				if ((skip & 1u) == 0)                        dst[c - keepLo]     = r0;
+				if (((skip & 2u) == 0) && (c + 1 < keepHi)) dst[c - keepLo + 1] = r1;
 				}
 			}
 		}
