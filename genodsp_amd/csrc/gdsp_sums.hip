@@ -714,7 +714,7 @@ void cumsum_apply_kernel (double* __restrict__ v, uint32_t n, uint32_t nchunks, 
 // Round 5.  What sank the three earlier single-pass forms (above) was (a) a SERIAL chain -- a group's running sum handed
 // from group to group, one hop of ~20 us under load per hop -- and (b) the chunk waiting for its prefix in LDS, which
 // caps what the chip holds in flight at 32 MiB.  This form has neither:
-//   * no chain.  Chunk c = (a, b, j) (4096 chunks of 4096 bases per super-group a, 64 per group b) needs
+//   * no chain.  Chunk c = (a, b, j) (4096 chunks of 8192 bases per super-group a, 64 per group b) needs
 //         prefix(c) = sum of S[a' < a]  +  sum of G[a][b' < b]  +  sum of T[a][b][j' < j]
 //     T = a chunk's own total, G = a group's, S = a super-group's.  Every chunk publishes T as soon as it has it; the
 //     LAST chunk of a group, which reads the other 63 totals anyway, publishes G, the last chunk of a super-group S.  A
@@ -723,28 +723,37 @@ void cumsum_apply_kernel (double* __restrict__ v, uint32_t n, uint32_t nchunks, 
 //     terms are +0), the three are added in one order, and a chunk's own scan is in registers in one order -- the bits do
 //     not depend on timing, run to run, and on exactly summable vectors (read depth) they are the reference's.
 //   * the chunk waits in REGISTERS (16 values a thread, loaded 16 bytes a lane, coalesced; its scans are DPP moves, no
-//     LDS round trips): 76 registers -> six workgroups per CU, 48 MiB in flight chip-wide, and LDS holds 36 words.
+//     LDS round trips): 76 registers -> six waves per SIMD = three workgroups of 512 per CU, 48 MiB in flight chip-wide,
+//     and LDS holds 68 words.
 // A published word is value and flag at once (one 8-byte store / load at agent scope, no fence): the work area is filled
 // with the one bit pattern no total can take (an all-ones NaN; a total that comes out as exactly that is published as the
 // default NaN).  Workgroups take chunks in launch order -- the dispatcher hands them out in that order, so whatever a
 // chunk waits for was dispatched before it: no ticket counter (4.3 ms by itself in round 3).
 // 16 B/base moved (24 in the three launches above).
-// Measured, 249 Mbp (tools/bench_scan.py, tools/exp_scan.sh; profiles/r05_scan_variants.txt): 0.946 ms = 0.53 of HBM on
-// 16 B/base, read depth and real values alike, against 1.016 ms for the three launches (GDSP_CUMSUM=3 keeps them).  With
-// the waits compiled out (-DCL_NOWAIT: wrong sums) the same kernel takes 0.725 ms (0.69): what the waits cost does not
-// depend on how many workgroups a CU holds (4 or 6: 0.944 / 0.946 ms; 8, with spills, 1.12) -- a chunk's terms come from
-// its contemporaries, which publish when it does, so it waits about one store-to-load round trip behind its own loads,
-// and that trip queues in the same memory pipelines as the stream.  Two forms built to take the wait out of the data's
-// way were slower: a tree of radix 16 in which a group's first chunk publishes the prefix in front of the group (a
+// Measured, 249 Mbp (tools/bench_scan.py, tools/exp_scan.sh; profiles/r05_cumsum_forms.txt): **0.751 ms = 0.66 of HBM**
+// on 16 B/base, read depth and real values alike, against 1.016 ms for the three launches (GDSP_CUMSUM=3 keeps them) and
+// 0.739 ms with the waits compiled out (-DCL_NOWAIT: wrong sums).  The first form -- chunks of 4096 bases, 256 threads --
+// took 0.946 ms (0.915 with one lane waiting for the newest term before the 64-lane fetch) against 0.725 without waits,
+// whatever the number of workgroups per CU (4 or 6: 0.944 / 0.946 ms; 8, with spills, 1.12): a chunk's terms come from
+// its contemporaries, which publish when it does, so it waits about one store-to-load round trip behind its own loads --
+// per CHUNK, so half as many chunks of twice the size pay half of it, and nearly all of the rest hides.  Two forms built
+// to take the wait out of the data's way were slower (measured on the 4096-base chunks): a tree of radix 16 in which a group's first chunk publishes the prefix in front of the group (a
 // chunk fetches <= 15 totals and one word: fewer polls, one hop deeper) 0.982 ms; every chunk visited twice by
 // workgroups a fixed lag apart, the first adding it up and publishing, the second -- its terms long there -- reading it
 // again out of the Infinity Cache and writing it: 1.04-1.05 ms at lags of 256 / 1024 / 4096 chunks (the second read
 // costs what the first does).
-#define CL_THREADS 256
-#define CL_CHUNK   4096
+// (Chunks of 8192 bases, 512 threads: with 4096 / 256 -- the same 16 values a thread, twice the chunks -- the pass took
+// 0.915 ms per 249 Mbp instead of 0.751 against 0.739 with the waits compiled out: what the waits cost is paid per chunk.)
+#ifndef CL_THREADS
+#define CL_THREADS 512
+#endif
+#ifndef CL_CHUNK
+#define CL_CHUNK   8192
+#endif
 #define CL_ROWS    (CL_CHUNK / (2 * CL_THREADS))          // 8 rows of 512 elements: thread t holds elements 512 u + 2 t, + 1
 #define CL_GROUP   64
 #define CL_SUPER   (CL_GROUP * CL_GROUP)
+static_assert (CL_ROWS * (CL_THREADS / 64) <= 64, "one wave scans the (row, wave) totals of a chunk");
 #define CL_SENTINEL 0xFFFFFFFFFFFFFFFFull
 #ifndef CL_TSTRIDE
 #define CL_TSTRIDE 1                                         // 8-byte words from one chunk's total to the next (32: a 256-byte line each)
