@@ -118,10 +118,12 @@ __device__ __forceinline__ long long pk_stamp_get (double* lds)
 // and, per wave, pad word HN_PAD_STATS + wave = { bit 0: a sign bit is set, bit 1: 0 < |x| < 2^-500 }.  The same elements
 // as the 256 own blocks: the whole staged tile.
 #define HN_PAD_STATS 4
+// CHG (gdsp_peaks.hip, the form for flat stretches): phase 1 leaves in the HIGH word of the own pad which of the block's
+// elements differ from the element before them (bit u), found on the values it reads anyway
 // RAW (gdsp_peaks.hip): the results are left without the window's normalisation (acc = S - C, not scale x (S - C)): the
 // interval test on high words compares, and a positive factor changes no comparison; with EE = 0 there is no direct-tap
 // sum to add either -- 32 vector instructions a thread less
-template <int W, bool STATS = false, int EE = HN_E, bool PADS = false, bool SSTATS = false, bool RAW = false>
+template <int W, bool STATS = false, int EE = HN_E, bool PADS = false, bool SSTATS = false, bool RAW = false, bool CHG = false>
 __device__ __forceinline__ bool hann_tile_sums (double* lds, double (*tot)[HN_THREADS], uint32_t* huge,
                                                 const double* __restrict__ in, uint32_t n, int64_t e0,
                                                 const HannConsts<W, EE>& K, double (&acc)[HN_G], uint32_t (*stats)[2] = NULL)
@@ -208,10 +210,17 @@ __device__ __forceinline__ bool hann_tile_sums (double* lds, double (*tot)[HN_TH
 		double a0 = 0.0, ar = 0.0, ai = 0.0;
 		uint32_t big = 0;                                          // largest exponent seen in the own block
 		uint32_t signs = 0;  bool tiny = false;
+		uint32_t chg = 0;                                          // (CHG) bit u: element u of the block differs from the one before it
+		long long before = (CHG && (p > 0))? __double_as_longlong (lds[(p - 1) * HN_PITCH + HN_G - 1]) : 0;
 #pragma unroll
 		for (int u=0 ; u<HN_G ; u++)
 			{
 			const double x = xb[u];
+			if (CHG)
+				{
+				chg |= ((__double_as_longlong (x) != before) || ((p == 0) && (u == 0)))? (1u << u) : 0u;     // (the tile's first element: a change)
+				before = __double_as_longlong (x);
+				}
 			if (!SSTATS) big = max (big, hann_magnitude_hi (x));
 			if (STATS)
 				{
@@ -225,6 +234,7 @@ __device__ __forceinline__ bool hann_tile_sums (double* lds, double (*tot)[HN_TH
 			P0[u] = a0;  Pr[u] = ar;  Pi[u] = ai;
 			}
 		tot[0][p] = a0;  tot[1][p] = ar;  tot[2][p] = ai;
+		if (CHG) hann_pad_word (lds, p)[1] = chg;
 		if (!SSTATS)
 			{
 			const bool any = (__builtin_amdgcn_ballot_w64 (big >= HN_HUGE_HI) != 0);   // the 256 blocks are the whole tile

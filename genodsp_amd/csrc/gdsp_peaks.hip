@@ -19,8 +19,11 @@
 //      would stay undecided even so takes the direct kernel instead (every block of the later launches reads the same
 //      counters and decides alike).  GDSP_PEAKS_FLAT=0: no CWM form, no read-back (rounds 3-4a).
 //   A  filter: block sums -> interval test -> `fill` / 0 written with 16-byte stores, undecided bases queued in the tile's
-//      own strip in HBM (16-bit tile-local indices; an LDS atomic per wave).  LDS and registers of hann_blocks_kernel:
-//      3 workgroups per CU.
+//      own strip in HBM (16-bit tile-local indices; an LDS atomic per wave); the certain peaks and the neighbourhoods of
+//      a tile's few undecided bases are evaluated in place, by a chain of taps in the first waves while the others store.
+//      40 KiB of LDS (image + block totals, everything else inside those two) and 128 registers: 4 workgroups per CU.
+//      CWM form: a base whose whole window lies in a run of equal inputs is written the run's value -- from a table
+//      (peaks_run_table_kernel) when the run's value is a count below PK_RUN_TABLE, by one chain of taps per run otherwise.
 //   B  exact: one workgroup per tile, 16 lanes per queued base: its 2h+1 neighbours' windows staged in LDS, one lane per
 //      neighbour evaluates tap by tap in the reference's order, the test is repeated on exact values, the base is rewritten.
 //   C  the direct fused kernel, gated: its blocks leave at once unless the vector's probe chose it or its queue overflowed.
@@ -87,6 +90,13 @@ __global__ void peaks_init_kernel (GdspPeaksCtl* ctl, GdspBatch B, uint32_t stri
 // minmax.c:1195-1216 follows on those values.  Such a tile is not listed for the exact kernel, which round 3 measured at
 // 54 us per 145 Mbp for visiting nearly every tile of a chromosome for one or two bases each.
 #define PK_NEED_INPLACE 12
+#ifndef PK_AHEAD
+#define PK_AHEAD 4                                           // passes of the store loop whose LDS reads are issued together
+#endif
+#ifndef PK_SHARE_INPLACE
+#define PK_SHARE_INPLACE 1
+#endif
+#define PK_RUN_TABLE 256                                      // CWM: the smoothed value of a run of the count x, x below this, from a table (peaks_run_table_kernel)
 // CWM (a vector of piecewise-constant input: read depth): every base of a flat stretch of such a signal ties with its
 // neighbours and is KEPT, so it needs its exact value, and the filter as it stands can only queue it -- the probe then
 // sends the vector to the direct kernel, 202 operations a base.  But a base whose whole WINDOW is one run of equal inputs
@@ -117,7 +127,7 @@ template <int W, bool FMA, bool MAX, int HH, bool PROBE, bool CWM>
 __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t tile,
                                                    const HannConsts<W, PK_E>& K, const double* __restrict__ d_taps, double fill, GdspPeaksCtl* ctl,
                                                    uint16_t* __restrict__ strip, uint32_t* __restrict__ tileCount, uint32_t cap,
-                                                   uint32_t* __restrict__ tileList, uint32_t gt)
+                                                   uint32_t* __restrict__ tileList, uint32_t gt, const double* __restrict__ runTable)
 	{
 	typedef HannGeom<W, PK_E> G;
 	constexpr double KAPPA = 16.0 * W * 2.220446049250313e-16;
@@ -136,23 +146,25 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 	__shared__ __attribute__((aligned(16))) double lds[HN_THREADS * HN_PITCH];
 	__shared__ __attribute__((aligned(16))) double tot[3][HN_THREADS];
 	constexpr int PAD_HUGE = 0, PAD_STATS = HN_PAD_STATS, PAD_NSURE = 8, PAD_QUEUED = 9, PAD_NLEAD = 10, PAD_NFLAT = 11, PAD_WLEAD = 12,
-	              PAD_ELO = 16, PAD_EHI = 16 + NW * PK_HMAX;
-	static_assert (PAD_EHI + NW * PK_HMAX <= HN_THREADS, "pad map");
+	              PAD_ELO = 16, PAD_EHI = 16 + NW * PK_HMAX, PAD_NCHAIN = PAD_EHI + NW * PK_HMAX;
+	static_assert (PAD_NCHAIN < 100, "pad map");     // (PAD_TAPS, below)
 	(void) PAD_HUGE;
 	auto padW = [&] (int i) -> uint32_t& { return *hann_pad_word (lds, i); };
 	auto padD = [&] (int i) -> double&   { return lds[i * HN_PITCH + HN_G]; };
 	auto chgBitsAt = [&] (int i) -> uint32_t& { return hann_pad_word (lds, i)[1]; };
 	constexpr int SURE_CAP = CWM? PK_SURE_CAP - PK_LEAD_CAP : PK_SURE_CAP;
 	char* const tb = reinterpret_cast<char*> (&tot[0][0]);
-	constexpr int OFF_ZERO = 0, OFF_SUREB = OFF_ZERO + 4 * (HN_THREADS/2), OFF_SUREL = OFF_SUREB + 4 * (HN_THREADS/2),
+	constexpr int OFF_CODE = 0, OFF_SUREL = OFF_CODE + 4 * HN_THREADS,
 	              OFF_NEEDL = OFF_SUREL + 2 * PK_SURE_CAP, OFF_EXACT = (OFF_NEEDL + 2 * PK_NEED_INPLACE + 7) & ~7,
 	              OFF_TAPS = OFF_EXACT + 8 * PK_NEED_INPLACE * (2*HH + 1), OFF_LEADL = OFF_TAPS + 8 * W,
-	              OFF_RUNT = (OFF_LEADL + 2 * PK_LEAD_CAP + 7) & ~7, OFF_FLATB = OFF_RUNT + (CWM? 8 * PK_LEAD_CAP : 0),
-	              OFF_LEADOF = OFF_FLATB + (CWM? 4 * (HN_THREADS/2) : 0), OFF_BLKRUN = OFF_LEADOF + (CWM? HN_THREADS : 0),
+	              OFF_RUNT = (OFF_LEADL + 2 * PK_LEAD_CAP + 7) & ~7,
+	              OFF_LEADOF = OFF_RUNT + (CWM? 8 * PK_LEAD_CAP : 0), OFF_BLKRUN = OFF_LEADOF + (CWM? HN_THREADS : 0),
 	              OFF_END = OFF_BLKRUN + (CWM? HN_THREADS : 0);
 	static_assert (OFF_END <= (int) sizeof(tot), "the lists do not fit on the block totals");
-	uint32_t* const zeroBits = reinterpret_cast<uint32_t*> (tb + OFF_ZERO);    // per block of 16 outputs (16 bits each): exact zeros
-	uint32_t* const sureBits = reinterpret_cast<uint32_t*> (tb + OFF_SUREB);   // ... peaks evaluated in place
+	// what the store loop writes on a base, two bits each, a word per block of 16 outputs: 0 `fill`, 1 an exact zero, 2 (CWM)
+	// its run's value, 3 nothing -- the base is written by the lane that evaluates it (until round 5 a bit map each: three
+	// LDS reads and their shifts per pair of outputs in a loop that is all instructions)
+	uint32_t* const codeBits = reinterpret_cast<uint32_t*> (tb + OFF_CODE);
 	uint16_t* const sureList = reinterpret_cast<uint16_t*> (tb + OFF_SUREL);
 	uint16_t* const needList = reinterpret_cast<uint16_t*> (tb + OFF_NEEDL);   // the first undecided bases: settled in place when there are no more than these
 	double*   const exactVal = reinterpret_cast<double*>   (tb + OFF_EXACT);   // ... from the exact values of their neighbourhoods
@@ -167,10 +179,9 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 	// tile), the flat bases as a bit map like the zeros', and per block of 16 outputs the number of its leader / of the
 	// leader of the run its flat bases belong to (a block meets one run: two runs' such bases lie a window apart)
 	double*   const runT     = reinterpret_cast<double*>   (tb + OFF_RUNT);
-	uint32_t* const flatBits = reinterpret_cast<uint32_t*> (tb + OFF_FLATB);
 	uint8_t*  const leaderOf = reinterpret_cast<uint8_t*>  (tb + OFF_LEADOF);
 	uint8_t*  const blockRun = reinterpret_cast<uint8_t*>  (tb + OFF_BLKRUN);
-	uint32_t& nsure = padW (PAD_NSURE), &queued = padW (PAD_QUEUED), &nlead = padW (PAD_NLEAD), &nflat = padW (PAD_NFLAT);
+	uint32_t& nsure = padW (PAD_NSURE), &queued = padW (PAD_QUEUED), &nlead = padW (PAD_NLEAD), &nflat = padW (PAD_NFLAT), &nchain = padW (PAD_NCHAIN);
 
 	const int      p         = threadIdx.x, lane = p & 63, wave = p >> 6;
 	const int64_t  keepStart = (int64_t) tile * stride;            // first output this tile stores
@@ -184,32 +195,17 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 	const int      keepLo    = h + sh;                             // smoothed values [keepLo, keepHi) are this tile's outputs
 	const int      keepHi    = (keepLo + stride < validHi)? keepLo + stride : validHi;
 
-	if (p == 0) { nsure = 0;  queued = 0;  nlead = 0;  nflat = 0; }   // (the barriers of the block sums come before their first use; staging leaves the pads alone)
+	if (p == 0) { nsure = 0;  queued = 0;  nlead = 0;  nflat = 0;  nchain = 0; }   // (the barriers of the block sums come before their first use; staging leaves the pads alone)
 	if (!PROBE && !CWM && (p < W)) tapAt (p) = d_taps[p];
 	double acc[HN_G];
 	if (!PROBE) PK_STAMP0 (lds);
-	bool direct = hann_tile_sums<W, false, PK_E, true, true, true> (lds, tot, NULL, in, n, e0, K, acc);     // (RAW: acc = S - C, the scale applied where magnitudes matter)
+	bool direct = hann_tile_sums<W, false, PK_E, true, true, true, CWM> (lds, tot, NULL, in, n, e0, K, acc);     // (RAW: acc = S - C, the scale applied where magnitudes matter)
 	if (!PROBE) PK_STAMP (lds, 3);                                 // phase 2 (the middle stretch) done in thread 0
 
 	// ---- what the tile's inputs are like (is a sign bit set, is there a nonzero magnitude below 2^-500) was found while
 	// they were staged, on the loading registers (hann_tile_sums, SSTATS: pad word PAD_STATS + wave; until round 5 a look at
 	// the own block in the LDS image here -- sixteen more LDS reads and a hundred integer instructions a thread).  CWM: the
-	// own block's change bits.
-	if (CWM)
-		{
-		const double* xb = lds + p * HN_PITCH;
-		uint32_t chg = 0;
-		long long before = (p > 0)? __double_as_longlong (lds[(p - 1) * HN_PITCH + HN_G - 1]) : 0;
-#pragma unroll
-		for (int u=0 ; u<HN_G ; u++)
-			{
-			const long long here = __double_as_longlong (xb[u]);
-			chg |= ((here != before) || ((p == 0) && (u == 0)))? (1u << u) : 0u;
-			before = here;
-			}
-		chgBitsAt (p) = chg;
-		}
-
+	// own block's change bits come from phase 1 of the block sums (CHG), in the pads' high words.
 	// the high words of the own block's smoothed values, as 32-bit integers (see the test below), and the words the
 	// neighbouring threads need: exchanged now, so that one barrier serves the statistics and the edges
 	const uint32_t away = MAX? 0u : 0x7FEFFFFFu;                   // outside the vector: beats nothing
@@ -289,26 +285,25 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 			uint32_t cwAll = 0, run2[HN_G + HH + 1];
 			if (CWM)
 				{
-				unsigned long long w0 = 0, w1 = 0;
-#pragma unroll
-				for (int j=0 ; j<4 ; j++) { w0 |= (unsigned long long) chgBitsAt (p - 7 + j) << (16*j);  w1 |= (unsigned long long) chgBitsAt (p - 3 + j) << (16*j); }
-				unsigned long long w2 = (p + 1 < HN_THREADS)? chgBitsAt (p + 1) : 0xFFFFull;
+				// In 32-bit words: a (0..31), b (32..63), c (64..95), d (96..127), e (128..143) of the string.  Base u's window is the
+				// string's positions u+13 .. u+112, so it is flat iff the last change at or before u+112 lies 100 or more back: the
+				// last change below position Q0 = 112-HH, and the NV positions from Q0 as the word m (bit i of m <-> position Q0+i).
+				const uint32_t a = chgBitsAt (p - 7) | (chgBitsAt (p - 6) << 16), b = chgBitsAt (p - 5) | (chgBitsAt (p - 4) << 16);
+				const uint32_t c = chgBitsAt (p - 3) | (chgBitsAt (p - 2) << 16), d = chgBitsAt (p - 1) | (chgBitsAt (p)     << 16);
+				const uint32_t e = (p + 1 < HN_THREADS)? chgBitsAt (p + 1) : 0xFFFFu;
 				// (the probe only counts: where changes are dense it does not look further.  The filter must: a base's leader is
 				//  found through what its neighbours' threads conclude from the same bits, so every thread concludes exactly)
-				if (!PROBE || (__popcll (w0) + __popcll (w1) + __popcll (w2) <= 8))
+				if (!PROBE || (__popc (a) + __popc (b) + __popc (c) + __popc (d) + __popc (e) <= 8))
 					{
-					cwAll = (1u << NV) - 1u;
-					auto rule_out = [&] (unsigned long long w, int base)
-						{
-						while (w != 0)
-							{
-							const int t = base + __builtin_ctzll (w);           // the change's offset in the string; it rules out u = t-112 .. t-13
-							w &= w - 1;
-							const int lo = max (t - 112 + HH, 0), hi = min (t - 13 + HH, NV - 1);
-							if (lo <= hi) cwAll &= ~((((hi - lo + 1) >= 32)? 0xFFFFFFFFu : ((1u << (hi - lo + 1)) - 1u)) << lo);
-							}
-						};
-					rule_out (w0, 0);  rule_out (w1, 64);  rule_out (w2, 128);
+					constexpr int Q0 = 112 - HH;                                // the string's position that ends the window of bit 0
+					static_assert ((Q0 > 96) && (Q0 + NV <= 144) && (NV <= 32), "the walk starts inside word d and ends inside e");
+					const uint32_t d0 = d & ((1u << (Q0 - 96)) - 1u);
+					int last = (d0 != 0)? (127 - __clz (d0)) : (c != 0)? (95 - __clz (c)) : (b != 0)? (63 - __clz (b)) : (a != 0)? (31 - __clz (a)) : -1000;
+					const uint32_t m = (d >> (Q0 - 96)) | ((e & ((1u << HH) - 1u)) << (128 - Q0));
+					// bit i's window is the positions Q0+i-99 .. Q0+i: nothing from Q0 up to it (i below m's lowest set bit), and the
+					// last change below Q0 a hundred or more back (i >= last - Q0 + 100)
+					const int from = last - Q0 + 100;
+					cwAll = (~m & (m - 1u)) & ((from <= 0)? 0xFFFFFFFFu : (from >= 32)? 0u : (0xFFFFFFFFu << from));
 					// (bases outside the vector are nobody's business)
 					const int first = blk * HN_G - HH;                          // base of bit 0
 					const int lo = max (validLo - first, 0), hi = min (validHi - first, NV);
@@ -316,7 +311,11 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 					}
 				uint32_t k2[NV];
 #pragma unroll
-				for (int i=0 ; i<NV ; i++) k2[i] = ((cwAll >> i) & 1u)? away : k[i];
+				for (int i=0 ; i<NV ; i++)
+					{
+					const uint32_t all = (uint32_t) (((int32_t) (cwAll << (31 - i))) >> 31);      // bit i over the whole word
+					k2[i] = MAX? (k[i] & ~all) : (k[i] | (all & away));                           // (away: 0 / the largest finite word, above which no word here lies)
+					}
 				runs_of (k2, run2);
 				}
 			uint32_t isFlat = 0;
@@ -460,6 +459,42 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 		return;
 		}
 
+	if (!PROBE) PK_STAMP (lds, 8);
+	// ---- CWM: the runs' leaders (a list like the certain peaks'; a block has at most one: its cw bases are one stretch), the
+	//      last leader's block at or before every block.  Before the other lists: a run's value from the table is a load from
+	//      memory, on its way while they are made
+	int    leadIncl = -1, runSlot = -1;
+	double runVal = 0.0;
+	if (CWM && !direct)
+		{
+		const int cnt = (cwLead != 0)? 1 : 0;
+		const int incl = pk_wave_sum_scan (cnt);
+		const int waveTotal = __builtin_amdgcn_readlane (incl, 63);
+		if (waveTotal != 0)
+			{
+			uint32_t base = 0;
+			if (lane == 0) base = atomicAdd (&nlead, (uint32_t) waveTotal);
+			base = (uint32_t) __shfl ((int) base, 0, 64);
+			const uint32_t at = base + (uint32_t) (incl - cnt);
+			if ((cnt != 0) && (at < PK_LEAD_CAP))
+				{
+				// the run's value: for a count below PK_RUN_TABLE (read depth is a count) the chain of taps has been walked
+				// once (peaks_run_table_kernel: the same operations in the same order on the same operands); any other
+				// value's run goes on the list for this tile's own chains
+				const int    u = __ffs ((int) cwLead) - 1;
+				const int    e = G::LO + blk * HN_G + u;                  // the window's first staged element: like all its others
+				const double X = lds[e + (e >> 4)];
+				leaderOf[blk] = (uint8_t) at;
+				if ((X >= 0.0) && (X < (double) PK_RUN_TABLE) && ((double) (int) X == X)) { runVal = runTable[(int) X];  runSlot = (int) at; }
+				else leadList[atomicAdd (&nchain, 1u)] = (uint16_t) (blk * HN_G + u);
+				}
+			}
+		leadIncl = (cwLead != 0)? blk : -1;
+		leadIncl = pk_wave_max_scan (leadIncl + 1) - 1;                  // (-1: no leader at or before this block in the wave)
+		if (lane == 63) padW (PAD_WLEAD + wave) = (uint32_t) leadIncl;
+		if ((__builtin_amdgcn_ballot_w64 (cwFlat != 0) != 0) && (lane == 0)) nflat = 1;     // (a flag: is there a flat base in the tile)
+		}
+	if (!PROBE) PK_STAMP (lds, 9);
 	// ---- certain peaks: a list in LDS (what does not fit joins the undecided)
 	if (!direct)
 		{
@@ -506,47 +541,24 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 				}
 			}
 		}
-	// ---- CWM: the runs' leaders (a list like the certain peaks'), the last leader's block at or before every block
-	int leadIncl = -1;
-	if (CWM && !direct)
-		{
-		const int cnt = __popc (cwLead);
-		const int incl = pk_wave_sum_scan (cnt);
-		const int waveTotal = __builtin_amdgcn_readlane (incl, 63);
-		if (waveTotal != 0)
-			{
-			uint32_t base = 0;
-			if (lane == 0) base = atomicAdd (&nlead, (uint32_t) waveTotal);
-			base = (uint32_t) __shfl ((int) base, 0, 64);
-			uint32_t at = base + (uint32_t) (incl - cnt);
-			uint32_t word = cwLead;
-			while (word != 0)
-				{
-				const int u = __ffs ((int) word) - 1;
-				word &= word - 1;
-				if (at < PK_LEAD_CAP) { leadList[at] = (uint16_t) (blk * HN_G + u);  leaderOf[blk] = (uint8_t) at; }
-				at++;
-				}
-			}
-		leadIncl = (cwLead != 0)? blk : -1;
-		leadIncl = pk_wave_max_scan (leadIncl + 1) - 1;                  // (-1: no leader at or before this block in the wave)
-		if (lane == 63) padW (PAD_WLEAD + wave) = (uint32_t) leadIncl;
-		int flat = __popc (cwFlat);
-		for (int off=32 ; off>0 ; off>>=1) flat += __shfl_xor (flat, off, 64);
-		if ((lane == 0) && (flat != 0)) atomicAdd (&nflat, (uint32_t) flat);
-		}
+	if (!PROBE) PK_STAMP (lds, 10);
+	if (CWM && (runSlot >= 0)) runT[runSlot] = runVal;
 	if (live)                                                      // every block of 16 has its own half word: plain stores
 		{
-		reinterpret_cast<uint16_t*> (zeroBits)[blk] = (uint16_t) isZero;
-		reinterpret_cast<uint16_t*> (sureBits)[blk] = (uint16_t) (direct? 0u : isSure);               // (what its own lane writes)
-		if (CWM) reinterpret_cast<uint16_t*> (flatBits)[blk] = (uint16_t) (direct? 0u : cwFlat);
+		auto spread = [] (uint32_t x)                                // bit i of 16 -> bit 2i
+			{
+			x = (x | (x << 8)) & 0x00FF00FFu;  x = (x | (x << 4)) & 0x0F0F0F0Fu;  x = (x | (x << 2)) & 0x33333333u;  x = (x | (x << 1)) & 0x55555555u;
+			return x;
+			};
+		// (a tile the exact kernel takes whole is written zeros and `fill` here; zero, certain and flat exclude each other)
+		codeBits[blk] = direct? spread (isZero) : (spread (isZero | isSure) | (spread (cwFlat | isSure) << 1));
 		}
 	__syncthreads ();
 	if (!PROBE) PK_STAMP (lds, 5);                                 // classification, lists, their barrier
 	const int  sure    = (int) ((nsure < SURE_CAP)? nsure : SURE_CAP);
 	const int  nq      = (int) queued;
-	const int  nl      = CWM? (int) nlead : 0;
-	if (CWM && (nl > PK_LEAD_CAP)) direct = true;                  // (more runs than a tile of 4096 can hold a hundred bases apart: never; the exact kernel takes the tile whole)
+	const int  nl      = CWM? (int) nchain : 0;                  // (the runs whose value this tile's chains find)
+	if (CWM && (nlead > PK_LEAD_CAP)) direct = true;                  // (more runs than a tile of 4096 can hold a hundred bases apart: never; the exact kernel takes the tile whole)
 	// (cap < PK_NEED_INPLACE only under the tests' GDSP_PEAKS_QUEUE_CAP: they want the strips and their overflow exercised)
 	const bool inPlace = !direct && (nq != 0) && (nq <= PK_NEED_INPLACE) && (sure + nl + nq * (2*HH + 1) <= HN_THREADS) && (cap >= PK_NEED_INPLACE);
 	if (p == 0)
@@ -556,6 +568,28 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 		if (q != 0) tileList[atomicAdd (&ctl->count, 1u)] = gt;    // (few tiles have anything for the exact kernel)
 		if (!direct && (queued > cap)) ctl->overflow = 1;          // more undecided bases than a strip holds: the vector goes through the direct kernel
 		}
+
+	// ---- CWM: which run a block's flat bases belong to: the last leader at or before the block (this wave's by the scan
+	//      above, the waves' before it by their last words).  Every pair that holds a flat base is written whole -- 16 bytes a
+	//      lane like the rest of the tile (until round 5 a lane wrote each flat base of its block by itself: sixteen 8-byte
+	//      stores a lane to sixty-four lines a wave, 1.5 x the tile's bytes at the memory).  With every run's value out of the
+	//      table (read depth) the flat bases go out with the rest of the tile, beside the certain peaks' chains; a tile that
+	//      has a run's value to find writes them behind those chains
+	auto resolve_runs = [&] ()
+		{
+		if (CWM && (cwFlat != 0))
+			{
+			int lb = leadIncl;
+			for (int w=0 ; w<wave ; w++) lb = max (lb, (int) padW (PAD_WLEAD + w));
+			blockRun[blk] = leaderOf[(lb >= 0)? lb : 0];             // (lb >= 0: a flat base's run has a leader at or before it)
+			}
+		};
+	const bool flatNow = CWM && !direct && (nflat != 0) && (nl == 0), flatLater = CWM && !direct && (nflat != 0) && (nl != 0);    // (uniform)
+	// (the undecided bases settled in place are left to their lanes by the store loop: marked now, so that the waves without
+	//  a chain of taps to walk can store while the others walk theirs)
+	if (inPlace && (p < nq)) atomicOr (&codeBits[needList[p] >> 4], 3u << (2 * (needList[p] & 15)));
+	if (flatNow) resolve_runs ();
+	if (flatNow || inPlace) __syncthreads ();                      // (uniform)
 
 	// ---- exact values of the certain peaks -- and of the neighbourhoods of the undecided bases settled in place -- one
 	//      lane each, from the staged inputs: tap by tap in the reference's order (sum.c:655-663); a certain peak is written
@@ -608,13 +642,59 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 			__builtin_amdgcn_sched_barrier (0);
 			}
 		if (p < sure)  out[compStart + c] = a;
-		else if (lead) runT[CWM? p - sure - nbrs : 0] = a;         // the value of every base of the run whose window lies inside it
+		else if (lead) runT[CWM? leaderOf[c >> 4] : 0] = a;        // the value of every base of the run whose window lies inside it
 		else           exactVal[p - sure] = inside? a : (MAX? -INFINITY : INFINITY);
 		}
+	if (!PROBE) PK_STAMP (lds, 6);                                 // thread 0's exact values (wave 0's chain of taps)
+	// ---- the tile's other outputs: zero where an exact zero stands, `fill` elsewhere (a queued base is rewritten by the
+	//      exact kernel), CWM: its run's value on a flat base; pairs, 16 bytes per lane; a pair that holds a certain peak
+	//      leaves that element to its lane
+	// (a wave that has evaluated exact values has done its share: the others divide the tile between them, and the
+	//  workgroup is done when the slower of the two jobs is, not after one behind the other -- round 5's stamps: the chain
+	//  of taps and the store loop were 17 % and 15 % of a workgroup's life, one behind the other in wave 0.  Giving wave 0
+	//  a seventh of the stores for balance made the loop's own cost in wave 0 four times what it saved)
+	// (four passes' LDS reads -- up to three levels of them, bits -> run -> value -- then their stores: a pass at a time
+	//  waits the levels out once per pass, a sixth of a tile's life on read depth by round 5's stamps)
+	double* dst = out + keepStart;
+	auto store_pairs = [&] (int q, int qn, bool flatToo, bool flatOnly)
+		{
+		constexpr int AHEAD = PK_AHEAD;
+		for (int c0 = keepLo + 2*q ; (q >= 0) && (c0 < keepHi) ; c0 += AHEAD * 2*qn)      // (keepLo is even)
+			{
+			uint32_t code[AHEAD];
+			double   T[AHEAD];
+#pragma unroll
+			for (int j=0 ; j<AHEAD ; j++)
+				{
+				const int c  = c0 + j * 2*qn;
+				const int cr = min (c, G::OUT - 2);                      // (a pair past the tile's end reads the last words and stores nothing)
+				code[j] = (codeBits[cr >> 4] >> (2 * (cr & 15))) & 15u;   // (c is even: a pair lies in one block)
+				T[j]    = (CWM && flatToo)? runT[blockRun[cr >> 4] & (PK_LEAD_CAP - 1)] : 0.0;      // (a block without a flat base: any run's)
+				}
+#pragma unroll
+			for (int j=0 ; j<AHEAD ; j++)
+				{
+				const int c = c0 + j * 2*qn;
+				if (c >= keepHi) continue;
+				const uint32_t a0 = code[j] & 3u, a1 = code[j] >> 2;
+				const bool     fl = CWM && ((a0 == 2u) || (a1 == 2u));
+				if (CWM && (fl? !flatToo : flatOnly)) continue;          // (a pair with a flat base: with the others, or in the pass behind the leaders' chains)
+				const double r0 = (a0 == 2u)? T[j] : (a0 == 1u)? 0.0 : fill, r1 = (a1 == 2u)? T[j] : (a1 == 1u)? 0.0 : fill;
+				if (((a0 != 3u) && (a1 != 3u)) && (c + 1 < keepHi)) gdsp_st2 (reinterpret_cast<double2*> (dst + (c - keepLo)), make_double2 (r0, r1));
+				else
+					{
+					if (a0 != 3u)                        dst[c - keepLo]     = r0;
+					if ((a1 != 3u) && (c + 1 < keepHi)) dst[c - keepLo + 1] = r1;
+					}
+				}
+			}
+		};
+	const int  chainWaves = (evals + 63) / 64;                     // waves 0 .. chainWaves-1 ran the chain of taps (uniform)
+	const bool share      = (chainWaves >= 1) && (chainWaves < NW) && (!inPlace || (PK_SHARE_INPLACE && (chainWaves == 1)));
+	store_pairs (share? p - 64 * chainWaves : p, share? HN_THREADS - 64 * chainWaves : HN_THREADS, flatNow, false);
 	if (inPlace)                                                   // (uniform over the workgroup)
 		{
-		if (p < nq) atomicOr (&sureBits[needList[p] >> 5], 1u << (needList[p] & 31));    // the store loop below leaves these to their lanes
-		__syncthreads ();
+		__syncthreads ();                                          // (the neighbourhoods' exact values are in)
 		if (p < nq)
 			{
 			const double* v = &exactVal[p * (2*HH + 1)];
@@ -625,61 +705,13 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 			out[compStart + needList[p]] = (MAX? (ext > centre) : (ext < centre))? fill : centre;
 			}
 		}
-
-	if (!PROBE) PK_STAMP (lds, 6);                                 // thread 0's exact values (wave 0's chain of taps), in-place settling
-	// ---- the tile's other outputs: zero where an exact zero stands, `fill` elsewhere (a queued base is rewritten by the
-	//      exact kernel); pairs, 16 bytes per lane; a pair that holds a certain peak leaves that element to its lane
-	// (a wave that has evaluated exact values has done its share: the others divide the tile between them, and the
-	//  workgroup is done when the slower of the two jobs is, not after one behind the other -- round 5's stamps: the chain
-	//  of taps and the store loop were 17 % and 15 % of a workgroup's life, one behind the other in wave 0.  Giving wave 0
-	//  a seventh of the stores for balance made the loop's own cost in wave 0 four times what it saved)
-	double* dst = out + keepStart;
-	const int  chainWaves = (evals + 63) / 64;                     // waves 0 .. chainWaves-1 ran the chain of taps (uniform)
-	const bool share      = (chainWaves >= 1) && (chainWaves < NW) && !inPlace;
-	const int  q          = share? p - 64 * chainWaves : p, qn = share? HN_THREADS - 64 * chainWaves : HN_THREADS;
-	for (int c = keepLo + 2*q ; (q >= 0) && (c < keepHi) ; c += 2*qn)     // (keepLo is even)
+	// (the flat bases of a tile with a run outside the table after the store loop, not before it: their values wait for the
+	//  leaders' chains in the first waves, and the other waves have the tile's stores to issue meanwhile)
+	if (flatLater)                                                 // (uniform)
 		{
-		const uint32_t two  = zeroBits[c >> 5] >> (c & 31);
-		const uint32_t skip = (sureBits[c >> 5] >> (c & 31)) & 3u;
-		if (CWM && (((flatBits[c >> 5] >> (c & 31)) & 3u) != 0)) continue;      // (a pair with a flat base: the pass behind the leaders' chains)
-		const double r0 = (two & 1u)? 0.0 : fill, r1 = (two & 2u)? 0.0 : fill;
-		if ((skip == 0) && (c + 1 < keepHi)) gdsp_st2 (reinterpret_cast<double2*> (dst + (c - keepLo)), make_double2 (r0, r1));
-		else
-			{
-			if ((skip & 1u) == 0)                        dst[c - keepLo]     = r0;
-			if (((skip & 2u) == 0) && (c + 1 < keepHi)) dst[c - keepLo + 1] = r1;
-			}
-		}
-	// (CWM's flat bases after the store loop, not before it: their values wait for the leaders' chains in the first waves,
-	//  and the other waves have the tile's stores to issue meanwhile)
-	if (CWM && !direct && (nflat != 0))                            // (uniform) the kept bases of flat stretches: their run's value
-		{
-		// which run a block's flat bases belong to: the last leader at or before the block (this wave's by the scan above, the
-		// waves' before it by their last words); then, behind the barrier the chains end at, every pair that holds a flat base
-		// is written whole -- 16 bytes a lane like the rest of the tile (until round 5 a lane wrote each flat base of its
-		// block by itself: sixteen 8-byte stores a lane to sixty-four lines a wave, 1.5 x the tile's bytes at the memory)
-		if (cwFlat != 0)
-			{
-			int lb = leadIncl;
-			for (int w=0 ; w<wave ; w++) lb = max (lb, (int) padW (PAD_WLEAD + w));
-			blockRun[blk] = leaderOf[(lb >= 0)? lb : 0];             // (lb >= 0: a flat base's run has a leader at or before it)
-			}
+		resolve_runs ();
 		__syncthreads ();
-		for (int c = keepLo + 2*p ; c < keepHi ; c += 2*HN_THREADS)
-			{
-			const uint32_t fl = (flatBits[c >> 5] >> (c & 31)) & 3u;
-			if (fl == 0) continue;
-			const uint32_t two  = zeroBits[c >> 5] >> (c & 31);
-			const uint32_t skip = (sureBits[c >> 5] >> (c & 31)) & 3u;
-			const double   T    = runT[blockRun[c >> 4]];
-			const double r0 = (fl & 1u)? T : (two & 1u)? 0.0 : fill, r1 = (fl & 2u)? T : (two & 2u)? 0.0 : fill;
-			if ((skip == 0) && (c + 1 < keepHi)) gdsp_st2 (reinterpret_cast<double2*> (dst + (c - keepLo)), make_double2 (r0, r1));
-			else
-				{
-				if ((skip & 1u) == 0)                        dst[c - keepLo]     = r0;
-				if (((skip & 2u) == 0) && (c + 1 < keepHi)) dst[c - keepLo + 1] = r1;
-				}
-			}
+		store_pairs (p, HN_THREADS, true, true);
 		}
 
 	if (!PROBE) PK_STAMP (lds, 7);                                 // the store loop issued
@@ -694,7 +726,7 @@ void peaks_probe_kernel (GdspBatch B, HannConsts<W, PK_E> K, GdspPeaksCtl* ctl)
 	const uint32_t take  = (tiles < PK_PROBE_TILES)? tiles : PK_PROBE_TILES;
 	if (j >= take) return;
 	const uint32_t tile = (uint32_t) (((uint64_t) j * tiles) / take);
-	peaks_filter_tile<W, false, MAX, HH, true, CWM> (B.in[v], NULL, B.n[v], tile, K, NULL, 0.0, &ctl[v], NULL, NULL, 0, NULL, 0);
+	peaks_filter_tile<W, false, MAX, HH, true, CWM> (B.in[v], NULL, B.n[v], tile, K, NULL, 0.0, &ctl[v], NULL, NULL, 0, NULL, 0, NULL);
 	}
 
 // The filter over the vectors of ONE form: plain, or (CWM) the form for vectors of flat stretches that writes a run's value
@@ -707,7 +739,7 @@ struct PeaksSub { uint32_t v[GDSP_BATCH_MAX], gt0[GDSP_BATCH_MAX]; };
 template <int W, bool FMA, bool MAX, int HH, bool CWM>
 __global__ __launch_bounds__(HN_THREADS) __attribute__((amdgpu_waves_per_eu(PK_WAVES, PK_WAVES)))
 void peaks_filter_kernel (GdspBatch S, PeaksSub M, HannConsts<W, PK_E> K, const double* __restrict__ d_taps, double fill, GdspPeaksCtl* ctl,
-                          uint16_t* strips, uint32_t* counts, uint32_t cap, uint32_t* tileList, int gate)
+                          uint16_t* strips, uint32_t* counts, uint32_t cap, uint32_t* tileList, int gate, const double* __restrict__ runTable)
 	{
 	const double* in;  double* out;  uint32_t n, i;
 	const uint32_t tile = gdsp_batch_tile (S, in, out, n, &i);
@@ -716,7 +748,7 @@ void peaks_filter_kernel (GdspBatch S, PeaksSub M, HannConsts<W, PK_E> K, const 
 	//  may issue its tile's)
 	if (gate && gdsp_peaks_takes_direct (ctl[v])) return;
 	peaks_filter_tile<W, FMA, MAX, HH, false, CWM> (in, out, n, tile, K, d_taps, fill, &ctl[v], strips + (size_t) gt * cap, counts + gt, cap,
-	                                                tileList + M.gt0[i], gt);
+	                                                tileList + M.gt0[i], gt, runTable);
 	}
 
 // The exact kernel, for the bases whose comparison needs exact values (ties and near-ties): a workgroup takes a tile from
@@ -810,7 +842,20 @@ extern "C" int gdsp_peaks_stamps (unsigned long long* out, int clear)
 #endif
 
 // ------------------------------------------------------------------- host ----
-struct PeaksWork { int device;  void* stream;  GdspPeaksCtl* ctl;  uint16_t* strips;  uint32_t* counts;  uint32_t* tileList;  size_t tiles; };
+struct PeaksWork { int device;  void* stream;  GdspPeaksCtl* ctl;  uint16_t* strips;  uint32_t* counts;  uint32_t* tileList;  size_t tiles;  double* runTable; };
+
+// The smoothed value of a base whose whole window holds the count x: the chain of taps of peaks_filter_tile (and of the
+// reference, sum.c:655-663) on W equal operands -- tap by tap, ascending, multiply then add from 0.0; entry PK_RUN_TABLE + x
+// the same with fused multiply-adds (--smooth=fma).  It depends on the window alone, so it is walked once per (device,
+// stream), on that stream, before the first filter launch there.
+template <int W>
+__global__ void peaks_run_table_kernel (const double* __restrict__ d_taps, double* __restrict__ table)
+	{
+	const double x = (double) threadIdx.x;
+	double a = 0.0, f = 0.0;
+	for (int k=0 ; k<W ; k++) { a = a + d_taps[k] * x;  f = __builtin_fma (d_taps[k], x, f); }
+	table[threadIdx.x] = a;  table[PK_RUN_TABLE + threadIdx.x] = f;
+	}
 static std::vector<PeaksWork> peaksWork;
 static std::mutex peaksWorkLock;
 
@@ -824,8 +869,14 @@ static int peaks_work (void* stream, size_t tiles, PeaksWork* out)
 	for (PeaksWork& e : peaksWork) { if ((e.device == device) && (e.stream == stream)) w = &e; }
 	if (w == NULL)
 		{
-		PeaksWork e = { device, stream, NULL, NULL, NULL, NULL, 0 };
+		PeaksWork e = { device, stream, NULL, NULL, NULL, NULL, 0, NULL };
+		const double* d_taps = NULL;
+		int rc = gdsp_smooth_taps_device (101, &d_taps);
+		if (rc != GDSP_OK) return rc;
 		GDSP_HIP_TRY (hipMalloc ((void**) &e.ctl, GDSP_BATCH_MAX * sizeof(GdspPeaksCtl)));
+		GDSP_HIP_TRY (hipMalloc ((void**) &e.runTable, 2 * PK_RUN_TABLE * sizeof(double)));
+		hipLaunchKernelGGL ((peaks_run_table_kernel<101>), dim3(1), dim3(PK_RUN_TABLE), 0, gdsp_stream (stream), d_taps, e.runTable);
+		GDSP_LAUNCH_CHECK ();
 		peaksWork.push_back (e);
 		w = &peaksWork.back ();
 		}
@@ -925,7 +976,7 @@ static int peaks_launch (const gdsp_batch_item* items, int count, const HannCons
 		GdspBatch S;
 		gdsp_batch_make (S, sub.data (), (int) sub.size (), [] (uint32_t n) { return ((uint64_t) n + stride - 1) / stride; });
 		const dim3 grid (S.tile0[GDSP_BATCH_MAX]), block (HN_THREADS);
-#define PK_FILTER(FMAV, CWMV) hipLaunchKernelGGL ((peaks_filter_kernel<101, FMAV, MAX, HH, CWMV>), grid, block, 0, s, S, M, K, d_taps, fill, w.ctl, w.strips, w.counts, cap, w.tileList, flatForm? 0 : 1)
+#define PK_FILTER(FMAV, CWMV) hipLaunchKernelGGL ((peaks_filter_kernel<101, FMAV, MAX, HH, CWMV>), grid, block, 0, s, S, M, K, d_taps, fill, w.ctl, w.strips, w.counts, cap, w.tileList, flatForm? 0 : 1, w.runTable + (FMAV? PK_RUN_TABLE : 0))
 		if (form == 1) { if (fma) PK_FILTER (true, true);   else PK_FILTER (false, true); }
 		else           { if (fma) PK_FILTER (true, false);  else PK_FILTER (false, false); }
 #undef PK_FILTER

@@ -657,6 +657,15 @@ def _filter_cases(n, rng):
         x[at: at + lens[k % len(lens)]] = vals[(k * 5) % len(vals)]
         at += lens[k % len(lens)]; k += 1
     cases["runs about a window long"] = x
+    # the flat form takes a run's value from a table when it is a count below 256 and walks the chain of taps otherwise:
+    # counts either side of the table's end, values between counts, counts past 2^31, all three in a tile
+    x = np.empty(n); at = 0; k = 0
+    lens = [130, 240, 101, 400, 180, 111, 350]
+    vals = [255.0, 254.0, 256.0, 255.0, 257.0, 255.5, 1.0, 2.0 ** 31, 3.0, 2.0 ** 40, 12.0, 1e6, 0.5, 200.0, 4294967296.0 + 7.0]
+    while at < n:
+        x[at: at + lens[k % len(lens)]] = vals[(k * 4) % len(vals)]
+        at += lens[k % len(lens)]; k += 1
+    cases["runs of counts about the table's end"] = x
     return cases
 
 

@@ -39,6 +39,8 @@ for kind, mode in (("real-valued", 1), ("read depth", 0)):
         c = buf[i] / max(tiles, 1)
         print("   %-44s %9.0f   (+%.0f)" % (names[i], c, c - prev))
         prev = c
+    for i, what in ((8, "... classified (before the lists)"), (9, "... leaders listed"), (10, "... all lists made")):
+        print("   %-44s %9.0f" % (what, buf[i] / max(tiles, 1)))
 PY
 touch genodsp_amd/csrc/gdsp_peaks.hip
 make -C genodsp_amd/csrc > /dev/null 2>&1
