@@ -118,6 +118,9 @@ __device__ __forceinline__ long long pk_stamp_get (double* lds)
 // and, per wave, pad word HN_PAD_STATS + wave = { bit 0: a sign bit is set, bit 1: 0 < |x| < 2^-500 }.  The same elements
 // as the 256 own blocks: the whole staged tile.
 #define HN_PAD_STATS 4
+#ifndef HN_REDO
+#define HN_REDO 1
+#endif
 // CHG (gdsp_peaks.hip, the form for flat stretches): phase 1 leaves in the HIGH word of the own pad which of the block's
 // elements differ from the element before them (bit u), found on the values it reads anyway
 // RAW (gdsp_peaks.hip): the results are left without the window's normalisation (acc = S - C, not scale x (S - C)): the
@@ -270,6 +273,30 @@ __device__ __forceinline__ bool hann_tile_sums (double* lds, double (*tot)[HN_TH
 			Tr += __builtin_fma (br, K.rotC[d-1], -(bi * K.rotS[d-1]));
 			Ti += __builtin_fma (br, K.rotS[d-1],   bi * K.rotC[d-1]);
 			}
+		// the own block's prefix sums, as phase 1 left them -- but the last ones are the block's totals, read back from the
+		// totals, and the first HN_REDO are made again from the block's first elements (the same operations on the same
+		// operands) where the last windows want them: 48 doubles alive from phase 1 to the end of phase 2 are more than the
+		// 128 registers of four waves per SIMD hold beside the sums in flight, and what the compiler spilled (5-7 doubles
+		// a lane, written and read back through scratch memory) went to memory with the tile's outputs
+		auto prefix = [&] (int u, double& q0, double& qr, double& qi)
+			{
+			if (u == HN_G - 1) { q0 = tot[0][p];  qr = tot[1][p];  qi = tot[2][p]; }
+			else if (u < HN_REDO)
+				{
+				const double* xb = lds + p * HN_PITCH;
+				q0 = 0.0;  qr = 0.0;  qi = 0.0;
+#pragma unroll
+				for (int v=0 ; v<HN_REDO ; v++)
+					{
+					if (v > u) continue;
+					const double x = xb[v];
+					q0 += x;
+					qr  = __builtin_fma (x, K.ownC[v], qr);
+					qi  = __builtin_fma (x, K.ownS[v], qi);
+					}
+				}
+			else { q0 = P0[u];  qr = Pr[u];  qi = Pi[u]; }
+			};
 		const double* lb = lds + (p - G::DQ) * HN_PITCH;            // block of the left ends of s >= DR
 		const double* la = lb - HN_PITCH + (HN_G - G::DR);          // last DR elements of the block before
 		double s0 = 0.0, sr = 0.0, si = 0.0;
@@ -282,9 +309,11 @@ __device__ __forceinline__ bool hann_tile_sums (double* lds, double (*tot)[HN_TH
 			si  = __builtin_fma (x, K.leftS[u], si);
 			if (u < HN_G)                                           // left end of the stretch whose right end is own[u]
 				{
-				const double z0 = (s0 + T0) + P0[u];
-				const double zr = (sr + Tr) + Pr[u];
-				const double zi = (si + Ti) + Pi[u];
+				double q0, qr, qi;
+				prefix (u, q0, qr, qi);
+				const double z0 = (s0 + T0) + q0;
+				const double zr = (sr + Tr) + qr;
+				const double zi = (si + Ti) + qi;
 				const double c  = __builtin_fma (K.demC[u], zr, -(K.demS[u] * zi));
 				acc[u] = RAW? ((EE == 0)? (z0 - c) : ((z0 - c) + acc[u])) : K.scale * ((z0 - c) + acc[u]);
 				}
@@ -298,9 +327,11 @@ __device__ __forceinline__ bool hann_tile_sums (double* lds, double (*tot)[HN_TH
 			s0 += x;
 			sr  = __builtin_fma (x, K.leftC[u], sr);
 			si  = __builtin_fma (x, K.leftS[u], si);
-			const double z0 = (s0 + T0) + P0[u];
-			const double zr = (sr + Tr) + Pr[u];
-			const double zi = (si + Ti) + Pi[u];
+			double q0, qr, qi;
+			prefix (u, q0, qr, qi);
+			const double z0 = (s0 + T0) + q0;
+			const double zr = (sr + Tr) + qr;
+			const double zi = (si + Ti) + qi;
 			const double c  = __builtin_fma (K.demC[u], zr, -(K.demS[u] * zi));
 			acc[u] = RAW? ((EE == 0)? (z0 - c) : ((z0 - c) + acc[u])) : K.scale * ((z0 - c) + acc[u]);
 			}

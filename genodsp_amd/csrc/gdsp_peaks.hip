@@ -142,12 +142,12 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 	//     high word = chgBits[p] (CWM); the edge values of the double-precision path take whole pads (they come after the
 	//     change bits' last use)
 	//   * what is written only after the barrier that follows the block sums' last read of the totals (B1 below) ON the
-	//     totals: the bit maps, the lists, the exact values, the window's taps, CWM's run values
+	//     totals: the blocks' code words, the lists, the exact values, CWM's run values
 	__shared__ __attribute__((aligned(16))) double lds[HN_THREADS * HN_PITCH];
 	__shared__ __attribute__((aligned(16))) double tot[3][HN_THREADS];
 	constexpr int PAD_HUGE = 0, PAD_STATS = HN_PAD_STATS, PAD_NSURE = 8, PAD_QUEUED = 9, PAD_NLEAD = 10, PAD_NFLAT = 11, PAD_WLEAD = 12,
 	              PAD_ELO = 16, PAD_EHI = 16 + NW * PK_HMAX, PAD_NCHAIN = PAD_EHI + NW * PK_HMAX;
-	static_assert (PAD_NCHAIN < 100, "pad map");     // (PAD_TAPS, below)
+	static_assert (PAD_NCHAIN < 210, "pad map");     // (PK_STAMPS keeps its clock in pads 210 and 211)
 	(void) PAD_HUGE;
 	auto padW = [&] (int i) -> uint32_t& { return *hann_pad_word (lds, i); };
 	auto padD = [&] (int i) -> double&   { return lds[i * HN_PITCH + HN_G]; };
@@ -156,7 +156,7 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 	char* const tb = reinterpret_cast<char*> (&tot[0][0]);
 	constexpr int OFF_CODE = 0, OFF_SUREL = OFF_CODE + 4 * HN_THREADS,
 	              OFF_NEEDL = OFF_SUREL + 2 * PK_SURE_CAP, OFF_EXACT = (OFF_NEEDL + 2 * PK_NEED_INPLACE + 7) & ~7,
-	              OFF_TAPS = OFF_EXACT + 8 * PK_NEED_INPLACE * (2*HH + 1), OFF_LEADL = OFF_TAPS + 8 * W,
+	              OFF_LEADL = OFF_EXACT + 8 * PK_NEED_INPLACE * (2*HH + 1),
 	              OFF_RUNT = (OFF_LEADL + 2 * PK_LEAD_CAP + 7) & ~7,
 	              OFF_LEADOF = OFF_RUNT + (CWM? 8 * PK_LEAD_CAP : 0), OFF_BLKRUN = OFF_LEADOF + (CWM? HN_THREADS : 0),
 	              OFF_END = OFF_BLKRUN + (CWM? HN_THREADS : 0);
@@ -168,12 +168,6 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 	uint16_t* const sureList = reinterpret_cast<uint16_t*> (tb + OFF_SUREL);
 	uint16_t* const needList = reinterpret_cast<uint16_t*> (tb + OFF_NEEDL);   // the first undecided bases: settled in place when there are no more than these
 	double*   const exactVal = reinterpret_cast<double*>   (tb + OFF_EXACT);   // ... from the exact values of their neighbourhoods
-	// the window, for the exact values (as scalar operands its 202 words crowd out the block sums' constants): in the plain
-	// form in pads PAD_TAPS .. PAD_TAPS + W - 1, fetched while the tile's loads are in flight; CWM keeps its change bits in
-	// every pad's high word, so there the taps go on the block totals, fetched behind B1 (and waited for before the lists' barrier)
-	constexpr int PAD_TAPS = 100;
-	static_assert (PAD_TAPS + W <= HN_THREADS, "pad map");
-	auto tapAt = [&] (int k) -> double& { return CWM? reinterpret_cast<double*> (tb + OFF_TAPS)[k] : lds[(PAD_TAPS + k) * HN_PITCH + HN_G]; };
 	uint16_t* const leadList = reinterpret_cast<uint16_t*> (tb + OFF_LEADL);
 	// CWM: a run's value per LEADER (the first base of the run in the tile whose window lies inside it; at most PK_LEAD_CAP a
 	// tile), the flat bases as a bit map like the zeros', and per block of 16 outputs the number of its leader / of the
@@ -196,7 +190,6 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 	const int      keepHi    = (keepLo + stride < validHi)? keepLo + stride : validHi;
 
 	if (p == 0) { nsure = 0;  queued = 0;  nlead = 0;  nflat = 0;  nchain = 0; }   // (the barriers of the block sums come before their first use; staging leaves the pads alone)
-	if (!PROBE && !CWM && (p < W)) tapAt (p) = d_taps[p];
 	double acc[HN_G];
 	if (!PROBE) PK_STAMP0 (lds);
 	bool direct = hann_tile_sums<W, false, PK_E, true, true, true, CWM> (lds, tot, NULL, in, n, e0, K, acc);     // (RAW: acc = S - C, the scale applied where magnitudes matter)
@@ -227,7 +220,6 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 		}
 	__syncthreads ();                                              // B1: nobody reads the block totals any more
 	if (!PROBE) PK_STAMP (lds, 4);                                 // statistics, high words, edges, barrier B1
-	if (!PROBE && CWM && (p < W)) tapAt (p) = d_taps[p];           // (on the totals; read after the next barrier)
 #pragma unroll
 	for (int t=0 ; t<HH ; t++)
 		{
@@ -612,9 +604,11 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 		for (int j=0 ; j<16 ; j++) at16[j] = lds + (e + (e >> 4)) + ((j >= 16 - (e & 15))? 1 : 0);
 		// (in batches of reads, then products, then sums: left to itself the compiler fetches two to four taps ahead and the
 		//  chain -- wave 0's, while the workgroup's LDS waits for it -- sits out an LDS round trip every few taps: 55 cycles
-		//  a tap by round 5's stamps, 41 in batches)
+		//  a tap by round 5's stamps, 41 in batches.  The window's taps as SCALAR operands, fetched a batch at a time from
+		//  memory where the chain wants them: as kernel arguments their 202 words crowded out the block sums' constants, and
+		//  as a second LDS read per tap -- a copy of the window in every tile's LDS -- they cost the chain 2 % of the kernel)
 		double a = 0.0;
-		constexpr int KB = 17, NB = (W + KB - 1) / KB;               // 101 = 5 x 17 + 16
+		constexpr int KB = 16, NB = (W + KB - 1) / KB;               // (a 64-byte scalar load is 8 taps)
 #pragma unroll
 		for (int b=0 ; b<NB ; b++)
 			{
@@ -623,7 +617,7 @@ __device__ __forceinline__ void peaks_filter_tile (const double* __restrict__ in
 			for (int j=0 ; j<KB ; j++)
 				{
 				const int k = b * KB + j;
-				if (k < W) { xv[j] = at16[k & 15][k + (k >> 4)];  wv[j] = tapAt (k); }
+				if (k < W) { xv[j] = at16[k & 15][k + (k >> 4)];  wv[j] = d_taps[k]; }
 				}
 			__builtin_amdgcn_sched_barrier (0);                      // every read of the batch before its first product
 			if (FMA)
