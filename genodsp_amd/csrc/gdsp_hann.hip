@@ -162,6 +162,9 @@ struct HannRT
 // 448-thread workgroups per CU were slower at every window tried) and adds
 // the blocks between in two levels: the totals of aligned groups of 16 blocks, plus at most 15 single blocks at either
 // end of the range (additions only, as before; fewer roundings than one by one).
+#ifndef HN_RT_REDO
+#define HN_RT_REDO 4
+#endif
 template <int E, int THREADS, bool SCAN>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3)))
 void hann_blocks_rt_kernel (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t ntiles,
@@ -315,9 +318,26 @@ void hann_blocks_rt_kernel (const double* __restrict__ in, double* __restrict__ 
 			si  = __builtin_fma (x, K.leftS[u], si);
 			if (u < HN_G)
 				{
-				const double z0 = (s0 + T0) + P0[u];
-				const double zr = (sr + Tr) + Pr[u];
-				const double zi = (si + Ti) + Pi[u];
+				// (the first prefix sums are made again from the block's first elements -- the same operations on the same
+				//  operands -- instead of kept from phase 1 to the walk's end: gdsp_hann_tile.h, phase 2)
+				double q0 = P0[u], qr = Pr[u], qi = Pi[u];
+				if (u < HN_RT_REDO)
+					{
+					const double* xb = lds + p * HN_PITCH;
+					q0 = 0.0;  qr = 0.0;  qi = 0.0;
+#pragma unroll
+					for (int v=0 ; v<HN_RT_REDO ; v++)
+						{
+						if (v > u) continue;
+						const double xv = xb[v];
+						q0 += xv;
+						qr  = __builtin_fma (xv, K.ownC[v], qr);
+						qi  = __builtin_fma (xv, K.ownS[v], qi);
+						}
+					}
+				const double z0 = (s0 + T0) + q0;
+				const double zr = (sr + Tr) + qr;
+				const double zi = (si + Ti) + qi;
 				const double c  = __builtin_fma (K.demC[u], zr, -(K.demS[u] * zi));
 				acc[u] = K.scale * ((z0 - c) + acc[u]);
 				}
