@@ -57,6 +57,16 @@
 
 #include "gdsp_hann_tile.h"
 
+// HN_FOUR: four workgroups per CU -- 40 960 bytes of LDS (the waves' verdicts in the image's pad slots) and 128 registers
+// (the direct taps at the windows' ends behind phase 2, the prefix sums' ends re-made there: gdsp_hann_tile.h)
+#ifndef HN_FOUR
+#define HN_FOUR 1
+#endif
+#if HN_FOUR
+#define HN_FOUR_WAVES __attribute__((amdgpu_waves_per_eu(4, 4)))
+#else
+#define HN_FOUR_WAVES
+#endif
 template <int W>
 __device__ __forceinline__ void hann_blocks_tile (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t tile,
                                                   const HannConsts<W>& K, const double* __restrict__ taps)
@@ -64,7 +74,11 @@ __device__ __forceinline__ void hann_blocks_tile (const double* __restrict__ in,
 	typedef HannGeom<W> G;
 	__shared__ __attribute__((aligned(16))) double lds[HN_THREADS * HN_PITCH];
 	__shared__ double tot[3][HN_THREADS];
+#if HN_FOUR
+	uint32_t* const huge = NULL;                                   // (the waves' verdicts in the image's pad slots: 40 KiB to the byte)
+#else
 	__shared__ __attribute__((aligned(16))) uint32_t huge[HN_THREADS/64];
+#endif
 
 	const int64_t  out0 = (int64_t) tile * G::OUT;
 	const int64_t  e0   = out0 - G::LEAD;                         // first staged element (even)
@@ -72,7 +86,7 @@ __device__ __forceinline__ void hann_blocks_tile (const double* __restrict__ in,
 	const bool     live = (p >= G::HALO_L) && (p < HN_THREADS - G::HALO_R);
 
 	double acc[HN_G];
-	const bool direct = hann_tile_sums<W> (lds, tot, huge, in, n, e0, K, acc);
+	const bool direct = hann_tile_sums<W, false, HN_E, HN_FOUR != 0, false, false, false, HN_FOUR != 0> (lds, tot, huge, in, n, e0, K, acc);
 	if (direct) hann_direct_tile (lds, taps, W, G::LO, G::OUT);    // (output o sits under taps LO+o .. LO+o+W-1 of the staged elements)
 	else
 		{
@@ -111,13 +125,13 @@ __device__ __forceinline__ void hann_blocks_tile (const double* __restrict__ in,
 	}
 
 template <int W>
-__global__ __launch_bounds__(HN_THREADS)
+__global__ __launch_bounds__(HN_THREADS) HN_FOUR_WAVES
 void hann_blocks_kernel (const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t ntiles,
                          HannConsts<W> K, const double* __restrict__ taps)
 	{ hann_blocks_tile<W> (in, out, n, gdsp_xcd_tile (blockIdx.x, ntiles), K, taps); }
 
 template <int W>                                                  // one grid over every vector of the table (gdsp_common.h)
-__global__ __launch_bounds__(HN_THREADS)
+__global__ __launch_bounds__(HN_THREADS) HN_FOUR_WAVES
 void hann_blocks_batch_kernel (GdspBatch B, HannConsts<W> K, const double* __restrict__ taps)
 	{
 	const double* in;  double* out;  uint32_t n;

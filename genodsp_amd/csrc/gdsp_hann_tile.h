@@ -126,7 +126,7 @@ __device__ __forceinline__ long long pk_stamp_get (double* lds)
 // RAW (gdsp_peaks.hip): the results are left without the window's normalisation (acc = S - C, not scale x (S - C)): the
 // interval test on high words compares, and a positive factor changes no comparison; with EE = 0 there is no direct-tap
 // sum to add either -- 32 vector instructions a thread less
-template <int W, bool STATS = false, int EE = HN_E, bool PADS = false, bool SSTATS = false, bool RAW = false, bool CHG = false>
+template <int W, bool STATS = false, int EE = HN_E, bool PADS = false, bool SSTATS = false, bool RAW = false, bool CHG = false, bool LATE0 = false>
 __device__ __forceinline__ bool hann_tile_sums (double* lds, double (*tot)[HN_THREADS], uint32_t* huge,
                                                 const double* __restrict__ in, uint32_t n, int64_t e0,
                                                 const HannConsts<W, EE>& K, double (&acc)[HN_G], uint32_t (*stats)[2] = NULL)
@@ -180,31 +180,38 @@ __device__ __forceinline__ bool hann_tile_sums (double* lds, double (*tot)[HN_TH
 	__syncthreads ();
 	if (PADS) PK_STAMP (lds, 1);                                   // staged (the tile's loads have landed)
 
-	// ---- phase 0: the E taps at either end of each of the 16 windows, directly
-#pragma unroll
-	for (int s=0 ; s<HN_G ; s++) acc[s] = 0.0;
-	if ((G::E > 0) && live)
+	// ---- phase 0: the E taps at either end of each of the 16 windows, directly.  LATE0: behind phase 2 -- the same
+	//      operations in the same order, added to the middle stretch's sum as before; only their sixteen sums do not sit
+	//      in registers through phases 1 and 2 (with them the block sums need 146 registers: three waves per SIMD)
+	auto edge_taps = [&] (double (&e)[HN_G])
 		{
-		const double* xl = lds + (p - G::HALO_L) * HN_PITCH;        // element b'-BACK of s=0 is xl[LO]
 #pragma unroll
-		for (int j=0 ; j<G::NEDGE ; j++)                            // window s meets input j under tap k = j-s+1
+		for (int s=0 ; s<HN_G ; s++) e[s] = 0.0;
+		if ((G::E > 0) && live)
 			{
-			const int    o = G::LO + j;
-			const double x = xl[o + (o >> 4)];
+			const double* xl = lds + (p - G::HALO_L) * HN_PITCH;        // element b'-BACK of s=0 is xl[LO]
 #pragma unroll
-			for (int s=0 ; s<HN_G ; s++)
-				{ if ((j - s >= 0) && (j - s < G::E)) acc[s] = __builtin_fma (K.edge[j-s], x, acc[s]); }
+			for (int j=0 ; j<G::NEDGE ; j++)                            // window s meets input j under tap k = j-s+1
+				{
+				const int    o = G::LO + j;
+				const double x = xl[o + (o >> 4)];
+#pragma unroll
+				for (int s=0 ; s<HN_G ; s++)
+					{ if ((j - s >= 0) && (j - s < G::E)) e[s] = __builtin_fma (K.edge[j-s], x, e[s]); }
+				}
+			const double* xr = lds + p * HN_PITCH;                      // element b'+m of window s is xr[s+m]
+#pragma unroll
+			for (int j=1 ; j<=G::NEDGE ; j++)                           // tap W+1-m = tap m from the far end
+				{
+				const double x = xr[j + (j >> 4)];
+#pragma unroll
+				for (int s=0 ; s<HN_G ; s++)
+					{ if ((j - s >= 1) && (j - s <= G::E)) e[s] = __builtin_fma (K.edge[G::E - (j-s)], x, e[s]); }
+				}
 			}
-		const double* xr = lds + p * HN_PITCH;                      // element b'+m of window s is xr[s+m]
-#pragma unroll
-		for (int j=1 ; j<=G::NEDGE ; j++)                           // tap W+1-m = tap m from the far end
-			{
-			const double x = xr[j + (j >> 4)];
-#pragma unroll
-			for (int s=0 ; s<HN_G ; s++)
-				{ if ((j - s >= 1) && (j - s <= G::E)) acc[s] = __builtin_fma (K.edge[G::E - (j-s)], x, acc[s]); }
-			}
-		}
+		};
+	static_assert (!(LATE0 && RAW), "RAW leaves no direct taps to add");
+	if (!LATE0) edge_taps (acc);
 
 	// ---- phase 1: prefix sums of the own block in the own phase
 	double P0[HN_G], Pr[HN_G], Pi[HN_G];
@@ -315,7 +322,7 @@ __device__ __forceinline__ bool hann_tile_sums (double* lds, double (*tot)[HN_TH
 				const double zr = (sr + Tr) + qr;
 				const double zi = (si + Ti) + qi;
 				const double c  = __builtin_fma (K.demC[u], zr, -(K.demS[u] * zi));
-				acc[u] = RAW? ((EE == 0)? (z0 - c) : ((z0 - c) + acc[u])) : K.scale * ((z0 - c) + acc[u]);
+				acc[u] = RAW? ((EE == 0)? (z0 - c) : ((z0 - c) + acc[u])) : LATE0? (z0 - c) : K.scale * ((z0 - c) + acc[u]);
 				}
 			}
 		T0 += s0;  Tr += sr;  Ti += si;                            // that block is whole for the remaining windows
@@ -333,7 +340,15 @@ __device__ __forceinline__ bool hann_tile_sums (double* lds, double (*tot)[HN_TH
 			const double zr = (sr + Tr) + qr;
 			const double zi = (si + Ti) + qi;
 			const double c  = __builtin_fma (K.demC[u], zr, -(K.demS[u] * zi));
-			acc[u] = RAW? ((EE == 0)? (z0 - c) : ((z0 - c) + acc[u])) : K.scale * ((z0 - c) + acc[u]);
+			acc[u] = RAW? ((EE == 0)? (z0 - c) : ((z0 - c) + acc[u])) : LATE0? (z0 - c) : K.scale * ((z0 - c) + acc[u]);
+			}
+		if (LATE0)
+			{
+			__builtin_amdgcn_sched_barrier (0);                      // (the direct taps behind the walk, not among its last steps: registers)
+			double e[HN_G];
+			edge_taps (e);
+#pragma unroll
+			for (int u=0 ; u<HN_G ; u++) acc[u] = K.scale * (acc[u] + e[u]);
 			}
 		}
 	return direct;
