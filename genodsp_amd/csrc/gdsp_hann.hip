@@ -24,7 +24,8 @@
 //            the suffix sums and finishing one output per step.
 // Elements sit in LDS with a pitch of 17 per block of 16, so the lane-strided ds_read_b64 of
 // all walks are conflict free; results return through the same LDS image for 16-byte coalesced
-// stores.  41 KiB of LDS per workgroup (3 workgroups per CU).
+// stores.  40 KiB of LDS per workgroup to the byte and 128 registers: 4 workgroups per CU (round 5; 41 KiB, 146 registers
+// and 3 until then: hann_blocks_tile below).
 //
 // Not bit-identical to the reference (different association, exact cosines instead of the
 // normalised taps' roundings): within the north star's one rounding per floating-point
